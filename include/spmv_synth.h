@@ -1,0 +1,148 @@
+/*
+ * spmv_synth.h -- deterministic synthetic sparse matrices and vectors.
+ *
+ * The reference has no generators: it only reads Matrix Market text
+ * (reference src/csr.c:31-171, ~0.6 us per entry).  BASELINE.json's GPU
+ * configs are synthetic (1M banded, 10M random), so the workload is
+ * DEFINED here, once, as counter-based functions of (seed, row, slot).
+ * Every row can be produced independently, on the host, inside the
+ * oracle, inside the reference harness and on the device, and all of
+ * them get the same bits.  Header only; C99 / C++ / HIP.
+ *
+ * Matrix families (rows have their columns in ascending order; duplicate
+ * columns are kept, as the reference loader keeps them):
+ *   SYNTH_BANDED  row i has K entries at columns s..s+K-1,
+ *                 s = clamp(i - K/2, 0, N-K).                (config 2)
+ *   SYNTH_RANDOM  row i has K entries, columns uniform in the window
+ *                 [i - W/2, i + W/2) clipped to [0, N); W >= 2N means
+ *                 "anywhere".                                (config 3, 5)
+ *   SYNTH_RAGGED  as SYNTH_RANDOM, but the row length is uniform in
+ *                 [K - K/4, K + K/4] (mean K): exercises HLL padding.
+ *   SYNTH_KKT     irregular: most rows short (K/4..K/2), every 64th row a
+ *                 long row of 8K entries, KKT-like arrow structure
+ *                 (stand-in for nlpkkt160, config 4, which cannot be
+ *                 downloaded here).
+ * Values are uniform in [-1, 1); x is uniform in [0, 1).
+ */
+#ifndef SPMV_SYNTH_H
+#define SPMV_SYNTH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SYNTH_FN __host__ __device__ static inline
+#else
+#define SYNTH_FN static inline
+#endif
+
+enum synth_kind {
+    SYNTH_BANDED = 0,
+    SYNTH_RANDOM = 1,
+    SYNTH_RAGGED = 2,
+    SYNTH_KKT = 3
+};
+
+typedef struct synth_spec {
+    int kind;       /* enum synth_kind */
+    int M, N;       /* logical shape of the (shard of the) matrix */
+    int K;          /* nominal entries per row */
+    int64_t W;      /* column window for the random families */
+    int64_t row0;   /* global index of local row 0 (multi-GPU shards) */
+    uint64_t seed;  /* matrix seed (42 in BASELINE configs) */
+} synth_spec;
+
+/* splitmix64 finaliser over a 64-bit counter */
+SYNTH_FN uint64_t synth_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+SYNTH_FN uint64_t synth_hash2(uint64_t seed, uint64_t a, uint64_t b) {
+    return synth_mix(synth_mix(seed ^ (a * 0xD1342543DE82EF95ull)) + b);
+}
+
+/* 53-bit uniform in [0,1) */
+SYNTH_FN double synth_u01(uint64_t h) {
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* x vector element (seed 7 in BASELINE configs), global index */
+SYNTH_FN double synth_x(uint64_t seed, int64_t idx) {
+    return synth_u01(synth_hash2(seed, 0x78u, (uint64_t)idx));
+}
+
+/* number of entries of GLOBAL row g */
+SYNTH_FN int synth_row_len(const synth_spec *s, int64_t g) {
+    switch (s->kind) {
+    case SYNTH_BANDED:
+    case SYNTH_RANDOM:
+        return s->K;
+    case SYNTH_RAGGED: {
+        int q = s->K / 4;
+        uint64_t h = synth_hash2(s->seed, 0x6c656eu, (uint64_t)g);
+        return s->K - q + (int)(h % (uint64_t)(2 * q + 1));
+    }
+    default: { /* SYNTH_KKT */
+        if ((g & 63) == 17)
+            return 8 * s->K;
+        int lo = s->K / 4, span = s->K / 4 + 1;
+        uint64_t h = synth_hash2(s->seed, 0x6b6b74u, (uint64_t)g);
+        return lo + (int)(h % (uint64_t)span);
+    }
+    }
+}
+
+/* value of slot j of GLOBAL row g, uniform in [-1,1) */
+SYNTH_FN double synth_val(const synth_spec *s, int64_t g, int j) {
+    uint64_t h = synth_hash2(s->seed ^ 0x76616cull, (uint64_t)g, (uint64_t)j);
+    return 2.0 * synth_u01(h) - 1.0;
+}
+
+/* unsorted column draw t of GLOBAL row g for the random families */
+SYNTH_FN int synth_col_draw(const synth_spec *s, int64_t g, int t) {
+    int64_t half = s->W / 2;
+    int64_t lo = g - half, hi = g + (s->W - half);
+    if (lo < 0)
+        lo = 0;
+    if (hi > s->N)
+        hi = s->N;
+    if (lo >= hi) { /* window fell off the right edge (M > N shards) */
+        lo = 0;
+        hi = s->N;
+    }
+    uint64_t h = synth_hash2(s->seed ^ 0x636f6cull, (uint64_t)g, (uint64_t)t);
+    return (int)(lo + (int64_t)(synth_u01(h) * (double)(hi - lo)));
+}
+
+/*
+ * Fill one row: cols[0..len) ascending, vals[0..len).  `len` must be
+ * synth_row_len(s, g).  Insertion sort: rows are short (K ~ 16..256).
+ */
+SYNTH_FN void synth_fill_row(const synth_spec *s, int64_t g, int len,
+                             int *cols, double *vals) {
+    if (s->kind == SYNTH_BANDED) {
+        int64_t st = g - s->K / 2;
+        if (st > (int64_t)s->N - len)
+            st = (int64_t)s->N - len;
+        if (st < 0)
+            st = 0;
+        for (int j = 0; j < len; ++j)
+            cols[j] = (int)(st + j);
+    } else {
+        for (int t = 0; t < len; ++t) {
+            int c = synth_col_draw(s, g, t);
+            int p = t;
+            while (p > 0 && cols[p - 1] > c) {
+                cols[p] = cols[p - 1];
+                --p;
+            }
+            cols[p] = c;
+        }
+    }
+    for (int j = 0; j < len; ++j)
+        vals[j] = synth_val(s, g, j);
+}
+
+#endif /* SPMV_SYNTH_H */

@@ -1,0 +1,347 @@
+/*
+ * ref_harness.c -- drives the REFERENCE's own CPU code (test infrastructure).
+ *
+ * This file is compiled together with the reference's C sources where they
+ * lie under /root/reference/src (csr.c, hll.c, vector.c, utils.c, mmio.c) by
+ * oracle/build_ref.sh; the result goes to oracle/_ref/ (git-ignored).  No
+ * reference source is copied and nothing is stubbed: the CUDA entry points
+ * that csr.c/hll.c mention are only reachable from bench_*_cuda_* wrappers,
+ * which this harness never calls, so the linker drops those sections
+ * (-ffunction-sections -Wl,--gc-sections) together with their undefined
+ * symbols.
+ *
+ * Uses only the reference's public API (include/csr.h, hll.h, vector.h,
+ * utils.h, err.h):
+ *   dump  <file.mtx>         io_load_csr -> csr_to_hll(row,col) -> x from
+ *                            vec_fill_random -> bench_csr_serial /
+ *                            bench_hll_serial; prints every array.
+ *   err   <file.mtx>         prints the loader's error code.
+ *   synth <kind> <M> <N> <K> <W> <seed> <xseed> <nsample>
+ *                            fills a sparse_csr from include/spmv_synth.h,
+ *                            runs the reference serial CSR + HLL kernels and
+ *                            prints a strided sample of y + a checksum.
+ *   time  <kind> <M> <N> <K> <W> <seed> <xseed> <reps> <thr> [<thr>...]
+ *                            CPU baseline: reference serial + OpenMP benches
+ *                            timed on the host cores (JSON on stdout).
+ *
+ * Doubles are printed as C99 hex floats (%a): exact round trip.
+ */
+#include <errno.h>
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "csr.h"
+#include "err.h"
+#include "hll.h"
+#include "utils.h"
+#include "vector.h"
+
+#include "../include/spmv_synth.h"
+
+static void put_ints(const char *key, const int *v, long n) {
+    printf("%s %ld", key, n);
+    for (long i = 0; i < n; ++i)
+        printf(" %d", v[i]);
+    printf("\n");
+}
+
+static void put_dbls(const char *key, const double *v, long n) {
+    printf("%s %ld", key, n);
+    for (long i = 0; i < n; ++i)
+        printf(" %a", v[i]);
+    printf("\n");
+}
+
+static void put_hll(const char *tag, const sparse_hll *H) {
+    printf("%s.hdr 5 %d %d %d %d %d\n", tag, H->M, H->N, H->NZ, H->hack_size,
+           H->num_blocks);
+    for (int b = 0; b < H->num_blocks; ++b) {
+        const ellpack_block *blk = &H->blocks[b];
+        char key[64];
+        long len = (long)blk->M * blk->max_NZ;
+        printf("%s.blk%d 4 %d %d %d %d\n", tag, b, blk->M, blk->N, blk->NZ,
+               blk->max_NZ);
+        snprintf(key, sizeof key, "%s.blk%d.JA", tag, b);
+        put_ints(key, blk->JA, len);
+        snprintf(key, sizeof key, "%s.blk%d.AS", tag, b);
+        put_dbls(key, blk->AS, len);
+    }
+}
+
+static int cmd_dump(const char *path) {
+    sparse_csr *A = io_load_csr(path);
+    if (IS_ERR(A)) {
+        printf("error 1 %d\n", PTR_ERR(A));
+        return 0;
+    }
+    printf("name %s\n", A->name);
+    printf("shape 3 %d %d %d\n", A->M, A->N, A->NZ);
+    put_ints("IRP", A->IRP, (long)A->M + 1);
+    put_ints("JA", A->JA, A->NZ);
+    put_dbls("AS", A->AS, A->NZ);
+
+    sparse_hll *Hr = csr_to_hll(A, false);
+    sparse_hll *Hc = csr_to_hll(A, true);
+    if (IS_ERR(Hr) || IS_ERR(Hc)) {
+        printf("error 1 %d\n", -ENOMEM);
+        return 0;
+    }
+    put_hll("hll_row", Hr);
+    put_hll("hll_col", Hc);
+
+    vec x = vec_create((size_t)A->N);
+    vec_fill_random(&x); /* glibc rand(), never seeded == srand(1) */
+    put_dbls("x", x.data, (long)x.len);
+
+    bench rc, rh;
+    if (bench_csr_serial(A, x.data, &rc) || bench_hll_serial(Hr, x.data, &rh))
+        return 2;
+    put_dbls("y_csr_serial", rc.data.data, (long)rc.data.len);
+    put_dbls("y_hll_serial", rh.data.data, (long)rh.data.len);
+    printf("validate 1 %d\n", validation_vec_result(rc.data, rh.data));
+    printf("gflops_probe 1 %a\n", compute_gflops(2.0, A->NZ));
+
+    bench_omp og = {.num_threads = 2}, on = {.num_threads = 2},
+              oh = {.num_threads = 2};
+    if (bench_csr_omp_guided(A, x.data, &og) ||
+        bench_csr_omp_nnz_balancing(A, x.data, &on) ||
+        bench_hll_omp(Hr, x.data, &oh))
+        return 2;
+    put_dbls("y_csr_omp_guided", og.bench.data.data, (long)og.bench.data.len);
+    put_dbls("y_csr_omp_nnz", on.bench.data.data, (long)on.bench.data.len);
+    put_dbls("y_hll_omp", oh.bench.data.data, (long)oh.bench.data.len);
+    printf("omp_names %s %s %s\n", og.name, on.name, oh.name);
+    printf("omp_nnz_threads 1 %d\n", on.num_threads);
+
+    vec_put(&rc.data);
+    vec_put(&rh.data);
+    vec_put(&og.bench.data);
+    vec_put(&on.bench.data);
+    vec_put(&oh.bench.data);
+    vec_put(&x);
+    hll_free(Hr);
+    hll_free(Hc);
+    csr_free(A);
+    return 0;
+}
+
+static int cmd_err(const char *path) {
+    sparse_csr *A = io_load_csr(path);
+    if (IS_ERR(A)) {
+        printf("error 1 %d\n", PTR_ERR(A));
+    } else {
+        printf("error 1 0\n");
+        csr_free(A);
+    }
+    return 0;
+}
+
+/* Build a reference sparse_csr from the shared synthetic definition. */
+static sparse_csr *synth_csr(const synth_spec *s) {
+    int M = s->M;
+    int *IRP = aligned_malloc(((size_t)M + 1) * sizeof(int));
+    if (!IRP)
+        return NULL;
+    long nz = 0;
+    IRP[0] = 0;
+    for (int i = 0; i < M; ++i) {
+        nz += synth_row_len(s, s->row0 + i);
+        IRP[i + 1] = (int)nz;
+    }
+    int *JA = aligned_malloc((size_t)nz * sizeof(int));
+    double *AS = aligned_malloc((size_t)nz * sizeof(double));
+    sparse_csr *A = malloc(sizeof *A);
+    if (!JA || !AS || !A)
+        return NULL;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; ++i)
+        synth_fill_row(s, s->row0 + i, IRP[i + 1] - IRP[i], JA + IRP[i],
+                       AS + IRP[i]);
+    init_csr(A, "synthetic", M, s->N, (int)nz, IRP, JA, AS);
+    return A;
+}
+
+static int parse_spec(char **a, synth_spec *s, uint64_t *xseed) {
+    s->kind = atoi(a[0]);
+    s->M = atoi(a[1]);
+    s->N = atoi(a[2]);
+    s->K = atoi(a[3]);
+    s->W = atoll(a[4]);
+    s->seed = strtoull(a[5], NULL, 10);
+    s->row0 = 0;
+    *xseed = strtoull(a[6], NULL, 10);
+    return 0;
+}
+
+static int cmd_synth(char **a) {
+    synth_spec s;
+    uint64_t xseed;
+    parse_spec(a, &s, &xseed);
+    int nsample = atoi(a[7]);
+    sparse_csr *A = synth_csr(&s);
+    if (!A)
+        return 2;
+    vec x = vec_create((size_t)s.N);
+    for (int i = 0; i < s.N; ++i)
+        x.data[i] = synth_x(xseed, i);
+    sparse_hll *H = csr_to_hll(A, false);
+    bench rc, rh;
+    if (IS_ERR(H) || bench_csr_serial(A, x.data, &rc) ||
+        bench_hll_serial(H, x.data, &rh))
+        return 2;
+    printf("shape 3 %d %d %d\n", A->M, A->N, A->NZ);
+    long stride = nsample > 0 ? (A->M + nsample - 1) / nsample : 1;
+    if (stride < 1)
+        stride = 1;
+    printf("stride 1 %ld\n", stride);
+    printf("y_csr_serial_sample");
+    long cnt = 0;
+    for (long i = 0; i < A->M; i += stride)
+        ++cnt;
+    printf(" %ld", cnt);
+    for (long i = 0; i < A->M; i += stride)
+        printf(" %a", rc.data.data[i]);
+    printf("\n");
+    double sum = 0.0, asum = 0.0;
+    int same = 1;
+    for (int i = 0; i < A->M; ++i) {
+        sum += rc.data.data[i];
+        asum += rc.data.data[i] < 0 ? -rc.data.data[i] : rc.data.data[i];
+        if (rc.data.data[i] != rh.data.data[i])
+            same = 0;
+    }
+    printf("y_sum 1 %a\n", sum);
+    printf("y_abs_sum 1 %a\n", asum);
+    printf("hll_bit_equal 1 %d\n", same);
+    return 0;
+}
+
+static double wall_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+static int cmp_d(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+static double median(double *v, int n) {
+    qsort(v, (size_t)n, sizeof *v, cmp_d);
+    return (n & 1) ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+}
+
+/*
+ * CPU baseline: the reference's own serial and OpenMP benches (single shot
+ * each, as the reference times them: clock() for serial, omp_get_wtime()
+ * for OpenMP) repeated `reps` times; we report the first (cold, the
+ * reference's own protocol) and the median.
+ */
+static int cmd_time(int argc, char **a) {
+    synth_spec s;
+    uint64_t xseed;
+    parse_spec(a, &s, &xseed);
+    int reps = atoi(a[7]);
+    if (reps < 1)
+        reps = 1;
+    if (reps > 64)
+        reps = 64;
+    double t0 = wall_ms();
+    sparse_csr *A = synth_csr(&s);
+    if (!A)
+        return 2;
+    vec x = vec_create((size_t)s.N);
+    for (int i = 0; i < s.N; ++i)
+        x.data[i] = synth_x(xseed, i);
+    sparse_hll *H = csr_to_hll(A, false);
+    if (IS_ERR(H))
+        return 2;
+    double t_prep = wall_ms() - t0;
+    double d[64];
+
+    printf("{\"rows\": %d, \"cols\": %d, \"nnz\": %d, \"prep_ms\": %.3f, "
+           "\"omp_max_threads\": %d, \"procs\": %d, \"runs\": [",
+           A->M, A->N, A->NZ, t_prep, omp_get_max_threads(),
+           omp_get_num_procs());
+    int first = 1;
+#define EMIT(fmt_, bench_, thr_)                                               \
+    do {                                                                       \
+        double cold = d[0];                                                    \
+        double med = median(d, reps);                                          \
+        printf("%s{\"format\": \"%s\", \"bench\": \"%s\", \"threads\": %d, "   \
+               "\"cold_ms\": %.6f, \"median_ms\": %.6f, \"gflops\": %.6f}",    \
+               first ? "" : ", ", fmt_, bench_, thr_, cold, med,               \
+               compute_gflops(med, A->NZ));                                    \
+        first = 0;                                                             \
+    } while (0)
+
+    for (int r = 0; r < reps; ++r) {
+        bench b;
+        if (bench_csr_serial(A, x.data, &b))
+            return 2;
+        d[r] = b.duration_ms;
+        vec_put(&b.data);
+    }
+    EMIT("CSR", "serial", 1);
+    for (int r = 0; r < reps; ++r) {
+        bench b;
+        if (bench_hll_serial(H, x.data, &b))
+            return 2;
+        d[r] = b.duration_ms;
+        vec_put(&b.data);
+    }
+    EMIT("HLL", "serial", 1);
+
+    for (int k = 8; k < argc; ++k) {
+        int thr = atoi(a[k]);
+        if (thr < 1 || thr > omp_get_max_threads())
+            continue; /* reference asserts on this (hll.c:184, csr.c:320) */
+        OMP_WARMUP(thr);
+        for (int r = 0; r < reps; ++r) {
+            bench_omp b = {.num_threads = thr};
+            if (bench_csr_omp_guided(A, x.data, &b))
+                return 2;
+            d[r] = b.bench.duration_ms;
+            vec_put(&b.bench.data);
+        }
+        EMIT("CSR", "omp_guided", thr);
+        int used = thr;
+        for (int r = 0; r < reps; ++r) {
+            bench_omp b = {.num_threads = thr};
+            if (bench_csr_omp_nnz_balancing(A, x.data, &b))
+                return 2;
+            d[r] = b.bench.duration_ms;
+            used = b.num_threads;
+            vec_put(&b.bench.data);
+        }
+        EMIT("CSR", "omp_nnz", used);
+        for (int r = 0; r < reps; ++r) {
+            bench_omp b = {.num_threads = thr};
+            if (bench_hll_omp(H, x.data, &b))
+                return 2;
+            d[r] = b.bench.duration_ms;
+            vec_put(&b.bench.data);
+        }
+        EMIT("HLL", "omp_guided", thr);
+    }
+    printf("]}\n");
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 3 && !strcmp(argv[1], "dump"))
+        return cmd_dump(argv[2]);
+    if (argc >= 3 && !strcmp(argv[1], "err"))
+        return cmd_err(argv[2]);
+    if (argc >= 10 && !strcmp(argv[1], "synth"))
+        return cmd_synth(argv + 2);
+    if (argc >= 10 && !strcmp(argv[1], "time"))
+        return cmd_time(argc - 2, argv + 2);
+    fprintf(stderr, "usage: %s dump|err <file.mtx> | synth ... | time ...\n",
+            argv[0]);
+    return 64;
+}
