@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X SpMV engine.
+
+Metric (BASELINE.json): fp64 SpMV GFLOP/s + achieved HBM GB/s (% of the
+8 TB/s roofline) at 1/2/4/8 MI355X.  Workload (BASELINE.json configs[2], the
+one the >=60 %-of-roofline target is quoted on; configs[4] at 8 GPUs):
+synthetic random HLL, hack 32, 32 nnz/row, 10M rows PER GPU (weak scaling),
+N = 10M x n_gpus columns, rows partitioned by contiguous ranges, x replicated,
+every rank computes its y fragment with the HLL kernel and the fragments are
+all-gathered in place over RCCL (torch.distributed backend "nccl").
+
+A step = one SpMV over the whole matrix (+ the all-gather of y when N > 1),
+inputs resident in HBM.  value = 2 * nnz_global / step time, in GFLOP/s
+(reference definition, include/utils.h:70-75).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ROWS_PER_GPU = 10_000_000
+NNZ_PER_ROW = 32
+MATRIX_SEED, X_SEED = 42, 7
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
+    ap.add_argument("--nnz-row", type=int, default=NNZ_PER_ROW)
+    ap.add_argument("--window", type=int, default=0,
+                    help="column window W of the random family; 0 = N "
+                         "(columns anywhere: the worst case)")
+    ap.add_argument("--family", default="random",
+                    choices=["banded", "random", "ragged", "kkt"])
+    ap.add_argument("--format", default="hll", choices=["hll", "csr"])
+    ap.add_argument("--kernel", type=int, default=-1,
+                    help="kernel id (hip_hll.h / hip_csr.h); -1 = default")
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="N>1: split each shard into row chunks and overlap "
+                         "the all-gather of chunk c with the kernel of c+1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(family, K, W):
+    """The reference's own serial + OpenMP CPU path (oracle/_ref/ref_fast,
+    built from /root/reference/src by oracle/build_ref.sh) on a bounded
+    sample of the same workload; falls back to the oracle port."""
+    rows = 2_000_000
+    kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3}[family]
+    cores = os.cpu_count() or 1
+    sample = ("%s %dx%d, %d nnz/row, W=%d (same generator, %d of the %d rows)"
+              % (family, rows, rows, K, W, rows, ROWS_PER_GPU))
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_fast")
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close",
+               OMP_PLACES="cores")
+    if os.path.exists(ref):
+        try:
+            out = subprocess.run(
+                [ref, "time", str(kind), str(rows), str(rows), str(K), str(W),
+                 str(MATRIX_SEED), str(X_SEED), "3", str(cores)],
+                capture_output=True, text=True, timeout=600, env=env, check=True)
+            runs = json.loads(out.stdout)["runs"]
+            best = max(runs, key=lambda r: r["gflops"])
+            serial = [r for r in runs if r["bench"] == "serial"
+                      and r["format"] == "CSR"][0]
+            return {"value": round(best["gflops"], 3), "unit": "GFLOP/s",
+                    "cores": best["threads"], "kind": "reference",
+                    "sample": sample,
+                    "best": "%s %s" % (best["format"], best["bench"]),
+                    "serial_csr_gflops": round(serial["gflops"], 3),
+                    "host_cores": cores, "runs": runs}
+        except Exception as e:  # pragma: no cover - depends on the box
+            err = "ref_fast failed: %r" % (e,)
+    else:
+        err = "oracle/_ref/ref_fast not present"
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    IRP, JA, AS = O.synth_csr(kind, rows, rows, K, W, MATRIX_SEED)
+    x = O.synth_x(X_SEED, 0, rows)
+    ms1 = O.time_csr_ms(IRP, JA, AS, x, 1, 3)
+    msn = O.time_csr_ms(IRP, JA, AS, x, cores, 3)
+    best_ms, thr = (ms1, 1) if ms1 <= msn else (msn, cores)
+    return {"value": round(2.0 * len(JA) / (best_ms * 1e6), 3),
+            "unit": "GFLOP/s", "cores": thr, "kind": "port", "sample": sample,
+            "note": err, "host_cores": cores}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import spmv_scpa_amd as S
+    from spmv_scpa_amd import dist as D
+
+    if not torch.cuda.is_available() or S.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: no GPU visible "
+                         "(there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    S.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    Mloc, K = args.rows_per_gpu, args.nnz_row
+    Mglob = Mloc * world
+    Nglob = Mglob
+    W = args.window if args.window > 0 else 2 * Nglob  # >= 2N: anywhere
+    kind = {"banded": S.SYNTH_BANDED, "random": S.SYNTH_RANDOM,
+            "ragged": S.SYNTH_RAGGED, "kkt": S.SYNTH_KKT}[args.family]
+    row0 = rank * Mloc
+
+    # ---- build the shard in HBM (device-side generator + converter) ----
+    t_setup = time.time()
+    dA = S.CsrDevice.generate(kind, Mloc, Nglob, K, W, row0, MATRIX_SEED)
+    if args.format == "hll":
+        kernel = args.kernel if args.kernel >= 0 else 1
+        mat = dA.to_hll(S.HLL_KERNEL_COL_MAJOR[kernel])
+        nnz_local, slots = dA.NZ, mat.slots
+        dA.release()
+        kname = "hll_" + S.HLL_KERNEL_NAMES[kernel]
+    else:
+        kernel = args.kernel if args.kernel >= 0 else 2
+        mat = dA
+        nnz_local, slots = dA.NZ, dA.NZ
+        kname = "csr_" + S.CSR_KERNEL_NAMES[kernel]
+    alg_bytes = mat.algorithmic_bytes  # per launch, per GPU
+
+    x = torch.empty(Nglob, dtype=torch.float64, device=dev)
+    y = torch.zeros(Mglob, dtype=torch.float64, device=dev)
+    S.dev_fill_synth(x.data_ptr(), Nglob, X_SEED, 0,
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    sharded = D.ShardedSpmv(mat, kernel, rank, world, Mloc, x, y,
+                            waves_per_block=args.waves, chunks=args.chunks)
+
+    # ---- correctness spot check against the counter-based definition ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    sharded.step()
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(1234 + rank)
+    rows = np.concatenate([[0, Mloc - 1], rng.integers(0, Mloc, 256)])
+    got = y[row0 + torch.as_tensor(rows, device=dev)].cpu().numpy()
+    for g, r in zip(got, rows):
+        want, scale = O.synth_row_dot(kind, Mloc, Nglob, K, W, row0,
+                                      MATRIX_SEED, X_SEED, row0 + int(r))
+        if abs(g - want) > 1e-6 * max(abs(want), 1e-3 * scale):
+            raise SystemExit("parity check failed on row %d: %r vs %r"
+                             % (row0 + r, g, want))
+
+    # ---- warm-up, then EXACTLY K timed steps ----
+    for _ in range(args.warmup):
+        sharded.step()
+    ev = [(torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        sharded.step(events=ev[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    nnz_global = nnz_local * world
+    value = 2.0 * nnz_global / (ms_per_step * 1e6)
+    kavg = float(np.mean(kern_ms))
+    achieved = alg_bytes / (kavg * 1e6)  # GB/s, this rank's kernel
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), "
+                  "1/2/4/8 MI355X",
+        "value": round(value, 2),
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s %s %dx%d per GPU (%dx%d global), hack 32, "
+                        "%d nnz/row, column window W=%s, seed %d"
+                        % (args.family, args.format.upper(), Mloc, Nglob, Mglob,
+                           Nglob, K, "N (anywhere)" if args.window <= 0
+                           else str(W), MATRIX_SEED),
+            "kernel": kname,
+            "rows_per_gpu": Mloc, "nnz_per_row": K, "nnz_global": nnz_global,
+            "stored_slots_per_gpu": slots,
+            "partition": "contiguous row ranges, x replicated, in-place "
+                         "all-gather(y) over RCCL" if world > 1 else "single GPU",
+            "chunks": args.chunks,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "kernel": kname,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_avg": round(kavg, 5),
+            "kernel_ms_min": round(float(np.min(kern_ms)), 5),
+            "kernel_gflops": round(2.0 * nnz_local / (kavg * 1e6), 2),
+        },
+        "setup_s": round(t_setup, 2),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.family, K, W)
+    if world == 1 and not args.no_extras:
+        out["extras"] = D.extra_measurements(S, torch, mat, args, x, y, Mloc,
+                                             Nglob, K, kind)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+/*
+ * hip_csr.h -- C-ABI of the CSR SpMV kernels for MI355X (gfx950).
+ *
+ * Replaces the reference's include/cuda_csr.h:10-25.  Same seam: plain
+ * extern "C" functions of the shape
+ *
+ *     double f(const sparse_csr *A, const double *x, double *y, void *arg);
+ *
+ * that the host layer passes as a function pointer to its benchmark harness
+ * (reference csr.c:182-199).  Contract:
+ *   - A, x (A->N doubles) and y (A->M doubles) are HOST memory owned by the
+ *     caller; the callee uploads, launches, downloads y and releases every
+ *     device allocation before returning (reference cuda_csr.cu:180-205);
+ *   - the return value is the kernel time in milliseconds measured with a
+ *     hipEvent pair on the launch stream (reference cuda_timer.cu:15-21),
+ *     or a NEGATIVE errno (-ENODEV no GPU, -ENOMEM, -EIO launch/copy fault):
+ *     the reference has no error channel; here every HIP call is checked;
+ *   - `arg` may be NULL, or point to a spmv_launch_opts (spmv_engine.h)
+ *     overriding the per-process default set by set_csr_waves_per_block().
+ *
+ * Kernel ids (index into the driver table, as in reference main.c:259-263):
+ *   0 thread_row    one lane per row
+ *   1 wave_row      one 64-lane wavefront per row, __shfl_down tree
+ *   2 subwave_row   G = 2..32 lanes per row (G from mean row length),
+ *                   segmented __shfl_down reduction inside the wave
+ *   3 block_row     one workgroup per row (very long rows)
+ *   4 stream        nnz-balanced: a workgroup streams a fixed nnz budget
+ *                   through LDS, rows are reduced from LDS (takes the slot
+ *                   of the reference's texture-cache variant, which has no
+ *                   CDNA counterpart)
+ */
+#ifndef SPMV_HIP_CSR_H
+#define SPMV_HIP_CSR_H
+
+#include "csr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPMV_NUM_CSR_KERNELS 5
+
+/* Wavefronts (64 lanes) per workgroup for subsequent one-shot calls;
+ * valid 1..16, default 4.  (reference: set_csr_warps_per_block) */
+void set_csr_waves_per_block(int waves);
+
+double csr_spmv_hip_thread_row(const sparse_csr *A, const double *x, double *y,
+                               void *arg);
+double csr_spmv_hip_wave_row(const sparse_csr *A, const double *x, double *y,
+                             void *arg);
+double csr_spmv_hip_subwave_row(const sparse_csr *A, const double *x,
+                                double *y, void *arg);
+double csr_spmv_hip_block_row(const sparse_csr *A, const double *x, double *y,
+                              void *arg);
+double csr_spmv_hip_stream(const sparse_csr *A, const double *x, double *y,
+                           void *arg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_HIP_CSR_H */

@@ -1,0 +1,133 @@
+/*
+ * spmv_engine.h -- persistent device-side API under the one-shot entry
+ * points of hip_csr.h / hip_hll.h.
+ *
+ * The reference uploads the whole matrix on every call and times a single
+ * un-warmed launch (cuda_csr.cu:180-234; one cudaMalloc pair and three
+ * copies PER HACK BLOCK for HLL, cuda_hll.cu:161-206).  Here a matrix is
+ * uploaded once into a device handle, launched any number of times on a
+ * caller-supplied HIP stream with device-resident x and y, and released.
+ * The one-shot functions are thin wrappers over this API.
+ *
+ * Plain C ABI: opaque handles, raw device pointers (e.g. a torch tensor's
+ * data_ptr()), `void *stream` = hipStream_t (NULL = default stream).
+ * Every function returns 0 or a negative errno; nothing falls back to the
+ * CPU: without a GPU they return -ENODEV.
+ *
+ * Device layout
+ *   CSR   IRP int32[M+1], JA int32[NZ], AS f64[NZ]          (as on host)
+ *         + row-block table for the nnz-balanced stream kernel
+ *   HLL   ja int32[S], as f64[S]  one slab each, S = sum_b M_b*max_NZ_b,
+ *         block b at slot offset off[b]; off int64[nb+1]; pads rewritten
+ *         (hip_hll.h).  Row- or col-major inside a block, chosen at upload.
+ *
+ * Algorithmic bytes per launch (used for roofline.achieved):
+ *   CSR   12*NZ + 4*(M+1) + 8*M + 8*N
+ *   HLL   12*S + 12*nb + 8*M + 8*N
+ */
+#ifndef SPMV_ENGINE_H
+#define SPMV_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "csr.h"
+#include "hll.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmv_launch_opts {
+    int waves_per_block; /* 1..16; 0 = process default (set_*_waves_per_block) */
+    int group;           /* lanes per row of the sub-wave kernels; 0 = auto */
+    int reserved[6];     /* must be 0 */
+} spmv_launch_opts;
+
+/* ---- devices ---- */
+int spmv_device_count(void); /* 0 when there is no usable GPU */
+int spmv_set_device(int device);
+int spmv_get_device(void);   /* current device or negative errno */
+/* name (<= len-1 chars), compute units, HBM bytes */
+int spmv_device_info(int device, char *name, size_t len, int *compute_units,
+                     size_t *hbm_bytes);
+
+/* ---- raw device memory, for hosts without their own allocator ---- */
+int spmv_dev_malloc(void **dptr, size_t bytes);
+int spmv_dev_free(void *dptr);
+int spmv_dev_memset(void *dptr, int byte, size_t bytes, void *stream);
+int spmv_copy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int spmv_copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int spmv_stream_sync(void *stream);
+/* x[i] = synth_x(seed, first + i) generated on the device */
+int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
+                        void *stream);
+
+/* ---- CSR handle ---- */
+typedef struct spmv_csr_dev spmv_csr_dev;
+
+int spmv_csr_upload(const sparse_csr *A, spmv_csr_dev **out);
+/* Build a synthetic matrix (spmv_synth.h) directly in device memory. */
+int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
+                      uint64_t seed, spmv_csr_dev **out);
+/* y[0..M) = A * x on `stream`; asynchronous. kernel = 0..4 (hip_csr.h). */
+int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
+                    const spmv_launch_opts *opts, const double *d_x,
+                    double *d_y, void *stream);
+/* rows [row_begin, row_end) only; d_y still indexed from row 0 */
+int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
+                         const spmv_launch_opts *opts, const double *d_x,
+                         double *d_y, int row_begin, int row_end,
+                         void *stream);
+int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ);
+int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A);
+/* download the device arrays into a host CSR (tests; generated matrices) */
+int spmv_csr_download(const spmv_csr_dev *A, sparse_csr **out);
+void spmv_csr_release(spmv_csr_dev *A);
+
+/* ---- HLL handle ---- */
+typedef struct spmv_hll_dev spmv_hll_dev;
+
+int spmv_hll_upload(const sparse_hll *H, int is_col_major, spmv_hll_dev **out);
+/* CSR -> HLL conversion on the device (reference hll.c:19-95 semantics,
+ * pads already rewritten); the CSR handle stays valid. */
+int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
+                      spmv_hll_dev **out);
+/* kernel = 0..3 (hip_hll.h); the handle's layout must match the kernel
+ * (0,3 row-major; 1,2 col-major) else -EINVAL. */
+int spmv_hll_launch(const spmv_hll_dev *H, int kernel,
+                    const spmv_launch_opts *opts, const double *d_x,
+                    double *d_y, void *stream);
+/* hack blocks [blk_begin, blk_end) only */
+int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
+                           const spmv_launch_opts *opts, const double *d_x,
+                           double *d_y, int blk_begin, int blk_end,
+                           void *stream);
+int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
+                   int *num_blocks, int64_t *slots, int *is_col_major);
+int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H);
+void spmv_hll_release(spmv_hll_dev *H);
+
+/*
+ * Timed loops: `warmup` untimed launches, then `iters` launches each
+ * bracketed by its own hipEvent pair on `stream`; ms_each[iters] receives
+ * the per-launch kernel times.  flush_bytes > 0 streams a scratch buffer of
+ * that size between iterations (outside the timed region) so that matrices
+ * smaller than the 256 MiB Infinity Cache are read from HBM.
+ */
+int spmv_csr_time(const spmv_csr_dev *A, int kernel,
+                  const spmv_launch_opts *opts, const double *d_x, double *d_y,
+                  int warmup, int iters, size_t flush_bytes, double *ms_each,
+                  void *stream);
+int spmv_hll_time(const spmv_hll_dev *H, int kernel,
+                  const spmv_launch_opts *opts, const double *d_x, double *d_y,
+                  int warmup, int iters, size_t flush_bytes, double *ms_each,
+                  void *stream);
+
+/* Library self-description: "spmv_scpa_amd <version> gfx950". */
+const char *spmv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_ENGINE_H */

@@ -1,0 +1,673 @@
+"""spmv_scpa_amd -- Python face of the MI355X SpMV engine.
+
+A thin ctypes binding over ``lib/libspmv_scpa_amd.so`` (host C API + HIP
+kernels for gfx950 behind a C ABI; headers in ``include/``).  The names
+mirror the reference's C host API (``io_load_csr``, ``csr_to_hll``,
+``bench_csr_serial`` ... reference include/csr.h:29-49, hll.h:54-70) so the
+tests read like calls into the reference.
+
+There is no Python or CPU fallback for the GPU path: if the shared library
+is missing the import fails, and without a GPU every ``*_hip`` call raises
+``OSError(ENODEV)``.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libspmv_scpa_amd.so")
+INCLUDE_DIR = os.path.join(ROOT, "include")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "%s not found: build it with `python -c 'import __graft_entry__ as g; "
+        "g.build()'` (make -C spmv_scpa_amd/csrc). There is no fallback path."
+        % LIB_PATH)
+_lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+MAX_NAME = 64
+HACK_SIZE = 32
+SYNTH_BANDED, SYNTH_RANDOM, SYNTH_RAGGED, SYNTH_KKT = 0, 1, 2, 3
+NUM_CSR_KERNELS = 5
+NUM_HLL_KERNELS = 4
+CSR_KERNEL_NAMES = ["thread_row", "wave_row", "subwave_row", "block_row",
+                    "stream"]
+HLL_KERNEL_NAMES = ["threads_row_major", "threads_col_major", "wave_block",
+                    "subwave_row"]
+#: layout each HLL kernel expects (reference main.c:324-325)
+HLL_KERNEL_COL_MAJOR = [False, True, True, False]
+
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(C.c_double)
+
+
+# ---------------------------------------------------------------- structs
+class SparseCSR(C.Structure):
+    _fields_ = [("name", C.c_char * MAX_NAME), ("M", C.c_int), ("N", C.c_int),
+                ("NZ", C.c_int), ("IRP", _ip), ("JA", _ip), ("AS", _dp)]
+
+
+class EllpackBlock(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("NZ", C.c_int),
+                ("max_NZ", C.c_int), ("JA", _ip), ("AS", _dp)]
+
+
+class SparseHLL(C.Structure):
+    _fields_ = [("name", C.c_char * MAX_NAME), ("M", C.c_int), ("N", C.c_int),
+                ("NZ", C.c_int), ("hack_size", C.c_int),
+                ("num_blocks", C.c_int), ("blocks", C.POINTER(EllpackBlock))]
+
+
+class Vec(C.Structure):
+    _fields_ = [("len", C.c_size_t), ("data", _dp)]
+
+
+class Bench(C.Structure):
+    _fields_ = [("duration_ms", C.c_double), ("gflops", C.c_double),
+                ("data", Vec)]
+
+
+class BenchOmp(C.Structure):
+    _fields_ = [("bench", Bench), ("name", C.c_char * MAX_NAME),
+                ("num_threads", C.c_int)]
+
+
+class BenchHip(C.Structure):
+    _fields_ = [("bench", Bench), ("waves_per_block", C.c_int)]
+
+
+class LaunchOpts(C.Structure):
+    _fields_ = [("waves_per_block", C.c_int), ("group", C.c_int),
+                ("reserved", C.c_int * 6)]
+
+
+_CSRp = C.POINTER(SparseCSR)
+_HLLp = C.POINTER(SparseHLL)
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(_lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+# ---------------------------------------------------------------- errors
+def _is_err(addr):
+    """IS_ERR of include/err.h on an integer address."""
+    return addr is not None and addr >= (1 << 64) - 4095
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise OSError(-rc, "%s: %s" % (what, os.strerror(-rc)))
+    return rc
+
+
+def _ptr_or_raise(p, what):
+    addr = C.cast(p, C.c_void_p).value
+    if addr is None:
+        raise OSError(0, "%s returned NULL" % what)
+    if _is_err(addr):
+        code = addr - (1 << 64)
+        raise OSError(-code, "%s: %s" % (what, os.strerror(-code)))
+    return p
+
+
+# ---------------------------------------------------------------- host API
+_sig("io_load_csr", _CSRp, C.c_char_p)
+_sig("csr_free", None, _CSRp)
+_sig("csr_alloc", _CSRp, C.c_char_p, C.c_int, C.c_int, C.c_int)
+_sig("csr_generate", _CSRp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+     C.c_int64, C.c_uint64)
+_sig("csr_row_slice", _CSRp, _CSRp, C.c_int, C.c_int)
+_sig("extract_matrix_name", None, C.c_char_p, C.c_char_p)
+_sig("partition_rows_nnz", _ip, _CSRp, _ip)
+_sig("partition_rows_even", _ip, C.c_int, C.c_int, C.c_int)
+_sig("csr_to_hll", _HLLp, _CSRp, C.c_bool)
+_sig("hll_free", None, _HLLp)
+_sig("hll_num_slots", C.c_int64, _HLLp)
+_sig("hll_is_contiguous", C.c_int, _HLLp)
+_sig("vec_put", None, C.POINTER(Vec))
+_sig("aligned_malloc", C.c_void_p, C.c_size_t)
+_sig("validation_vec_result", C.c_int, Vec, Vec)
+_sig("max_rel_err", C.c_double, Vec, Vec, _dp)
+for _n in ("bench_csr_serial",):
+    _sig(_n, C.c_int, _CSRp, _dp, C.POINTER(Bench))
+for _n in ("bench_csr_omp_guided", "bench_csr_omp_nnz_balancing"):
+    _sig(_n, C.c_int, _CSRp, _dp, C.POINTER(BenchOmp))
+for _n in ("bench_hll_serial", "bench_hll_serial_col_major"):
+    _sig(_n, C.c_int, _HLLp, _dp, C.POINTER(Bench))
+_sig("bench_hll_omp", C.c_int, _HLLp, _dp, C.POINTER(BenchOmp))
+for _n in CSR_KERNEL_NAMES:
+    _sig("bench_csr_hip_" + _n, C.c_int, _CSRp, _dp, C.POINTER(BenchHip))
+    _sig("csr_spmv_hip_" + _n, C.c_double, _CSRp, _dp, _dp, C.c_void_p)
+for _n in HLL_KERNEL_NAMES:
+    _sig("bench_hll_hip_" + _n, C.c_int, _HLLp, _dp, C.POINTER(BenchHip))
+    _sig("hll_spmv_hip_" + _n, C.c_double, _HLLp, _dp, _dp, C.c_void_p)
+_sig("set_csr_waves_per_block", None, C.c_int)
+_sig("set_hll_waves_per_block", None, C.c_int)
+_sig("logger_init", C.c_int, C.c_char_p)
+_sig("logger_close", None)
+_sig("log_csr_serial_benchmark", None, _CSRp, Bench)
+_sig("log_hll_serial_benchmark", None, _HLLp, Bench)
+_sig("log_csr_omp_benchmark", None, _CSRp, BenchOmp)
+_sig("log_hll_omp_benchmark", None, _HLLp, BenchOmp)
+_sig("log_csr_hip_benchmark", None, _CSRp, BenchHip, C.c_int)
+_sig("log_hll_hip_benchmark", None, _HLLp, BenchHip, C.c_int)
+_sig("log_roofline", None, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+     C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double)
+
+# ---------------------------------------------------------------- engine API
+_sig("spmv_version", C.c_char_p)
+_sig("spmv_device_count", C.c_int)
+_sig("spmv_set_device", C.c_int, C.c_int)
+_sig("spmv_get_device", C.c_int)
+_sig("spmv_device_info", C.c_int, C.c_int, C.c_char_p, C.c_size_t, _ip,
+     C.POINTER(C.c_size_t))
+_sig("spmv_dev_malloc", C.c_int, C.POINTER(C.c_void_p), C.c_size_t)
+_sig("spmv_dev_free", C.c_int, C.c_void_p)
+_sig("spmv_dev_memset", C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p)
+_sig("spmv_copy_h2d", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("spmv_copy_d2h", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("spmv_stream_sync", C.c_int, C.c_void_p)
+_sig("spmv_dev_fill_synth", C.c_int, C.c_void_p, C.c_int64, C.c_uint64,
+     C.c_int64, C.c_void_p)
+_sig("spmv_csr_upload", C.c_int, _CSRp, C.POINTER(C.c_void_p))
+_sig("spmv_csr_generate", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+     C.c_int64, C.c_int64, C.c_uint64, C.POINTER(C.c_void_p))
+_sig("spmv_csr_launch", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
+     C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("spmv_csr_launch_rows", C.c_int, C.c_void_p, C.c_int,
+     C.POINTER(LaunchOpts), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+     C.c_void_p)
+_sig("spmv_csr_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64))
+_sig("spmv_csr_algorithmic_bytes", C.c_int64, C.c_void_p)
+_sig("spmv_csr_download", C.c_int, C.c_void_p, C.POINTER(_CSRp))
+_sig("spmv_csr_release", None, C.c_void_p)
+_sig("spmv_hll_upload", C.c_int, _HLLp, C.c_int, C.POINTER(C.c_void_p))
+_sig("spmv_hll_from_csr", C.c_int, C.c_void_p, C.c_int,
+     C.POINTER(C.c_void_p))
+_sig("spmv_hll_launch", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
+     C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("spmv_hll_launch_blocks", C.c_int, C.c_void_p, C.c_int,
+     C.POINTER(LaunchOpts), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+     C.c_void_p)
+_sig("spmv_hll_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64),
+     _ip, C.POINTER(C.c_int64), _ip)
+_sig("spmv_hll_algorithmic_bytes", C.c_int64, C.c_void_p)
+_sig("spmv_hll_release", None, C.c_void_p)
+_sig("spmv_csr_time", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
+     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, _dp, C.c_void_p)
+_sig("spmv_hll_time", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
+     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, _dp, C.c_void_p)
+
+
+def declared_symbols():
+    """Every function name declared in include/*.h (non-inline)."""
+    names = set()
+    pat = re.compile(r"^[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", re.M | re.S)
+    for fn in sorted(os.listdir(INCLUDE_DIR)):
+        if not fn.endswith(".h"):
+            continue
+        text = open(os.path.join(INCLUDE_DIR, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+        for m in pat.finditer(text):
+            head = m.group(0)
+            if "static" in head.split("(")[0] or "typedef" in head.split("(")[0]:
+                continue
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def check_symbols():
+    """Raise if the library lacks a symbol the headers declare."""
+    missing = [n for n in declared_symbols() if not hasattr(_lib, n)]
+    if missing:
+        raise ImportError("libspmv_scpa_amd.so lacks: %s" % ", ".join(missing))
+    return True
+
+
+# ---------------------------------------------------------------- helpers
+def _as_d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _take_vec(v):
+    """Copy a C vec into numpy and release it (vec_put)."""
+    n = v.len
+    out = np.ctypeslib.as_array(v.data, (n,)).copy() if n else np.zeros(0)
+    _lib.vec_put(C.byref(v))
+    return out
+
+
+def _opts(waves_per_block=0, group=0):
+    o = LaunchOpts()
+    o.waves_per_block = int(waves_per_block)
+    o.group = int(group)
+    return o
+
+
+def version():
+    return _lib.spmv_version().decode()
+
+
+def device_count():
+    return _lib.spmv_device_count()
+
+
+def set_device(d):
+    _check(_lib.spmv_set_device(d), "spmv_set_device")
+
+
+def device_info(d=0):
+    name = C.create_string_buffer(256)
+    cus = C.c_int()
+    mem = C.c_size_t()
+    _check(_lib.spmv_device_info(d, name, 256, C.byref(cus), C.byref(mem)),
+           "spmv_device_info")
+    return name.value.decode(), cus.value, mem.value
+
+
+# ---------------------------------------------------------------- CSR / HLL
+_keepalive = {}
+
+
+def io_load_csr(path):
+    return _ptr_or_raise(_lib.io_load_csr(os.fsencode(path)), "io_load_csr")
+
+
+def csr_free(A):
+    key = C.addressof(A.contents)
+    if key in _keepalive:  # built over numpy arrays: nothing to free in C
+        del _keepalive[key]
+    else:
+        _lib.csr_free(A)
+
+
+def csr_from_arrays(name, M, N, IRP, JA, AS):
+    """A sparse_csr whose arrays are the given numpy arrays (no copy when
+    they are already int32 / float64 contiguous)."""
+    IRP = np.ascontiguousarray(IRP, dtype=np.int32)
+    JA = np.ascontiguousarray(JA, dtype=np.int32)
+    AS = np.ascontiguousarray(AS, dtype=np.float64)
+    assert len(IRP) == M + 1 and len(JA) == len(AS) == IRP[-1]
+    s = SparseCSR()
+    s.name = name.encode()[:MAX_NAME - 1]
+    s.M, s.N, s.NZ = M, N, int(IRP[-1])
+    s.IRP = IRP.ctypes.data_as(_ip)
+    s.JA = JA.ctypes.data_as(_ip)
+    s.AS = AS.ctypes.data_as(_dp)
+    p = C.pointer(s)
+    _keepalive[C.addressof(s)] = (s, IRP, JA, AS)
+    return p
+
+
+def csr_generate(kind, M, N, K, W, row0=0, seed=42):
+    return _ptr_or_raise(_lib.csr_generate(kind, M, N, K, W, row0, seed),
+                         "csr_generate")
+
+
+def csr_row_slice(A, r0, r1):
+    return _ptr_or_raise(_lib.csr_row_slice(A, r0, r1), "csr_row_slice")
+
+
+def csr_arrays(A):
+    """numpy views (no copy) of IRP, JA, AS."""
+    a = A.contents
+    IRP = np.ctypeslib.as_array(a.IRP, (a.M + 1,))
+    JA = np.ctypeslib.as_array(a.JA, (max(a.NZ, 1),))[:a.NZ]
+    AS = np.ctypeslib.as_array(a.AS, (max(a.NZ, 1),))[:a.NZ]
+    return IRP, JA, AS
+
+
+def extract_matrix_name(path):
+    buf = C.create_string_buffer(MAX_NAME)
+    _lib.extract_matrix_name(os.fsencode(path), buf)
+    return buf.value.decode()
+
+
+def partition_rows_nnz(A, parts):
+    n = C.c_int(parts)
+    p = _ptr_or_raise(_lib.partition_rows_nnz(A, C.byref(n)),
+                      "partition_rows_nnz")
+    out = np.ctypeslib.as_array(p, (n.value + 1,)).copy()
+    _libc_free(p)
+    return out
+
+
+def partition_rows_even(M, parts, align=HACK_SIZE):
+    p = _ptr_or_raise(_lib.partition_rows_even(M, parts, align),
+                      "partition_rows_even")
+    out = np.ctypeslib.as_array(p, (parts + 1,)).copy()
+    _libc_free(p)
+    return out
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _libc_free(p):
+    _libc.free(C.cast(p, C.c_void_p))
+
+
+def csr_to_hll(A, col_major):
+    return _ptr_or_raise(_lib.csr_to_hll(A, bool(col_major)), "csr_to_hll")
+
+
+def hll_free(H):
+    _lib.hll_free(H)
+
+
+def hll_num_slots(H):
+    return _lib.hll_num_slots(H)
+
+
+def hll_blocks(H):
+    """list of (M, N, NZ, max_NZ, JA copy, AS copy) per hack block."""
+    h = H.contents
+    out = []
+    for b in range(h.num_blocks):
+        k = h.blocks[b]
+        n = k.M * k.max_NZ
+        ja = np.ctypeslib.as_array(k.JA, (n,)).copy() if n else np.zeros(0, np.int32)
+        as_ = np.ctypeslib.as_array(k.AS, (n,)).copy() if n else np.zeros(0)
+        out.append((k.M, k.N, k.NZ, k.max_NZ, ja, as_))
+    return out
+
+
+# ---------------------------------------------------------------- CPU benches
+def bench_csr_serial(A, x):
+    x, xp = _as_d(x)
+    b = Bench()
+    _check(_lib.bench_csr_serial(A, xp, C.byref(b)), "bench_csr_serial")
+    return _take_vec(b.data), b.duration_ms, b.gflops
+
+
+def _omp(fn, M, x, threads):
+    x, xp = _as_d(x)
+    b = BenchOmp()
+    b.num_threads = threads
+    _check(fn(M, xp, C.byref(b)), fn.__name__)
+    return (_take_vec(b.bench.data), b.bench.duration_ms, b.bench.gflops,
+            b.name.decode(), b.num_threads)
+
+
+def bench_csr_omp_guided(A, x, threads):
+    return _omp(_lib.bench_csr_omp_guided, A, x, threads)
+
+
+def bench_csr_omp_nnz_balancing(A, x, threads):
+    return _omp(_lib.bench_csr_omp_nnz_balancing, A, x, threads)
+
+
+def bench_hll_serial(H, x, col_major=False):
+    x, xp = _as_d(x)
+    b = Bench()
+    fn = _lib.bench_hll_serial_col_major if col_major else _lib.bench_hll_serial
+    _check(fn(H, xp, C.byref(b)), "bench_hll_serial")
+    return _take_vec(b.data), b.duration_ms, b.gflops
+
+
+def bench_hll_omp(H, x, threads):
+    return _omp(_lib.bench_hll_omp, H, x, threads)
+
+
+def validation_vec_result(expected, res):
+    e, ep = _as_d(expected)
+    r, rp = _as_d(res)
+    return _lib.validation_vec_result(Vec(len(e), ep), Vec(len(r), rp))
+
+
+def max_rel_err(expected, res, scale=None):
+    e, ep = _as_d(expected)
+    r, rp = _as_d(res)
+    sp = None
+    if scale is not None:
+        s, sp = _as_d(scale)
+    return _lib.max_rel_err(Vec(len(e), ep), Vec(len(r), rp), sp)
+
+
+# ---------------------------------------------------------------- GPU one-shot
+def csr_spmv_hip(A, x, kernel=2, waves_per_block=0, group=0):
+    """y = A x through the one-shot C-ABI entry point (hip_csr.h): host
+    arrays in, host y out, returns (y, kernel_ms)."""
+    x, xp = _as_d(x)
+    assert len(x) == A.contents.N
+    y = np.zeros(A.contents.M)
+    o = _opts(waves_per_block, group)
+    fn = getattr(_lib, "csr_spmv_hip_" + CSR_KERNEL_NAMES[kernel])
+    ms = fn(A, xp, y.ctypes.data_as(_dp), C.cast(C.pointer(o), C.c_void_p))
+    if ms < 0:
+        _check(int(ms), "csr_spmv_hip_" + CSR_KERNEL_NAMES[kernel])
+    return y, ms
+
+
+def hll_spmv_hip(H, x, kernel=1, waves_per_block=0):
+    x, xp = _as_d(x)
+    assert len(x) == H.contents.N
+    y = np.zeros(H.contents.M)
+    o = _opts(waves_per_block)
+    fn = getattr(_lib, "hll_spmv_hip_" + HLL_KERNEL_NAMES[kernel])
+    ms = fn(H, xp, y.ctypes.data_as(_dp), C.cast(C.pointer(o), C.c_void_p))
+    if ms < 0:
+        _check(int(ms), "hll_spmv_hip_" + HLL_KERNEL_NAMES[kernel])
+    return y, ms
+
+
+def bench_csr_hip(A, x, kernel, waves_per_block=4):
+    x, xp = _as_d(x)
+    b = BenchHip()
+    b.waves_per_block = waves_per_block
+    fn = getattr(_lib, "bench_csr_hip_" + CSR_KERNEL_NAMES[kernel])
+    _check(fn(A, xp, C.byref(b)), "bench_csr_hip_" + CSR_KERNEL_NAMES[kernel])
+    return _take_vec(b.bench.data), b.bench.duration_ms, b.bench.gflops
+
+
+def bench_hll_hip(H, x, kernel, waves_per_block=4):
+    x, xp = _as_d(x)
+    b = BenchHip()
+    b.waves_per_block = waves_per_block
+    fn = getattr(_lib, "bench_hll_hip_" + HLL_KERNEL_NAMES[kernel])
+    _check(fn(H, xp, C.byref(b)), "bench_hll_hip_" + HLL_KERNEL_NAMES[kernel])
+    return _take_vec(b.bench.data), b.bench.duration_ms, b.bench.gflops
+
+
+# ---------------------------------------------------------------- persistent
+class DevBuffer:
+    """Raw device allocation (for hosts that do not bring torch tensors)."""
+
+    ptr = None
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(_lib.spmv_dev_malloc(C.byref(p), nbytes), "spmv_dev_malloc")
+        self.ptr, self.nbytes = p.value, nbytes
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        buf = cls(max(a.nbytes, 16))
+        _check(_lib.spmv_copy_h2d(buf.ptr, a.ctypes.data, a.nbytes),
+               "spmv_copy_h2d")
+        return buf
+
+    def to_numpy(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        _check(_lib.spmv_copy_d2h(out.ctypes.data, self.ptr, out.nbytes),
+               "spmv_copy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.spmv_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def dev_fill_synth(ptr, n, seed, first=0, stream=None):
+    _check(_lib.spmv_dev_fill_synth(ptr, n, seed, first, stream),
+           "spmv_dev_fill_synth")
+
+
+def stream_sync(stream=None):
+    _check(_lib.spmv_stream_sync(stream), "spmv_stream_sync")
+
+
+class CsrDevice:
+    """A CSR matrix resident in HBM (spmv_engine.h, spmv_csr_dev)."""
+
+    h = None
+
+    def __init__(self, handle):
+        self.h = handle
+        M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
+        _lib.spmv_csr_shape(self.h, C.byref(M), C.byref(N), C.byref(NZ))
+        self.M, self.N, self.NZ = M.value, N.value, NZ.value
+
+    @classmethod
+    def upload(cls, A):
+        h = C.c_void_p()
+        _check(_lib.spmv_csr_upload(A, C.byref(h)), "spmv_csr_upload")
+        return cls(h)
+
+    @classmethod
+    def generate(cls, kind, M, N, K, W, row0=0, seed=42):
+        h = C.c_void_p()
+        _check(_lib.spmv_csr_generate(kind, M, N, K, W, row0, seed,
+                                      C.byref(h)), "spmv_csr_generate")
+        return cls(h)
+
+    @property
+    def algorithmic_bytes(self):
+        return _lib.spmv_csr_algorithmic_bytes(self.h)
+
+    def launch(self, kernel, d_x, d_y, waves_per_block=0, group=0,
+               stream=None, rows=None):
+        o = _opts(waves_per_block, group)
+        if rows is None:
+            rc = _lib.spmv_csr_launch(self.h, kernel, C.byref(o), d_x, d_y,
+                                      stream)
+        else:
+            rc = _lib.spmv_csr_launch_rows(self.h, kernel, C.byref(o), d_x,
+                                           d_y, rows[0], rows[1], stream)
+        _check(rc, "spmv_csr_launch")
+
+    def time(self, kernel, d_x, d_y, warmup=3, iters=20, flush_bytes=0,
+             waves_per_block=0, group=0, stream=None):
+        o = _opts(waves_per_block, group)
+        ms = np.zeros(max(iters, 1))
+        _check(_lib.spmv_csr_time(self.h, kernel, C.byref(o), d_x, d_y, warmup,
+                                  iters, flush_bytes, ms.ctypes.data_as(_dp),
+                                  stream), "spmv_csr_time")
+        return ms[:iters]
+
+    def download(self):
+        p = _CSRp()
+        _check(_lib.spmv_csr_download(self.h, C.byref(p)), "spmv_csr_download")
+        return p
+
+    def to_hll(self, col_major):
+        h = C.c_void_p()
+        _check(_lib.spmv_hll_from_csr(self.h, int(col_major), C.byref(h)),
+               "spmv_hll_from_csr")
+        return HllDevice(h)
+
+    def release(self):
+        if self.h:
+            _lib.spmv_csr_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.release()
+
+
+class HllDevice:
+    """An HLL matrix resident in HBM (spmv_engine.h, spmv_hll_dev)."""
+
+    h = None
+
+    def __init__(self, handle):
+        self.h = handle
+        M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
+        nb, S, cm = C.c_int(), C.c_int64(), C.c_int()
+        _lib.spmv_hll_shape(self.h, C.byref(M), C.byref(N), C.byref(NZ),
+                            C.byref(nb), C.byref(S), C.byref(cm))
+        self.M, self.N, self.NZ = M.value, N.value, NZ.value
+        self.num_blocks, self.slots = nb.value, S.value
+        self.col_major = bool(cm.value)
+
+    @classmethod
+    def upload(cls, H, col_major):
+        h = C.c_void_p()
+        _check(_lib.spmv_hll_upload(H, int(col_major), C.byref(h)),
+               "spmv_hll_upload")
+        return cls(h)
+
+    @property
+    def algorithmic_bytes(self):
+        return _lib.spmv_hll_algorithmic_bytes(self.h)
+
+    def launch(self, kernel, d_x, d_y, waves_per_block=0, stream=None,
+               blocks=None):
+        o = _opts(waves_per_block)
+        if blocks is None:
+            rc = _lib.spmv_hll_launch(self.h, kernel, C.byref(o), d_x, d_y,
+                                      stream)
+        else:
+            rc = _lib.spmv_hll_launch_blocks(self.h, kernel, C.byref(o), d_x,
+                                             d_y, blocks[0], blocks[1], stream)
+        _check(rc, "spmv_hll_launch")
+
+    def time(self, kernel, d_x, d_y, warmup=3, iters=20, flush_bytes=0,
+             waves_per_block=0, stream=None):
+        o = _opts(waves_per_block)
+        ms = np.zeros(max(iters, 1))
+        _check(_lib.spmv_hll_time(self.h, kernel, C.byref(o), d_x, d_y, warmup,
+                                  iters, flush_bytes, ms.ctypes.data_as(_dp),
+                                  stream), "spmv_hll_time")
+        return ms[:iters]
+
+    def release(self):
+        if self.h:
+            _lib.spmv_hll_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.release()
+
+
+# ---------------------------------------------------------------- vectors
+_sig("vec_create", Vec, C.c_size_t)
+_sig("vec_fill", None, C.POINTER(Vec), C.c_double)
+_sig("vec_fill_random", None, C.POINTER(Vec))
+_sig("vec_fill_synth", None, C.POINTER(Vec), C.c_uint64, C.c_int64)
+
+
+def vec_random(n, reseed=True):
+    """The reference's x: rand()/RAND_MAX in index order.  reseed=True puts
+    the C library generator in its never-seeded state first (srand(1))."""
+    if reseed:
+        _libc.srand(1)
+    v = _lib.vec_create(n)
+    _lib.vec_fill_random(C.byref(v))
+    return _take_vec(v)
+
+
+def vec_synth(n, seed=7, first=0):
+    v = _lib.vec_create(n)
+    _lib.vec_fill_synth(C.byref(v), seed, first)
+    return _take_vec(v)
+
+
+def compute_gflops(ms, nnz):
+    """2*nnz / (ms*1e6), 0 for ms <= 0 (reference utils.h:70-75)."""
+    return (2.0 * nnz) / (ms * 1e6) if ms > 0.0 else 0.0

@@ -1,0 +1,485 @@
+/*
+ * csr.c -- CSR container, Matrix Market loader, synthetic generator, row
+ * partitions and the CPU / GPU benchmark wrappers (API: include/csr.h).
+ *
+ * Behavioural reference: src/csr.c of 0xmenna/spmv-scpa (cited per
+ * function).  The implementation is new: one pass over an in-memory image
+ * of the file and a stable counting sort by row, instead of two fscanf
+ * passes over the text.
+ */
+#include <errno.h>
+#include <limits.h>
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "csr.h"
+#include "err.h"
+#include "hip_csr.h"
+#include "mm_header.h"
+#include "spmv_engine.h"
+#include "spmv_synth.h"
+
+/* ------------------------------------------------------------------ */
+/* container                                                            */
+/* ------------------------------------------------------------------ */
+
+void extract_matrix_name(const char *path, char *name_out) {
+    const char *slash = strrchr(path, '/');
+    const char *base = slash ? slash + 1 : path;
+    size_t n = strlen(base);
+    if (n > 4 && memcmp(base + n - 4, ".mtx", 4) == 0)
+        n -= 4;
+    if (n > MAX_NAME - 1)
+        n = MAX_NAME - 1;
+    memcpy(name_out, base, n);
+    name_out[n] = '\0';
+}
+
+sparse_csr *csr_alloc(const char *name, int M, int N, int NZ) {
+    if (M < 0 || N < 0 || NZ < 0)
+        return ERR_PTR(-EINVAL);
+    sparse_csr *A = malloc(sizeof *A);
+    int *irp = aligned_malloc(((size_t)M + 1) * sizeof(int));
+    int *ja = aligned_malloc((size_t)NZ * sizeof(int));
+    double *as = aligned_malloc((size_t)NZ * sizeof(double));
+    if (!A || !irp || !ja || !as) {
+        free(A);
+        free(irp);
+        free(ja);
+        free(as);
+        return ERR_PTR(-ENOMEM);
+    }
+    memset(irp, 0, ((size_t)M + 1) * sizeof(int));
+    init_csr(A, name ? name : "", M, N, NZ, irp, ja, as);
+    return A;
+}
+
+void csr_free(sparse_csr *A) {
+    if (IS_ERR_OR_NULL(A))
+        return;
+    free(A->IRP);
+    free(A->JA);
+    free(A->AS);
+    free(A);
+}
+
+/* ------------------------------------------------------------------ */
+/* Matrix Market loader                                                 */
+/* ------------------------------------------------------------------ */
+
+static int is_space(int c) {
+    return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' ||
+           c == '\f';
+}
+
+/* "%d": optional blanks, optional sign, at least one digit */
+static int scan_int(const char **pp, const char *end, int *out) {
+    const char *p = *pp;
+    while (p < end && is_space((unsigned char)*p))
+        ++p;
+    int neg = 0;
+    if (p < end && (*p == '-' || *p == '+'))
+        neg = (*p++ == '-');
+    if (p >= end || *p < '0' || *p > '9')
+        return 0;
+    long long v = 0;
+    while (p < end && *p >= '0' && *p <= '9') {
+        v = v * 10 + (*p++ - '0');
+        if (v > (long long)INT_MAX + 1)
+            v = (long long)INT_MAX + 1; /* saturate; caught by range check */
+    }
+    if (neg)
+        v = -v;
+    if (v > INT_MAX)
+        v = INT_MAX;
+    if (v < INT_MIN)
+        v = INT_MIN;
+    *out = (int)v;
+    *pp = p;
+    return 1;
+}
+
+/* "%lf": strtod accepts what scanf accepts (decimal, exponent, hex, inf,
+ * nan); the buffer is NUL-terminated so it cannot run past `end`. */
+static int scan_double(const char **pp, const char *end, double *out) {
+    const char *p = *pp;
+    while (p < end && is_space((unsigned char)*p))
+        ++p;
+    if (p >= end)
+        return 0;
+    char *stop;
+    double v = strtod(p, &stop);
+    if (stop == p)
+        return 0;
+    *out = v;
+    *pp = stop;
+    return 1;
+}
+
+static int read_whole_file(const char *path, char **buf, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return -errno;
+    size_t cap = 1 << 16, n = 0;
+    char *b = malloc(cap + 1);
+    if (!b) {
+        fclose(f);
+        return -ENOMEM;
+    }
+    for (;;) {
+        size_t got = fread(b + n, 1, cap - n, f);
+        n += got;
+        if (got == 0)
+            break;
+        if (n == cap) {
+            cap *= 2;
+            char *nb = realloc(b, cap + 1);
+            if (!nb) {
+                free(b);
+                fclose(f);
+                return -ENOMEM;
+            }
+            b = nb;
+        }
+    }
+    int bad = ferror(f);
+    fclose(f);
+    if (bad) {
+        free(b);
+        return -EIO;
+    }
+    b[n] = '\0';
+    *buf = b;
+    *len = n;
+    return 0;
+}
+
+sparse_csr *io_load_csr(const char *path) {
+    char *text = NULL;
+    size_t len = 0;
+    int rc = read_whole_file(path, &text, &len);
+    if (rc)
+        return ERR_PTR(rc);
+
+    int *ei = NULL, *ej = NULL, *fill = NULL;
+    double *ev = NULL;
+    sparse_csr *A = NULL;
+    mm_info mm;
+
+    /* reference csr.c:48-57: only "matrix coordinate real|pattern" */
+    if (mm_parse_header(text, len, &mm) != MM_OK || mm.object != 'M' ||
+        mm.format != 'C' || !(mm.field == 'R' || mm.field == 'P') ||
+        mm.rows < 0 || mm.cols < 0 || mm.entries < 0) {
+        rc = -EINVAL;
+        goto done;
+    }
+    const int M = mm.rows, N = mm.cols, nz0 = mm.entries;
+    const int mirror = (mm.symmetry == 'S'); /* csr.c:58: 'K','H' as general */
+    const int pattern = (mm.field == 'P');
+
+    ei = malloc(((size_t)nz0 + 1) * sizeof *ei);
+    ej = malloc(((size_t)nz0 + 1) * sizeof *ej);
+    ev = pattern ? NULL : malloc(((size_t)nz0 + 1) * sizeof *ev);
+    fill = calloc((size_t)M + 1, sizeof *fill);
+    if (!ei || !ej || (!pattern && !ev) || !fill) {
+        rc = -ENOMEM;
+        goto done;
+    }
+
+    /* single scan: parse, validate, count per row (file order kept) */
+    const char *p = text + mm.data_offset, *end = text + len;
+    long long stored = 0;
+    for (int e = 0; e < nz0; ++e) {
+        int i, j;
+        double v = 1.0;
+        if (!scan_int(&p, end, &i) || !scan_int(&p, end, &j) ||
+            (!pattern && !scan_double(&p, end, &v))) {
+            rc = -EIO; /* csr.c:71-79 */
+            goto done;
+        }
+        --i;
+        --j;
+        if (i < 0 || i >= M || j < 0 || j >= N) {
+            rc = -ERANGE; /* csr.c:84-87 */
+            goto done;
+        }
+        ei[e] = i;
+        ej[e] = j;
+        if (!pattern)
+            ev[e] = v;
+        fill[i]++;
+        stored++;
+        if (mirror && i != j) {
+            fill[j]++;
+            stored++;
+        }
+    }
+    if (stored > INT_MAX) {
+        rc = -EOVERFLOW;
+        goto done;
+    }
+
+    A = csr_alloc("", M, N, (int)stored);
+    if (IS_ERR(A)) {
+        rc = PTR_ERR(A);
+        A = NULL;
+        goto done;
+    }
+    extract_matrix_name(path, A->name);
+    for (int r = 0; r < M; ++r)
+        A->IRP[r + 1] = A->IRP[r] + fill[r];
+    memset(fill, 0, ((size_t)M + 1) * sizeof *fill);
+
+    /* stable scatter: an entry, then its mirror image (csr.c:138-145) */
+    for (int e = 0; e < nz0; ++e) {
+        int i = ei[e], j = ej[e];
+        double v = pattern ? 1.0 : ev[e];
+        size_t at = (size_t)A->IRP[i] + (size_t)fill[i]++;
+        A->JA[at] = j;
+        A->AS[at] = v;
+        if (mirror && i != j) {
+            size_t bt = (size_t)A->IRP[j] + (size_t)fill[j]++;
+            A->JA[bt] = i;
+            A->AS[bt] = v;
+        }
+    }
+
+done:
+    free(text);
+    free(ei);
+    free(ej);
+    free(ev);
+    free(fill);
+    if (rc) {
+        csr_free(A);
+        return ERR_PTR(rc);
+    }
+    return A;
+}
+
+/* ------------------------------------------------------------------ */
+/* synthetic matrices, slices, partitions                               */
+/* ------------------------------------------------------------------ */
+
+sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
+                         int64_t row0, uint64_t seed) {
+    if (M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_KKT ||
+        (kind == SYNTH_BANDED && N < K))
+        return ERR_PTR(-EINVAL);
+    synth_spec s = {kind, M, N, K, W, row0, seed};
+    long long nz = 0;
+    if (kind == SYNTH_BANDED || kind == SYNTH_RANDOM) {
+        nz = (long long)M * K;
+    } else {
+#pragma omp parallel for schedule(static) reduction(+ : nz)
+        for (int i = 0; i < M; ++i)
+            nz += synth_row_len(&s, row0 + i);
+    }
+    if (nz > INT_MAX)
+        return ERR_PTR(-EOVERFLOW);
+    static const char *names[] = {"synth_banded", "synth_random",
+                                  "synth_ragged", "synth_kkt"};
+    sparse_csr *A = csr_alloc(names[kind], M, N, (int)nz);
+    if (IS_ERR(A))
+        return A;
+    for (int i = 0; i < M; ++i)
+        A->IRP[i + 1] = A->IRP[i] + synth_row_len(&s, row0 + i);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = 0; i < M; ++i)
+        synth_fill_row(&s, row0 + i, A->IRP[i + 1] - A->IRP[i],
+                       A->JA + A->IRP[i], A->AS + A->IRP[i]);
+    return A;
+}
+
+sparse_csr *csr_row_slice(const sparse_csr *A, int r0, int r1) {
+    if (!A || r0 < 0 || r1 < r0 || r1 > A->M)
+        return ERR_PTR(-EINVAL);
+    int base = A->IRP[r0], nz = A->IRP[r1] - base;
+    sparse_csr *S = csr_alloc(A->name, r1 - r0, A->N, nz);
+    if (IS_ERR(S))
+        return S;
+    for (int r = r0; r <= r1; ++r)
+        S->IRP[r - r0] = A->IRP[r] - base;
+    memcpy(S->JA, A->JA + base, (size_t)nz * sizeof(int));
+    memcpy(S->AS, A->AS + base, (size_t)nz * sizeof(double));
+    return S;
+}
+
+/* Greedy cut at total/parts entries (behaviour of reference csr.c:218-276:
+ * a range closes as soon as its running count reaches the target, the last
+ * range takes the remainder, and the number of ranges shrinks when rows run
+ * out first). */
+int *partition_rows_nnz(const sparse_csr *A, int *parts) {
+    if (!A || !parts || *parts < 1)
+        return ERR_PTR(-EINVAL);
+    int want = *parts;
+    int *starts = malloc(((size_t)want + 1) * sizeof *starts);
+    if (!starts)
+        return ERR_PTR(-ENOMEM);
+    double target = (double)((long long)A->IRP[A->M] - A->IRP[0]) / want;
+    double load = 0.0;
+    int k = 0;
+    starts[0] = 0;
+    for (int r = 0; r < A->M && k < want - 1; ++r) {
+        load += (double)(A->IRP[r + 1] - A->IRP[r]);
+        if (load >= target) {
+            starts[++k] = r + 1;
+            load = 0.0;
+        }
+    }
+    starts[k + 1] = A->M;
+    *parts = k + 1;
+    return starts;
+}
+
+int *partition_rows_even(int M, int parts, int align) {
+    if (M < 0 || parts < 1 || align < 1)
+        return ERR_PTR(-EINVAL);
+    int *starts = malloc(((size_t)parts + 1) * sizeof *starts);
+    if (!starts)
+        return ERR_PTR(-ENOMEM);
+    long long per = ((long long)M + parts - 1) / parts;
+    per = (per + align - 1) / align * align;
+    for (int k = 0; k <= parts; ++k) {
+        long long s = per * k;
+        starts[k] = (int)(s < M ? s : M);
+    }
+    return starts;
+}
+
+/* ------------------------------------------------------------------ */
+/* CPU kernels (reference csr.c:201-216, 278-339)                       */
+/* ------------------------------------------------------------------ */
+
+typedef double (*csr_kernel_fn)(const sparse_csr *, const double *, double *,
+                                void *);
+
+static inline double row_dot(const sparse_csr *A, const double *x, int i) {
+    double acc = 0.0;
+    for (int k = A->IRP[i]; k < A->IRP[i + 1]; ++k)
+        acc += A->AS[k] * x[A->JA[k]];
+    return acc;
+}
+
+static double csr_spmv_serial(const sparse_csr *A, const double *x, double *y,
+                              void *arg) {
+    (void)arg;
+    double t0 = now(); /* CPU time, as the reference (utils.h:68) */
+    for (int i = 0; i < A->M; ++i)
+        y[i] = row_dot(A, x, i);
+    return now() - t0;
+}
+
+static double csr_spmv_omp_guided(const sparse_csr *A, const double *x,
+                                  double *y, void *arg) {
+    int threads = *(const int *)arg;
+    double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(guided) num_threads(threads)
+    for (int i = 0; i < A->M; ++i)
+        y[i] = row_dot(A, x, i);
+    return (omp_get_wtime() - t0) * 1e3;
+}
+
+struct nnz_ranges {
+    int parts;
+    const int *starts;
+};
+
+static double csr_spmv_omp_ranges(const sparse_csr *A, const double *x,
+                                  double *y, void *arg) {
+    const struct nnz_ranges *rg = arg;
+    double t0 = omp_get_wtime();
+#pragma omp parallel num_threads(rg->parts)
+    {
+        /* a team smaller than requested still covers every range */
+        int team = omp_get_num_threads();
+        for (int t = omp_get_thread_num(); t < rg->parts; t += team)
+            for (int i = rg->starts[t]; i < rg->starts[t + 1]; ++i)
+                y[i] = row_dot(A, x, i);
+    }
+    return (omp_get_wtime() - t0) * 1e3;
+}
+
+/* harness shared by every CSR benchmark (reference csr.c:182-199): fresh
+ * zeroed y, one call, record time / GFLOP/s, hand y to the caller */
+static int run_csr_bench(const sparse_csr *A, const double *x, bench *out,
+                         void *arg, csr_kernel_fn fn) {
+    vec y = vec_create((size_t)A->M);
+    if (!y.data)
+        return -ENOMEM;
+    double ms = fn(A, x, y.data, arg);
+    if (ms < 0.0) { /* GPU entry points report failures as -errno */
+        vec_put(&y);
+        return (int)ms;
+    }
+    out->duration_ms = ms;
+    out->gflops = compute_gflops(ms, A->NZ);
+    out->data = y;
+    return 0;
+}
+
+int bench_csr_serial(const sparse_csr *A, const double *x, bench *out) {
+    return run_csr_bench(A, x, out, NULL, csr_spmv_serial);
+}
+
+int bench_csr_omp_guided(const sparse_csr *A, const double *x,
+                         bench_omp *out) {
+    snprintf(out->name, sizeof out->name, "omp_guided");
+    if (out->num_threads < 1)
+        return -EINVAL;
+    return run_csr_bench(A, x, &out->bench, &out->num_threads,
+                         csr_spmv_omp_guided);
+}
+
+int bench_csr_omp_nnz_balancing(const sparse_csr *A, const double *x,
+                                bench_omp *out) {
+    snprintf(out->name, sizeof out->name, "omp_nnz");
+    if (out->num_threads < 1)
+        return -EINVAL;
+    int *starts = partition_rows_nnz(A, &out->num_threads);
+    if (IS_ERR(starts))
+        return PTR_ERR(starts);
+    struct nnz_ranges rg = {out->num_threads, starts};
+    int rc = run_csr_bench(A, x, &out->bench, &rg, csr_spmv_omp_ranges);
+    free(starts);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* GPU wrappers (counterparts of reference csr.c:382-415)               */
+/* ------------------------------------------------------------------ */
+
+static int run_csr_hip(const sparse_csr *A, const double *x, bench_hip *out,
+                       csr_kernel_fn fn) {
+    spmv_launch_opts opts;
+    memset(&opts, 0, sizeof opts);
+    opts.waves_per_block = out->waves_per_block;
+    return run_csr_bench(A, x, &out->bench, &opts, fn);
+}
+
+int bench_csr_hip_thread_row(const sparse_csr *A, const double *x,
+                             bench_hip *out) {
+    return run_csr_hip(A, x, out, csr_spmv_hip_thread_row);
+}
+
+int bench_csr_hip_wave_row(const sparse_csr *A, const double *x,
+                           bench_hip *out) {
+    return run_csr_hip(A, x, out, csr_spmv_hip_wave_row);
+}
+
+int bench_csr_hip_subwave_row(const sparse_csr *A, const double *x,
+                              bench_hip *out) {
+    return run_csr_hip(A, x, out, csr_spmv_hip_subwave_row);
+}
+
+int bench_csr_hip_block_row(const sparse_csr *A, const double *x,
+                            bench_hip *out) {
+    return run_csr_hip(A, x, out, csr_spmv_hip_block_row);
+}
+
+int bench_csr_hip_stream(const sparse_csr *A, const double *x,
+                         bench_hip *out) {
+    return run_csr_hip(A, x, out, csr_spmv_hip_stream);
+}

@@ -1,0 +1,278 @@
+/*
+ * csr_kernels.hip -- fp64 CSR SpMV kernels for gfx950 (wave64).
+ *
+ * Five kernels fill the five slots of the reference's driver table
+ * (reference cuda_csr.cu:19-178, main.c:259-263); the designs are new:
+ *
+ *   0 thread_row   lane per row.
+ *   1 wave_row     one 64-lane wavefront per row, lanes stride the row,
+ *                  __shfl_down tree over 64 lanes.
+ *   2 subwave_row  G lanes per row (G = 2..32), 64/G rows per wavefront;
+ *                  a wavefront reads 64 consecutive entries per load, so the
+ *                  JA/AS streams stay fully coalesced whatever the row
+ *                  length; segmented __shfl_down(width G) reduction with
+ *                  every lane taking part (no early exit before a shuffle,
+ *                  unlike reference cuda_csr.cu:72-73).
+ *   3 block_row    one workgroup per row: wave partials through LDS.
+ *   4 stream       nnz-balanced: a workgroup owns consecutive rows holding
+ *                  <= STREAM_NNZ entries (table built at upload), streams
+ *                  products a_ij*x_j into LDS with coalesced loads, then
+ *                  reduces each row from LDS with a per-workgroup lane
+ *                  group; rows longer than the budget get a workgroup to
+ *                  themselves.  Insensitive to row-length skew.
+ *
+ * No MFMA: there is no dense contraction.  Bound: HBM streams (12 B/entry)
+ * plus the x gathers.  JA/AS are read once -> non-temporal loads, so they
+ * do not evict x from L2 / Infinity Cache.
+ */
+#include "hip_common.h"
+
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) {
+    return __builtin_nontemporal_load(p);
+}
+
+/* ------------------------------------------------------------------ */
+__global__ void k_csr_thread_row(int r0, int r1, const int *__restrict__ irp,
+                                 const int *__restrict__ ja,
+                                 const double *__restrict__ as,
+                                 const double *__restrict__ x,
+                                 double *__restrict__ y) {
+    int row = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= r1)
+        return;
+    double acc = 0.0;
+    for (int k = irp[row], e = irp[row + 1]; k < e; ++k)
+        acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+    y[row] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+__global__ void k_csr_wave_row(int r0, int r1, const int *__restrict__ irp,
+                               const int *__restrict__ ja,
+                               const double *__restrict__ as,
+                               const double *__restrict__ x,
+                               double *__restrict__ y) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    const int waves = blockDim.x / WAVE;
+    const int row = r0 + blockIdx.x * waves + wave; /* wave-uniform */
+    if (row >= r1)
+        return;
+    double acc = 0.0;
+    const int beg = irp[row], end = irp[row + 1];
+    for (int k = beg + lane; k < end; k += WAVE)
+        acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1)
+        acc += __shfl_down(acc, d, WAVE);
+    if (lane == 0)
+        y[row] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+template <int G>
+__global__ void k_csr_subwave_row(int r0, int r1,
+                                  const int *__restrict__ irp,
+                                  const int *__restrict__ ja,
+                                  const double *__restrict__ as,
+                                  const double *__restrict__ x,
+                                  double *__restrict__ y) {
+    const int sub = threadIdx.x & (G - 1);
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = (long long)r0 + gid / G;
+    const bool live = row < r1;
+    double acc = 0.0;
+    if (live) {
+        const int beg = irp[row], end = irp[row + 1];
+        for (int k = beg + sub; k < end; k += G)
+            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+    }
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1)
+        acc += __shfl_down(acc, d, G);
+    if (live && sub == 0)
+        y[row] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+__global__ void k_csr_block_row(int r0, int r1, const int *__restrict__ irp,
+                                const int *__restrict__ ja,
+                                const double *__restrict__ as,
+                                const double *__restrict__ x,
+                                double *__restrict__ y) {
+    __shared__ double part[16];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    const int waves = blockDim.x / WAVE;
+    for (int row = r0 + blockIdx.x; row < r1; row += gridDim.x) {
+        double acc = 0.0;
+        const int beg = irp[row], end = irp[row + 1];
+        for (int k = beg + threadIdx.x; k < end; k += blockDim.x)
+            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+#pragma unroll
+        for (int d = WAVE / 2; d > 0; d >>= 1)
+            acc += __shfl_down(acc, d, WAVE);
+        if (lane == 0)
+            part[wave] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            double t = lane < waves ? part[lane] : 0.0;
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1)
+                t += __shfl_down(t, d, 16);
+            if (lane == 0)
+                y[row] = t;
+        }
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/*
+ * stream: workgroup k owns rows [rowblk[k], rowblk[k+1]).  Either their
+ * entries fit the LDS budget, or the range is a single long row.
+ */
+__global__ void __launch_bounds__(STREAM_THREADS)
+    k_csr_stream(int blk0, const int *__restrict__ rowblk,
+                 const int *__restrict__ irp, const int *__restrict__ ja,
+                 const double *__restrict__ as, const double *__restrict__ x,
+                 double *__restrict__ y) {
+    __shared__ double prod[STREAM_NNZ];
+    __shared__ double part[STREAM_THREADS / WAVE];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int rb = blk0 + blockIdx.x;
+    const int row_a = rowblk[rb], row_b = rowblk[rb + 1];
+    const int beg = irp[row_a], end = irp[row_b];
+    const int cnt = end - beg;
+
+    if (cnt > STREAM_NNZ) {
+        /* one long row: every lane strides it, block-wide reduction */
+        double acc = 0.0;
+        for (int k = beg + tid; k < end; k += STREAM_THREADS)
+            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+#pragma unroll
+        for (int d = WAVE / 2; d > 0; d >>= 1)
+            acc += __shfl_down(acc, d, WAVE);
+        if (lane == 0)
+            part[tid / WAVE] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
+                t += part[w];
+            y[row_a] = t;
+        }
+        return;
+    }
+
+    /* phase 1: coalesced stream of the workgroup's entries -> products */
+    for (int k = tid; k < cnt; k += STREAM_THREADS)
+        prod[k] = ld_stream(as + beg + k) * x[ld_stream(ja + beg + k)];
+    __syncthreads();
+
+    /* phase 2: G lanes per row, G from the mean row length of this range */
+    const int rows = row_b - row_a;
+    int g = 1;
+    while (g < WAVE && g * rows * 2 <= cnt)
+        g <<= 1; /* g ~ mean length / 2, power of two, <= 64 */
+    const int sub = tid & (g - 1);
+    const int per_pass = STREAM_THREADS / g;
+    for (int r = tid / g; r < rows + (per_pass - rows % per_pass) % per_pass;
+         r += per_pass) {
+        double acc = 0.0;
+        const bool live = r < rows;
+        if (live) {
+            const int a = irp[row_a + r] - beg, b = irp[row_a + r + 1] - beg;
+            for (int k = a + sub; k < b; k += g)
+                acc += prod[k];
+        }
+        for (int d = g >> 1; d > 0; d >>= 1)
+            acc += __shfl_down(acc, d, WAVE);
+        if (live && sub == 0)
+            y[row_a + r] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+static int pick_group(const spmv_csr_dev *A, int group) {
+    if (group >= 2 && group <= 32 && (group & (group - 1)) == 0)
+        return group;
+    double mean = A->M > 0 ? (double)A->NZ / A->M : 1.0;
+    int g = 2;
+    while (g < 32 && g < mean)
+        g <<= 1;
+    return g;
+}
+
+template <int G>
+static void launch_subwave(int r0, int r1, int threads,
+                           const spmv_csr_dev *A, const double *x, double *y,
+                           hipStream_t s) {
+    long long lanes = (long long)(r1 - r0) * G;
+    unsigned grid = (unsigned)((lanes + threads - 1) / threads);
+    hipLaunchKernelGGL(k_csr_subwave_row<G>, dim3(grid), dim3(threads), 0, s,
+                       r0, r1, A->irp, A->ja, A->as, x, y);
+}
+
+int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
+                      const double *x, double *y, int r0, int r1,
+                      hipStream_t s) {
+    if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
+        return -EINVAL;
+    if (r0 == r1)
+        return 0;
+    const int threads = waves * WAVE;
+    const int rows = r1 - r0;
+    /* the stream kernel's row-block table covers the whole matrix; a row
+     * sub-range (chunked multi-GPU overlap) runs the sub-wave kernel */
+    if (kernel == 4 && (r0 != 0 || r1 != A->M))
+        kernel = 2;
+    switch (kernel) {
+    case 0:
+        hipLaunchKernelGGL(k_csr_thread_row,
+                           dim3((rows + threads - 1) / threads), dim3(threads),
+                           0, s, r0, r1, A->irp, A->ja, A->as, x, y);
+        break;
+    case 1:
+        hipLaunchKernelGGL(k_csr_wave_row, dim3((rows + waves - 1) / waves),
+                           dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
+                           x, y);
+        break;
+    case 2:
+        switch (pick_group(A, group)) {
+        case 2:
+            launch_subwave<2>(r0, r1, threads, A, x, y, s);
+            break;
+        case 4:
+            launch_subwave<4>(r0, r1, threads, A, x, y, s);
+            break;
+        case 8:
+            launch_subwave<8>(r0, r1, threads, A, x, y, s);
+            break;
+        case 16:
+            launch_subwave<16>(r0, r1, threads, A, x, y, s);
+            break;
+        default:
+            launch_subwave<32>(r0, r1, threads, A, x, y, s);
+            break;
+        }
+        break;
+    case 3: {
+        int grid = rows < 65536 * 16 ? rows : 65536 * 16;
+        hipLaunchKernelGGL(k_csr_block_row, dim3(grid), dim3(threads), 0, s,
+                           r0, r1, A->irp, A->ja, A->as, x, y);
+        break;
+    }
+    case 4: {
+        if (A->n_rowblk > 0)
+            hipLaunchKernelGGL(k_csr_stream, dim3(A->n_rowblk),
+                               dim3(STREAM_THREADS), 0, s, 0, A->rowblk,
+                               A->irp, A->ja, A->as, x, y);
+        break;
+    }
+    default:
+        return -EINVAL;
+    }
+    return hip_errno(hipGetLastError());
+}

@@ -1,0 +1,816 @@
+/*
+ * engine.hip -- device management, matrix upload / generation / conversion,
+ * launch dispatch, event timing and the one-shot C-ABI entry points
+ * (API: include/spmv_engine.h, hip_csr.h, hip_hll.h).
+ *
+ * Everything here is host code around the kernels of csr_kernels.hip and
+ * hll_kernels.hip.  There is no CPU fallback: without a usable GPU every
+ * entry point returns -ENODEV.
+ */
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "err.h"
+#include "hip_common.h"
+#include "hip_csr.h"
+#include "hip_hll.h"
+#include "spmv_synth.h"
+
+int g_csr_waves = 4;
+int g_hll_waves = 4;
+
+extern "C" {
+
+const char *spmv_version(void) { return "spmv_scpa_amd 0.1 gfx950"; }
+
+void set_csr_waves_per_block(int waves) {
+    g_csr_waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+}
+
+void set_hll_waves_per_block(int waves) {
+    g_hll_waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+}
+
+/* ------------------------------------------------------------------ */
+/* devices and raw memory                                               */
+/* ------------------------------------------------------------------ */
+
+int spmv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int spmv_set_device(int device) {
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    HIP_RET(hipSetDevice(device));
+    return 0;
+}
+
+int spmv_get_device(void) {
+    int d = 0;
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    HIP_RET(hipGetDevice(&d));
+    return d;
+}
+
+int spmv_device_info(int device, char *name, size_t len, int *compute_units,
+                     size_t *hbm_bytes) {
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    hipDeviceProp_t p;
+    HIP_RET(hipGetDeviceProperties(&p, device));
+    if (name && len)
+        snprintf(name, len, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units)
+        *compute_units = p.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = p.totalGlobalMem;
+    return 0;
+}
+
+int spmv_dev_malloc(void **dptr, size_t bytes) {
+    if (!dptr)
+        return -EINVAL;
+    *dptr = NULL;
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    HIP_RET(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+
+int spmv_dev_free(void *dptr) {
+    if (!dptr)
+        return 0;
+    HIP_RET(hipFree(dptr));
+    return 0;
+}
+
+int spmv_dev_memset(void *dptr, int byte, size_t bytes, void *stream) {
+    HIP_RET(hipMemsetAsync(dptr, byte, bytes, (hipStream_t)stream));
+    return 0;
+}
+
+int spmv_copy_h2d(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0)
+        return 0;
+    HIP_RET(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int spmv_copy_d2h(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0)
+        return 0;
+    HIP_RET(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spmv_stream_sync(void *stream) {
+    HIP_RET(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+} /* extern "C" */
+
+/* ------------------------------------------------------------------ */
+/* device-side synthetic generation (include/spmv_synth.h)              */
+/* ------------------------------------------------------------------ */
+
+__global__ void k_fill_x(double *x, int64_t n, uint64_t seed, int64_t first) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        x[i] = synth_x(seed, first + i);
+}
+
+__global__ void k_synth_lens(synth_spec s, int *lens) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < s.M)
+        lens[i] = synth_row_len(&s, s.row0 + i);
+}
+
+/* one lane per row; rows are short, the insertion sort runs in place */
+__global__ void k_synth_rows(synth_spec s, const int *irp, int *ja,
+                             double *as) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.M)
+        return;
+    int beg = irp[i], len = irp[i + 1] - beg;
+    synth_fill_row(&s, s.row0 + i, len, ja + beg, as + beg);
+}
+
+/* CSR -> HLL on the device: per-block width, then slot fill */
+__global__ void k_block_width(int M, const int *irp, int *width) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    int len = row < M ? irp[row + 1] - irp[row] : 0;
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1)
+        len = max(len, __shfl_down(len, d, 32));
+    if ((threadIdx.x & 31) == 0 && row < M)
+        width[row / 32] = len;
+}
+
+__global__ void k_hll_fill(int M, int col_major, const int *irp,
+                           const int *cja, const double *cas,
+                           const int64_t *off, int *ja, double *as) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M)
+        return;
+    int b = row / 32, i = row % 32;
+    int rows = min(32, M - b * 32);
+    int64_t o = off[b];
+    int w = (int)((off[b + 1] - o) / rows);
+    int beg = irp[row], len = irp[row + 1] - beg;
+    int last = 0; /* pad -> previous valid column, or 0 (hip_hll.h) */
+    for (int j = 0; j < w; ++j) {
+        int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
+        if (j < len) {
+            last = cja[beg + j];
+            ja[t] = last;
+            as[t] = cas[beg + j];
+        } else {
+            ja[t] = last;
+            as[t] = 0.0;
+        }
+    }
+}
+
+/* scratch sweep used to push a small working set out of the Infinity Cache */
+__global__ void k_flush(double *buf, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        buf[i] = buf[i] * 1.0000001 + 1.0;
+}
+
+/* ------------------------------------------------------------------ */
+/* row-block table of the CSR stream kernel (host, O(M))                */
+/* ------------------------------------------------------------------ */
+static void build_rowblk(const int *irp, int M, std::vector<int> &tab,
+                         int *max_len) {
+    tab.clear();
+    tab.push_back(0);
+    int start = 0, longest = 0;
+    for (int r = 0; r < M; ++r) {
+        int len = irp[r + 1] - irp[r];
+        longest = std::max(longest, len);
+        int have = irp[r] - irp[start];
+        bool full = (have + len > STREAM_NNZ) || (r - start >= STREAM_THREADS);
+        if (full && r > start) {
+            tab.push_back(r); /* close [start, r) */
+            start = r;
+        }
+    }
+    if (M > start)
+        tab.push_back(M);
+    *max_len = longest;
+}
+
+static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
+    int rc = 0;
+    std::vector<int> tab;
+    std::vector<int> tmp;
+    if (!host_irp) {
+        tmp.resize((size_t)d->M + 1);
+        HIP_TRY(hipMemcpy(tmp.data(), d->irp, ((size_t)d->M + 1) * sizeof(int),
+                          hipMemcpyDeviceToHost));
+        host_irp = tmp.data();
+    }
+    build_rowblk(host_irp, d->M, tab, &d->max_row_len);
+    d->n_rowblk = (int)tab.size() - 1;
+    HIP_TRY(hipMalloc((void **)&d->rowblk, tab.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(d->rowblk, tab.data(), tab.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+fail:
+    return rc;
+}
+
+extern "C" {
+
+int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
+                        void *stream) {
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_fill_x, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       0, (hipStream_t)stream, d_x, n, seed, first);
+    return hip_errno(hipGetLastError());
+}
+
+/* ------------------------------------------------------------------ */
+/* CSR handle                                                           */
+/* ------------------------------------------------------------------ */
+
+void spmv_csr_release(spmv_csr_dev *d) {
+    if (!d)
+        return;
+    (void)hipFree(d->irp);
+    (void)hipFree(d->ja);
+    (void)hipFree(d->as);
+    (void)hipFree(d->rowblk);
+    free(d);
+}
+
+static int csr_alloc_dev(int M, int N, int64_t NZ, spmv_csr_dev **out) {
+    int rc = 0;
+    spmv_csr_dev *d = (spmv_csr_dev *)calloc(1, sizeof *d);
+    if (!d)
+        return -ENOMEM;
+    d->M = M;
+    d->N = N;
+    d->NZ = NZ;
+    HIP_TRY(hipGetDevice(&d->device));
+    HIP_TRY(hipMalloc((void **)&d->irp, ((size_t)M + 1) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->ja, std::max<size_t>(NZ, 4) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->as, std::max<size_t>(NZ, 2) * sizeof(double)));
+    *out = d;
+    return 0;
+fail:
+    spmv_csr_release(d);
+    return rc;
+}
+
+int spmv_csr_upload(const sparse_csr *A, spmv_csr_dev **out) {
+    if (!A || !out || A->M < 0 || A->NZ < 0)
+        return -EINVAL;
+    *out = NULL;
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    spmv_csr_dev *d = NULL;
+    int rc = csr_alloc_dev(A->M, A->N, A->NZ, &d);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(d->irp, A->IRP, ((size_t)A->M + 1) * sizeof(int),
+                      hipMemcpyHostToDevice));
+    if (A->NZ > 0) {
+        HIP_TRY(hipMemcpy(d->ja, A->JA, (size_t)A->NZ * sizeof(int),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->as, A->AS, (size_t)A->NZ * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+    rc = finish_csr_handle(d, A->IRP);
+    if (rc)
+        goto fail;
+    *out = d;
+    return 0;
+fail:
+    spmv_csr_release(d);
+    return rc;
+}
+
+int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
+                      uint64_t seed, spmv_csr_dev **out) {
+    if (!out || M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED ||
+        kind > SYNTH_KKT || (kind == SYNTH_BANDED && N < K))
+        return -EINVAL;
+    *out = NULL;
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    synth_spec s = {kind, M, N, K, W, row0, seed};
+    int rc = 0;
+    spmv_csr_dev *d = NULL;
+    /* row lengths on the device, prefix sum on the host (O(M) ints) */
+    std::vector<int> irp((size_t)M + 1, 0);
+    if (M > 0) {
+        int *d_len = NULL;
+        HIP_RET(hipMalloc((void **)&d_len, (size_t)M * sizeof(int)));
+        hipLaunchKernelGGL(k_synth_lens, dim3((M + 255) / 256), dim3(256), 0,
+                           0, s, d_len);
+        hipError_t e = hipMemcpy(irp.data() + 1, d_len, (size_t)M * sizeof(int),
+                                 hipMemcpyDeviceToHost);
+        (void)hipFree(d_len);
+        if (e != hipSuccess)
+            return hip_errno(e);
+    }
+    int64_t nz = 0;
+    for (int i = 0; i < M; ++i) {
+        nz += irp[(size_t)i + 1];
+        if (nz > INT32_MAX)
+            return -EOVERFLOW;
+        irp[(size_t)i + 1] = (int)nz;
+    }
+    rc = csr_alloc_dev(M, N, nz, &d);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(d->irp, irp.data(), ((size_t)M + 1) * sizeof(int),
+                      hipMemcpyHostToDevice));
+    if (M > 0)
+        hipLaunchKernelGGL(k_synth_rows, dim3((M + 127) / 128), dim3(128), 0,
+                           0, s, d->irp, d->ja, d->as);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    rc = finish_csr_handle(d, irp.data());
+    if (rc)
+        goto fail;
+    *out = d;
+    return 0;
+fail:
+    spmv_csr_release(d);
+    return rc;
+}
+
+int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ) {
+    if (!A)
+        return -EINVAL;
+    if (M)
+        *M = A->M;
+    if (N)
+        *N = A->N;
+    if (NZ)
+        *NZ = A->NZ;
+    return 0;
+}
+
+int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A) {
+    return 12 * A->NZ + 4 * ((int64_t)A->M + 1) + 8 * (int64_t)A->M +
+           8 * (int64_t)A->N;
+}
+
+int spmv_csr_download(const spmv_csr_dev *A, sparse_csr **out) {
+    if (!A || !out)
+        return -EINVAL;
+    if (A->NZ > INT32_MAX)
+        return -EOVERFLOW;
+    sparse_csr *h = csr_alloc("device", A->M, A->N, (int)A->NZ);
+    if (IS_ERR(h))
+        return PTR_ERR(h);
+    int rc = 0;
+    HIP_TRY(hipMemcpy(h->IRP, A->irp, ((size_t)A->M + 1) * sizeof(int),
+                      hipMemcpyDeviceToHost));
+    if (A->NZ > 0) {
+        HIP_TRY(hipMemcpy(h->JA, A->ja, (size_t)A->NZ * sizeof(int),
+                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h->AS, A->as, (size_t)A->NZ * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    }
+    *out = h;
+    return 0;
+fail:
+    csr_free(h);
+    return rc;
+}
+
+int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
+                         const spmv_launch_opts *opts, const double *d_x,
+                         double *d_y, int row_begin, int row_end,
+                         void *stream) {
+    if (!A)
+        return -EINVAL;
+    return csr_launch_kernel(A, kernel, pick_waves(opts, g_csr_waves),
+                             opts ? opts->group : 0, d_x, d_y, row_begin,
+                             row_end, (hipStream_t)stream);
+}
+
+int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
+                    const spmv_launch_opts *opts, const double *d_x,
+                    double *d_y, void *stream) {
+    if (!A)
+        return -EINVAL;
+    return spmv_csr_launch_rows(A, kernel, opts, d_x, d_y, 0, A->M, stream);
+}
+
+/* ------------------------------------------------------------------ */
+/* HLL handle                                                           */
+/* ------------------------------------------------------------------ */
+
+void spmv_hll_release(spmv_hll_dev *d) {
+    if (!d)
+        return;
+    (void)hipFree(d->ja);
+    (void)hipFree(d->as);
+    (void)hipFree(d->off);
+    free(d);
+}
+
+static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
+                         const int64_t *host_off, spmv_hll_dev **out) {
+    int rc = 0;
+    spmv_hll_dev *d = (spmv_hll_dev *)calloc(1, sizeof *d);
+    if (!d)
+        return -ENOMEM;
+    d->M = M;
+    d->N = N;
+    d->NZ = NZ;
+    d->nb = nb;
+    d->col_major = col_major ? 1 : 0;
+    d->slots = host_off[nb];
+    HIP_TRY(hipGetDevice(&d->device));
+    /* +64 slots of slack: vector loads of the last chunk stay in bounds */
+    HIP_TRY(hipMalloc((void **)&d->ja, ((size_t)d->slots + 64) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->as, ((size_t)d->slots + 64) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&d->off, ((size_t)nb + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMemcpy(d->off, host_off, ((size_t)nb + 1) * sizeof(int64_t),
+                      hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+fail:
+    spmv_hll_release(d);
+    return rc;
+}
+
+int spmv_hll_upload(const sparse_hll *H, int is_col_major,
+                    spmv_hll_dev **out) {
+    if (!H || !out || H->hack_size != HACK_SIZE)
+        return -EINVAL;
+    *out = NULL;
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    const int nb = H->num_blocks;
+    std::vector<int64_t> off((size_t)nb + 1, 0);
+    int maxw = 0;
+    for (int b = 0; b < nb; ++b) {
+        off[(size_t)b + 1] =
+            off[b] + (int64_t)H->blocks[b].M * H->blocks[b].max_NZ;
+        maxw = std::max(maxw, H->blocks[b].max_NZ);
+    }
+    spmv_hll_dev *d = NULL;
+    int rc = hll_alloc_dev(H->M, H->N, H->NZ, nb, is_col_major, off.data(), &d);
+    if (rc)
+        return rc;
+    d->max_width = maxw;
+    if (d->slots > 0) {
+        if (hll_is_contiguous(H)) { /* slab-backed: two copies */
+            HIP_TRY(hipMemcpy(d->ja, H->blocks[0].JA,
+                              (size_t)d->slots * sizeof(int),
+                              hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d->as, H->blocks[0].AS,
+                              (size_t)d->slots * sizeof(double),
+                              hipMemcpyHostToDevice));
+        } else { /* blocks allocated one by one: pack while copying */
+            for (int b = 0; b < nb; ++b) {
+                size_t n = (size_t)(off[(size_t)b + 1] - off[b]);
+                if (!n)
+                    continue;
+                HIP_TRY(hipMemcpy(d->ja + off[b], H->blocks[b].JA,
+                                  n * sizeof(int), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(d->as + off[b], H->blocks[b].AS,
+                                  n * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
+        rc = hll_fix_pads_dev(d, 0);
+        if (rc)
+            goto fail;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    *out = d;
+    return 0;
+fail:
+    spmv_hll_release(d);
+    return rc;
+}
+
+int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
+                      spmv_hll_dev **out) {
+    if (!A || !out)
+        return -EINVAL;
+    *out = NULL;
+    const int M = A->M, nb = (M + 31) / 32;
+    int rc = 0;
+    int *d_w = NULL;
+    spmv_hll_dev *d = NULL;
+    std::vector<int> w((size_t)nb, 0);
+    std::vector<int64_t> off((size_t)nb + 1, 0);
+    int maxw = 0;
+    if (nb > 0) {
+        HIP_TRY(hipMalloc((void **)&d_w, (size_t)nb * sizeof(int)));
+        hipLaunchKernelGGL(k_block_width, dim3((M + 255) / 256), dim3(256), 0,
+                           0, M, A->irp, d_w);
+        HIP_TRY(hipMemcpy(w.data(), d_w, (size_t)nb * sizeof(int),
+                          hipMemcpyDeviceToHost));
+    }
+    for (int b = 0; b < nb; ++b) {
+        int rows = std::min(32, M - b * 32);
+        off[(size_t)b + 1] = off[b] + (int64_t)rows * w[b];
+        maxw = std::max(maxw, w[b]);
+    }
+    rc = hll_alloc_dev(M, A->N, A->NZ, nb, is_col_major, off.data(), &d);
+    if (rc)
+        goto fail;
+    d->max_width = maxw;
+    if (M > 0) {
+        hipLaunchKernelGGL(k_hll_fill, dim3((M + 255) / 256), dim3(256), 0, 0,
+                           M, d->col_major, A->irp, A->ja, A->as, d->off,
+                           d->ja, d->as);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    (void)hipFree(d_w);
+    *out = d;
+    return 0;
+fail:
+    (void)hipFree(d_w);
+    spmv_hll_release(d);
+    return rc;
+}
+
+int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
+                   int *num_blocks, int64_t *slots, int *is_col_major) {
+    if (!H)
+        return -EINVAL;
+    if (M)
+        *M = H->M;
+    if (N)
+        *N = H->N;
+    if (NZ)
+        *NZ = H->NZ;
+    if (num_blocks)
+        *num_blocks = H->nb;
+    if (slots)
+        *slots = H->slots;
+    if (is_col_major)
+        *is_col_major = H->col_major;
+    return 0;
+}
+
+int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H) {
+    return 12 * H->slots + 12 * (int64_t)H->nb + 8 * (int64_t)H->M +
+           8 * (int64_t)H->N;
+}
+
+int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
+                           const spmv_launch_opts *opts, const double *d_x,
+                           double *d_y, int blk_begin, int blk_end,
+                           void *stream) {
+    if (!H)
+        return -EINVAL;
+    int waves = pick_waves(opts, g_hll_waves);
+    if (kernel == 1 && waves > 8)
+        waves = 8; /* 6 KiB of LDS per wavefront, stay under 64 KiB */
+    return hll_launch_kernel(H, kernel, waves, d_x, d_y, blk_begin, blk_end,
+                             (hipStream_t)stream);
+}
+
+int spmv_hll_launch(const spmv_hll_dev *H, int kernel,
+                    const spmv_launch_opts *opts, const double *d_x,
+                    double *d_y, void *stream) {
+    if (!H)
+        return -EINVAL;
+    return spmv_hll_launch_blocks(H, kernel, opts, d_x, d_y, 0, H->nb, stream);
+}
+
+} /* extern "C" */
+
+/* ------------------------------------------------------------------ */
+/* event-timed loops                                                    */
+/* ------------------------------------------------------------------ */
+
+template <typename Launch>
+static int timed_loop(Launch launch, int warmup, int iters, size_t flush_bytes,
+                      double *ms_each, hipStream_t s) {
+    int rc = 0;
+    hipEvent_t e0 = NULL, e1 = NULL;
+    double *scratch = NULL;
+    size_t nflush = flush_bytes / sizeof(double);
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    if (nflush) {
+        HIP_TRY(hipMalloc((void **)&scratch, nflush * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(scratch, 0, nflush * sizeof(double), s));
+    }
+    for (int it = -warmup; it < iters; ++it) {
+        if (nflush)
+            hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, s, scratch,
+                               nflush);
+        HIP_TRY(hipEventRecord(e0, s));
+        rc = launch();
+        if (rc)
+            goto fail;
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        if (it >= 0) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            ms_each[it] = (double)ms;
+        }
+    }
+fail:
+    if (e0)
+        (void)hipEventDestroy(e0);
+    if (e1)
+        (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    return rc;
+}
+
+extern "C" {
+
+int spmv_csr_time(const spmv_csr_dev *A, int kernel,
+                  const spmv_launch_opts *opts, const double *d_x, double *d_y,
+                  int warmup, int iters, size_t flush_bytes, double *ms_each,
+                  void *stream) {
+    if (!A || iters < 0 || warmup < 0 || (iters && !ms_each))
+        return -EINVAL;
+    return timed_loop(
+        [&]() { return spmv_csr_launch(A, kernel, opts, d_x, d_y, stream); },
+        warmup, iters, flush_bytes, ms_each, (hipStream_t)stream);
+}
+
+int spmv_hll_time(const spmv_hll_dev *H, int kernel,
+                  const spmv_launch_opts *opts, const double *d_x, double *d_y,
+                  int warmup, int iters, size_t flush_bytes, double *ms_each,
+                  void *stream) {
+    if (!H || iters < 0 || warmup < 0 || (iters && !ms_each))
+        return -EINVAL;
+    return timed_loop(
+        [&]() { return spmv_hll_launch(H, kernel, opts, d_x, d_y, stream); },
+        warmup, iters, flush_bytes, ms_each, (hipStream_t)stream);
+}
+
+/* ------------------------------------------------------------------ */
+/* one-shot entry points: the reference's seam (hip_csr.h / hip_hll.h)  */
+/* upload -> one event-timed launch -> download -> release              */
+/* (reference cuda_csr.cu:210-234, cuda_hll.cu:235-260)                 */
+/* ------------------------------------------------------------------ */
+
+static double one_shot_vectors(int M, int N, const double *x, double *y,
+                               double **d_x, double **d_y) {
+    int rc = 0;
+    *d_x = *d_y = NULL;
+    HIP_TRY(hipMalloc((void **)d_x, std::max<size_t>(N, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)d_y, std::max<size_t>(M, 1) * sizeof(double)));
+    if (N > 0)
+        HIP_TRY(hipMemcpy(*d_x, x, (size_t)N * sizeof(double),
+                          hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(*d_y, 0, std::max<size_t>(M, 1) * sizeof(double)));
+    (void)y;
+fail:
+    return (double)rc;
+}
+
+static double csr_one_shot(const sparse_csr *A, const double *x, double *y,
+                           void *arg, int kernel) {
+    if (!A || !x || !y)
+        return -EINVAL;
+    const spmv_launch_opts *opts = (const spmv_launch_opts *)arg;
+    spmv_csr_dev *d = NULL;
+    double *d_x = NULL, *d_y = NULL, ms = 0.0;
+    int rc = spmv_csr_upload(A, &d);
+    if (rc)
+        return rc;
+    rc = (int)one_shot_vectors(A->M, A->N, x, y, &d_x, &d_y);
+    if (!rc)
+        rc = spmv_csr_time(d, kernel, opts, d_x, d_y, 0, 1, 0, &ms, NULL);
+    if (!rc && A->M > 0)
+        rc = spmv_copy_d2h(y, d_y, (size_t)A->M * sizeof(double));
+    (void)hipFree(d_x);
+    (void)hipFree(d_y);
+    spmv_csr_release(d);
+    return rc ? (double)rc : ms;
+}
+
+static double hll_one_shot(const sparse_hll *H, const double *x, double *y,
+                           void *arg, int kernel, int col_major) {
+    if (!H || !x || !y)
+        return -EINVAL;
+    const spmv_launch_opts *opts = (const spmv_launch_opts *)arg;
+    spmv_hll_dev *d = NULL;
+    double *d_x = NULL, *d_y = NULL, ms = 0.0;
+    int rc = spmv_hll_upload(H, col_major, &d);
+    if (rc)
+        return rc;
+    rc = (int)one_shot_vectors(H->M, H->N, x, y, &d_x, &d_y);
+    if (!rc)
+        rc = spmv_hll_time(d, kernel, opts, d_x, d_y, 0, 1, 0, &ms, NULL);
+    if (!rc && H->M > 0)
+        rc = spmv_copy_d2h(y, d_y, (size_t)H->M * sizeof(double));
+    (void)hipFree(d_x);
+    (void)hipFree(d_y);
+    spmv_hll_release(d);
+    return rc ? (double)rc : ms;
+}
+
+double csr_spmv_hip_thread_row(const sparse_csr *A, const double *x, double *y,
+                               void *arg) {
+    return csr_one_shot(A, x, y, arg, 0);
+}
+double csr_spmv_hip_wave_row(const sparse_csr *A, const double *x, double *y,
+                             void *arg) {
+    return csr_one_shot(A, x, y, arg, 1);
+}
+double csr_spmv_hip_subwave_row(const sparse_csr *A, const double *x,
+                                double *y, void *arg) {
+    return csr_one_shot(A, x, y, arg, 2);
+}
+double csr_spmv_hip_block_row(const sparse_csr *A, const double *x, double *y,
+                              void *arg) {
+    return csr_one_shot(A, x, y, arg, 3);
+}
+double csr_spmv_hip_stream(const sparse_csr *A, const double *x, double *y,
+                           void *arg) {
+    return csr_one_shot(A, x, y, arg, 4);
+}
+
+double hll_spmv_hip_threads_row_major(const sparse_hll *H, const double *x,
+                                      double *y, void *arg) {
+    return hll_one_shot(H, x, y, arg, 0, 0);
+}
+double hll_spmv_hip_threads_col_major(const sparse_hll *H, const double *x,
+                                      double *y, void *arg) {
+    return hll_one_shot(H, x, y, arg, 1, 1);
+}
+double hll_spmv_hip_wave_block(const sparse_hll *H, const double *x, double *y,
+                               void *arg) {
+    return hll_one_shot(H, x, y, arg, 2, 1);
+}
+double hll_spmv_hip_subwave_row(const sparse_hll *H, const double *x,
+                                double *y, void *arg) {
+    return hll_one_shot(H, x, y, arg, 3, 0);
+}
+
+/* ------------------------------------------------------------------ */
+/* the reference's own symbol names (include/spmv_ref_abi.h)            */
+/* ------------------------------------------------------------------ */
+void set_csr_warps_per_block(int w) { set_csr_waves_per_block(w); }
+void set_hll_warps_per_block(int w) { set_hll_waves_per_block(w); }
+
+double csr_spmv_cuda_thread_row(const sparse_csr *A, const double *x,
+                                double *y, void *unused) {
+    (void)unused;
+    return csr_one_shot(A, x, y, NULL, 0);
+}
+double csr_spmv_cuda_warp_row(const sparse_csr *A, const double *x, double *y,
+                              void *unused) {
+    (void)unused;
+    return csr_one_shot(A, x, y, NULL, 1);
+}
+double csr_spmv_cuda_halfwarp_row(const sparse_csr *A, const double *x,
+                                  double *y, void *unused) {
+    (void)unused;
+    return csr_one_shot(A, x, y, NULL, 2);
+}
+double csr_spmv_cuda_block_row(const sparse_csr *A, const double *x, double *y,
+                               void *unused) {
+    (void)unused;
+    return csr_one_shot(A, x, y, NULL, 3);
+}
+double csr_spmv_cuda_halfwarp_row_text(const sparse_csr *A, const double *x,
+                                       double *y, void *unused) {
+    (void)unused;
+    return csr_one_shot(A, x, y, NULL, 4);
+}
+double hll_spmv_cuda_threads_row_major(const sparse_hll *H, const double *x,
+                                       double *y, void *unused) {
+    (void)unused;
+    return hll_one_shot(H, x, y, NULL, 0, 0);
+}
+double hll_spmv_cuda_threads_col_major(const sparse_hll *H, const double *x,
+                                       double *y, void *unused) {
+    (void)unused;
+    return hll_one_shot(H, x, y, NULL, 1, 1);
+}
+double hll_spmv_cuda_warp_block(const sparse_hll *H, const double *x,
+                                double *y, void *unused) {
+    (void)unused;
+    return hll_one_shot(H, x, y, NULL, 2, 1);
+}
+double hll_spmv_cuda_halfwarp_row(const sparse_hll *H, const double *x,
+                                  double *y, void *unused) {
+    (void)unused;
+    return hll_one_shot(H, x, y, NULL, 3, 0);
+}
+
+} /* extern "C" */

@@ -1,0 +1,104 @@
+/*
+ * hip_common.h -- internals shared by the HIP translation units
+ * (engine.hip, csr_kernels.hip, hll_kernels.hip).  Not installed.
+ */
+#ifndef SPMV_HIP_COMMON_H
+#define SPMV_HIP_COMMON_H
+
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spmv_engine.h"
+
+#define WAVE 64 /* gfx950 wavefront */
+
+/* HIP status -> negative errno (the host API's error convention) */
+static inline int hip_errno(hipError_t e) {
+    switch (e) {
+    case hipSuccess:
+        return 0;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice:
+    case hipErrorInsufficientDriver:
+    case hipErrorNotInitialized:
+        return -ENODEV;
+    case hipErrorOutOfMemory:
+        return -ENOMEM;
+    case hipErrorInvalidValue:
+    case hipErrorInvalidConfiguration:
+        return -EINVAL;
+    default:
+        return -EIO;
+    }
+}
+
+#define HIP_TRY(call)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            rc = hip_errno(e_);                                               \
+            goto fail;                                                        \
+        }                                                                     \
+    } while (0)
+
+#define HIP_RET(call)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess)                                                 \
+            return hip_errno(e_);                                             \
+    } while (0)
+
+/* nnz budget of one workgroup of the CSR stream kernel */
+#define STREAM_NNZ 2048
+#define STREAM_THREADS 256
+
+struct spmv_csr_dev {
+    int M, N;
+    int64_t NZ;
+    int device;
+    int *irp;   /* [M+1] */
+    int *ja;    /* [NZ]  */
+    double *as; /* [NZ]  */
+    /* stream kernel: workgroup k owns rows [rowblk[k], rowblk[k+1]) */
+    int *rowblk;
+    int n_rowblk;
+    int max_row_len;
+};
+
+struct spmv_hll_dev {
+    int M, N;
+    int64_t NZ;
+    int device;
+    int nb;        /* hack blocks */
+    int col_major; /* layout inside a block */
+    int64_t slots; /* S */
+    int max_width; /* largest max_NZ */
+    int *ja;       /* [S] pads already rewritten */
+    double *as;    /* [S] */
+    int64_t *off;  /* [nb+1] slot offset of each block */
+};
+
+/* clamp the launch knob: waves per workgroup */
+static inline int pick_waves(const spmv_launch_opts *o, int dflt) {
+    int w = (o && o->waves_per_block > 0) ? o->waves_per_block : dflt;
+    if (w < 1)
+        w = 1;
+    if (w > 16)
+        w = 16;
+    return w;
+}
+
+/* kernel launchers (csr_kernels.hip / hll_kernels.hip) */
+int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
+                      const double *x, double *y, int r0, int r1,
+                      hipStream_t s);
+int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
+                      const double *x, double *y, int b0, int b1,
+                      hipStream_t s);
+int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s);
+
+extern int g_csr_waves; /* process defaults behind set_*_waves_per_block */
+extern int g_hll_waves;
+
+#endif /* SPMV_HIP_COMMON_H */

@@ -1,0 +1,308 @@
+/*
+ * hll_kernels.hip -- fp64 HLL (hacked ELLPACK, hack = 32) SpMV kernels for
+ * gfx950 (wave64).
+ *
+ * Four kernels fill the four slots of the reference's driver table
+ * (reference cuda_hll.cu:19-152, main.c:310-315); the designs are new.
+ * Device layout: one JA slab and one AS slab; hack block b occupies slots
+ * [off[b], off[b+1]) with rows_b = min(32, M - 32 b) rows and width
+ * w_b = (off[b+1] - off[b]) / rows_b; pads already point at a valid column
+ * and carry the value 0.0 (hip_hll.h).
+ *
+ *   0 threads_row_major  lane per row; slot(i,j) = i*w + j.
+ *   1 threads_col_major  lane per row; a 64-lane wavefront owns TWO hack
+ *                        blocks (lanes 0-31 / 32-63).  Each block's slab is
+ *                        contiguous, so the wavefront copies it to LDS in
+ *                        chunks of 8 columns with 16 B/lane loads (1 KiB per
+ *                        instruction, fully coalesced), then every lane
+ *                        walks its row out of LDS (conflict-free: lane i
+ *                        reads word j*32+i) and gathers x.
+ *   2 wave_block         same mapping, direct global loads, no LDS.
+ *   3 subwave_row        16 lanes per row over row-major blocks,
+ *                        __shfl_down(width 16) reduction.
+ *
+ * No MFMA (no dense contraction).  JA/AS stream once -> non-temporal loads;
+ * x gathers are ordinary cached loads.
+ */
+#include "hip_common.h"
+
+#define HACK 32
+
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) {
+    return __builtin_nontemporal_load(p);
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+/* ------------------------------------------------------------------ */
+/* pad rewrite on the device (reference cuda_hll.cu:173-195 does it on  */
+/* the host, block by block): pad -> previous valid column, or 0.        */
+/* ------------------------------------------------------------------ */
+__global__ void k_hll_fix_pads(int M, int col_major,
+                               const int64_t *__restrict__ off,
+                               int *__restrict__ ja) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M)
+        return;
+    int b = row / HACK, i = row % HACK;
+    int rows = min(HACK, M - b * HACK);
+    int64_t o = off[b];
+    int w = (int)((off[b + 1] - o) / rows);
+    int last = 0;
+    for (int j = 0; j < w; ++j) {
+        int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
+        int c = ja[t];
+        if (c < 0)
+            ja[t] = last;
+        else
+            last = c;
+    }
+}
+
+int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s) {
+    if (H->M == 0)
+        return 0;
+    hipLaunchKernelGGL(k_hll_fix_pads, dim3((H->M + 255) / 256), dim3(256), 0,
+                       s, H->M, H->col_major, H->off, H->ja);
+    return hip_errno(hipGetLastError());
+}
+
+/* ------------------------------------------------------------------ */
+/* 0: lane per row, row-major                                           */
+/* ------------------------------------------------------------------ */
+__global__ void k_hll_row_major(int M, int b0, int b1,
+                                const int64_t *__restrict__ off,
+                                const int *__restrict__ ja,
+                                const double *__restrict__ as,
+                                const double *__restrict__ x,
+                                double *__restrict__ y) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int b = b0 + (int)(t / HACK), i = (int)(t % HACK);
+    if (b >= b1)
+        return;
+    int rows = min(HACK, M - b * HACK);
+    if (i >= rows)
+        return;
+    int64_t o = off[b];
+    int w = (int)((off[b + 1] - o) / rows);
+    const int *rj = ja + o + (int64_t)i * w;
+    const double *ra = as + o + (int64_t)i * w;
+    double acc = 0.0;
+    for (int j = 0; j < w; ++j)
+        acc += ld_stream(ra + j) * x[ld_stream(rj + j)];
+    y[(int64_t)b * HACK + i] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+/* 2: wavefront per pair of hack blocks, col-major, direct loads        */
+/* ------------------------------------------------------------------ */
+__global__ void k_hll_col_direct(int M, int b0, int b1,
+                                 const int64_t *__restrict__ off,
+                                 const int *__restrict__ ja,
+                                 const double *__restrict__ as,
+                                 const double *__restrict__ x,
+                                 double *__restrict__ y) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int b = b0 + (int)(t / HACK), i = (int)(t % HACK);
+    if (b >= b1)
+        return;
+    int rows = min(HACK, M - b * HACK);
+    if (i >= rows)
+        return;
+    int64_t o = off[b];
+    int w = (int)((off[b + 1] - o) / rows);
+    const int *cj = ja + o + i;
+    const double *ca = as + o + i;
+    double acc = 0.0;
+    int j = 0;
+    for (; j + 4 <= w; j += 4) {
+        int c0 = ld_stream(cj + (int64_t)(j + 0) * rows);
+        int c1 = ld_stream(cj + (int64_t)(j + 1) * rows);
+        int c2 = ld_stream(cj + (int64_t)(j + 2) * rows);
+        int c3 = ld_stream(cj + (int64_t)(j + 3) * rows);
+        double a0 = ld_stream(ca + (int64_t)(j + 0) * rows);
+        double a1 = ld_stream(ca + (int64_t)(j + 1) * rows);
+        double a2 = ld_stream(ca + (int64_t)(j + 2) * rows);
+        double a3 = ld_stream(ca + (int64_t)(j + 3) * rows);
+        double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc += a0 * x0;
+        acc += a1 * x1;
+        acc += a2 * x2;
+        acc += a3 * x3;
+    }
+    for (; j < w; ++j)
+        acc += ld_stream(ca + (int64_t)j * rows) *
+               x[ld_stream(cj + (int64_t)j * rows)];
+    y[(int64_t)b * HACK + i] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+/* 1: lane per row, col-major, hack blocks staged through LDS           */
+/*    (full 32-row blocks only; the launcher sends a ragged tail block  */
+/*    to k_hll_col_direct)                                              */
+/* ------------------------------------------------------------------ */
+#define CH 8                     /* columns per staged chunk */
+#define CH_SLOTS (CH * HACK)     /* 256 slots: 1 KiB of JA, 2 KiB of AS */
+
+__global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
+                              const int *__restrict__ ja,
+                              const double *__restrict__ as,
+                              const double *__restrict__ x,
+                              double *__restrict__ y) {
+    /* per wavefront: two blocks x (256 ints + 256 doubles) = 6 KiB */
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    const int waves = blockDim.x / WAVE;
+    double *s_as = (double *)lds_raw + (size_t)wave * 2 * CH_SLOTS;
+    int *s_ja = (int *)((double *)lds_raw + (size_t)waves * 2 * CH_SLOTS) +
+                (size_t)wave * 2 * CH_SLOTS;
+
+    const int bA = b0 + 2 * (blockIdx.x * waves + wave); /* wave-uniform */
+    if (bA >= b1)
+        return;
+    const bool hasB = bA + 1 < b1;
+    const int64_t oA = off[bA], oB = off[bA + 1];
+    const int nA = (int)(oB - oA); /* slots of block A = 32 * wA */
+    const int nB = hasB ? (int)(off[bA + 2] - oB) : 0;
+    const int half = lane >> 5, i = lane & 31;
+    const int w = (half ? nB : nA) >> 5;
+    const int nmax = nA > nB ? nA : nB;
+
+    const int *gjA = ja + oA, *gjB = ja + oB;
+    const double *gaA = as + oA, *gaB = as + oB;
+    double acc = 0.0;
+
+    for (int s0 = 0; s0 < nmax; s0 += CH_SLOTS) {
+        /* coalesced 16 B/lane copies of the chunk [s0, s0+256) of each block */
+        const int sj = s0 + 4 * lane;       /* 4 ints   */
+        const int sa = s0 + 2 * lane;       /* 2 doubles, twice */
+        v4i jA = {0, 0, 0, 0}, jB = {0, 0, 0, 0};
+        v2d aA0 = {0, 0}, aA1 = {0, 0}, aB0 = {0, 0}, aB1 = {0, 0};
+        if (sj < nA)
+            jA = ld_stream((const v4i *)(gjA + sj));
+        if (sj < nB)
+            jB = ld_stream((const v4i *)(gjB + sj));
+        if (sa < nA)
+            aA0 = ld_stream((const v2d *)(gaA + sa));
+        if (sa + 128 < nA)
+            aA1 = ld_stream((const v2d *)(gaA + sa + 128));
+        if (sa < nB)
+            aB0 = ld_stream((const v2d *)(gaB + sa));
+        if (sa + 128 < nB)
+            aB1 = ld_stream((const v2d *)(gaB + sa + 128));
+        *(v4i *)(s_ja + 4 * lane) = jA;
+        *(v4i *)(s_ja + CH_SLOTS + 4 * lane) = jB;
+        *(v2d *)(s_as + 2 * lane) = aA0;
+        *(v2d *)(s_as + 128 + 2 * lane) = aA1;
+        *(v2d *)(s_as + CH_SLOTS + 2 * lane) = aB0;
+        *(v2d *)(s_as + CH_SLOTS + 128 + 2 * lane) = aB1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int c0 = s0 >> 5;
+        const int *lj = s_ja + half * CH_SLOTS + i;
+        const double *la = s_as + half * CH_SLOTS + i;
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            if (c0 + jj < w) {
+                int c = lj[jj * HACK];
+                acc += la[jj * HACK] * x[c];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (half == 0 || hasB)
+        y[(int64_t)(bA + half) * HACK + i] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+/* 3: 16 lanes per row, row-major                                       */
+/* ------------------------------------------------------------------ */
+__global__ void k_hll_subwave_row(int M, int b0, int b1,
+                                  const int64_t *__restrict__ off,
+                                  const int *__restrict__ ja,
+                                  const double *__restrict__ as,
+                                  const double *__restrict__ x,
+                                  double *__restrict__ y) {
+    const int sub = threadIdx.x & 15;
+    long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int b = b0 + (int)(g / HACK), i = (int)(g % HACK);
+    double acc = 0.0;
+    bool live = false;
+    if (b < b1) {
+        int rows = min(HACK, M - b * HACK);
+        if (i < rows) {
+            live = true;
+            int64_t o = off[b];
+            int w = (int)((off[b + 1] - o) / rows);
+            const int *rj = ja + o + (int64_t)i * w;
+            const double *ra = as + o + (int64_t)i * w;
+            for (int j = sub; j < w; j += 16)
+                acc += ld_stream(ra + j) * x[ld_stream(rj + j)];
+        }
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1)
+        acc += __shfl_down(acc, d, 16);
+    if (live && sub == 0)
+        y[(int64_t)b * HACK + i] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
+                      const double *x, double *y, int b0, int b1,
+                      hipStream_t s) {
+    if (!H || !x || !y || b0 < 0 || b1 > H->nb || b0 > b1)
+        return -EINVAL;
+    if ((kernel == 0 || kernel == 3) == (H->col_major != 0))
+        return -EINVAL; /* layout of the handle does not fit the kernel */
+    if (b0 == b1)
+        return 0;
+    const int threads = waves * WAVE;
+    const long long lanes = (long long)(b1 - b0) * HACK;
+    switch (kernel) {
+    case 0:
+        hipLaunchKernelGGL(k_hll_row_major,
+                           dim3((unsigned)((lanes + threads - 1) / threads)),
+                           dim3(threads), 0, s, H->M, b0, b1, H->off, H->ja,
+                           H->as, x, y);
+        break;
+    case 1: {
+        /* full blocks through LDS; a ragged last block goes direct */
+        int full_end = b1;
+        if (b1 == H->nb && (H->M % HACK) != 0)
+            full_end = b1 - 1;
+        if (full_end > b0) {
+            int pairs = (full_end - b0 + 1) / 2;
+            size_t lds = (size_t)waves * 2 * CH_SLOTS * (sizeof(double) + sizeof(int));
+            hipLaunchKernelGGL(k_hll_col_lds,
+                               dim3((pairs + waves - 1) / waves),
+                               dim3(threads), lds, s, b0, full_end, H->off,
+                               H->ja, H->as, x, y);
+        }
+        if (full_end < b1)
+            hipLaunchKernelGGL(k_hll_col_direct, dim3(1), dim3(WAVE), 0, s,
+                               H->M, full_end, b1, H->off, H->ja, H->as, x, y);
+        break;
+    }
+    case 2:
+        hipLaunchKernelGGL(k_hll_col_direct,
+                           dim3((unsigned)((lanes + threads - 1) / threads)),
+                           dim3(threads), 0, s, H->M, b0, b1, H->off, H->ja,
+                           H->as, x, y);
+        break;
+    case 3:
+        hipLaunchKernelGGL(
+            k_hll_subwave_row,
+            dim3((unsigned)((lanes * 16 + threads - 1) / threads)),
+            dim3(threads), 0, s, H->M, b0, b1, H->off, H->ja, H->as, x, y);
+        break;
+    default:
+        return -EINVAL;
+    }
+    return hip_errno(hipGetLastError());
+}

@@ -1,0 +1,77 @@
+/* utils.c -- allocation, validation and usage text (API: include/utils.h). */
+#include <math.h>
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "utils.h"
+
+void *aligned_malloc(size_t size) {
+    void *p = NULL;
+    if (posix_memalign(&p, ALIGNMENT, size ? size : ALIGNMENT) != 0)
+        return NULL;
+    return p;
+}
+
+/* The reference's -d criterion (utils.c:39-60): absolute L2 distance. */
+int validation_vec_result(const vec expected, const vec res) {
+    if (expected.len != res.len)
+        return -1;
+    double acc = 0.0;
+    for (size_t i = 0; i < res.len; ++i) {
+        double d = expected.data[i] - res.data[i];
+        acc += d * d;
+    }
+    return sqrt(acc) > 1e-1 ? -1 : 0;
+}
+
+double max_rel_err(const vec expected, const vec res, const double *scale) {
+    if (expected.len != res.len)
+        return -1.0;
+    double worst = 0.0;
+    for (size_t i = 0; i < res.len; ++i) {
+        double den = fabs(expected.data[i]);
+        double fl = scale ? 1e-3 * scale[i] : 0.0;
+        if (fl > den)
+            den = fl;
+        if (den < 1e-300)
+            den = 1e-300;
+        double e = fabs(res.data[i] - expected.data[i]) / den;
+        if (e > worst || e != e)
+            worst = (e != e) ? INFINITY : e;
+    }
+    return worst;
+}
+
+void log_prog_usage(const char *prog) {
+    fprintf(stderr,
+            "Usage: %s (-m <matrix.mtx> | -s <family>) -o <out-dir> [options]\n"
+            "  -m, --matrix <file>     Matrix Market file to process\n"
+            "  -s, --synthetic <kind>  banded | random | ragged | kkt\n"
+            "      --rows <M> --nnz-row <K> --window <W>   synthetic shape\n"
+            "  -o, --out <dir>         directory for serial.csv omp.csv cuda.csv\n"
+            "  -d, --debug             validate every result against serial CSR\n"
+            "  -g, --gpus <n>          GPUs to row-partition over (default 1)\n"
+            "  -i, --iters <n>         timed GPU launches per kernel (default 20)\n"
+            "      --no-cpu            skip the serial / OpenMP benchmarks\n"
+            "  -h, --help              show this message\n",
+            prog);
+}
+
+void print_result_vector(const vec res) {
+    printf("Result vector y (length %zu)\n", res.len);
+    for (size_t i = 0; i < res.len; ++i)
+        printf("  y[%zu] = %.4f\n", i, res.data[i]);
+    printf("\n");
+}
+
+void omp_warmup(int num_threads) {
+    if (num_threads < 1)
+        num_threads = 1;
+    double sink = 0.0;
+#pragma omp parallel for schedule(guided) num_threads(num_threads) reduction(+ : sink)
+    for (int j = 0; j < 1000000; ++j)
+        sink += j * 0.5;
+    volatile double keep = sink;
+    (void)keep;
+}

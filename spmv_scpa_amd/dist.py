@@ -1,0 +1,223 @@
+"""Row-partitioned multi-GPU SpMV: one process per GPU, RCCL over xGMI.
+
+The reference is single-GPU and has no collective; this is new.
+Scheme: contiguous row ranges whose boundaries are multiples of
+the hack size (32) so no HLL block straddles two GPUs; every rank holds the
+full-length x and a full-length y, computes its own fragment
+y[row0 : row0 + rows] with the local kernel, then the fragments are
+exchanged so that every rank ends with the whole y (the next x of an
+iterative method).
+
+Exchange modes
+  "allgather"  one in-place all_gather_into_tensor (ncclAllGather) per step.
+  "p2p"        the shard is cut into row chunks; as soon as the kernel of
+               chunk c has finished, chunk c is sent to every peer with
+               grouped isend/irecv (ncclSend/ncclRecv inside one group,
+               landing directly in the peer's y) while the kernel of chunk
+               c+1 runs: xGMI is point-to-point, so each of the 7 links
+               carries one peer's chunk.
+
+`compute` is pluggable so that the partition + exchange logic is testable on
+CPU with the gloo backend (tests/test_dist_gloo.py); the product binds it to
+the HIP launch.
+"""
+import numpy as np
+
+HACK = 32
+
+
+def even_row_partition(total_rows, world, align=HACK):
+    """starts[world+1]; equal counts rounded up to `align` (csr.h
+    partition_rows_even has the same arithmetic)."""
+    per = -(-total_rows // world)
+    per = -(-per // align) * align
+    return [min(per * k, total_rows) for k in range(world + 1)]
+
+
+def chunk_bounds(rows, chunks, align=HACK):
+    """row chunk boundaries of one shard, multiples of `align`."""
+    chunks = max(1, min(chunks, max(1, rows // align)))
+    per = -(-rows // chunks)
+    per = -(-per // align) * align
+    b = [min(per * k, rows) for k in range(chunks + 1)]
+    return [v for i, v in enumerate(b) if i == 0 or v > b[i - 1]]
+
+
+class ShardExchange:
+    """Exchange of equally sized y fragments between `world` ranks.
+
+    y is the full-length vector (rows_per_rank * world); rank r owns
+    y[r*rows_per_rank : (r+1)*rows_per_rank].
+    """
+
+    def __init__(self, y, rank, world, rows_per_rank, mode="allgather",
+                 group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.y, self.rank, self.world = y, rank, world
+        self.rows = rows_per_rank
+        self.mode = mode
+        self.group = group
+        assert y.numel() == rows_per_rank * world
+        self.mine = y[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+
+    def gather_all(self):
+        """whole fragments, in place"""
+        if self.world == 1:
+            return None
+        if self.mode == "allgather":
+            return self.dist.all_gather_into_tensor(self.y, self.mine,
+                                                    group=self.group,
+                                                    async_op=True)
+        return self.send_chunk(0, self.rows)
+
+    def send_chunk(self, a, b):
+        """rows [a, b) of every rank's fragment -> every other rank (grouped
+        point-to-point; returns the list of requests)"""
+        if self.world == 1 or b <= a:
+            return []
+        ops = []
+        for step in range(1, self.world):
+            dst = (self.rank + step) % self.world
+            src = (self.rank - step) % self.world
+            ops.append(self.dist.P2POp(self.dist.isend, self.mine[a:b], dst,
+                                       group=self.group))
+            ops.append(self.dist.P2POp(
+                self.dist.irecv,
+                self.y[src * self.rows + a:src * self.rows + b], src,
+                group=self.group))
+        return self.dist.batch_isend_irecv(ops)
+
+
+def wait_all(work):
+    if work is None:
+        return
+    if isinstance(work, (list, tuple)):
+        for w in work:
+            w.wait()
+    else:
+        work.wait()
+
+
+class ShardedSpmv:
+    """One rank's part of y = A x over `world` GPUs.
+
+    mat            CsrDevice or HllDevice holding rows [row0, row0+rows)
+    x, y           full-length torch tensors on this rank's GPU
+    chunks         > 1: overlap the exchange of chunk c with the kernel of c+1
+    """
+
+    def __init__(self, mat, kernel, rank, world, rows_per_rank, x, y,
+                 waves_per_block=0, chunks=1, mode=None, compute=None):
+        import torch
+        self.torch = torch
+        self.mat, self.kernel = mat, kernel
+        self.rank, self.world, self.rows = rank, world, rows_per_rank
+        self.x, self.y = x, y
+        self.waves = waves_per_block
+        self.row0 = rank * rows_per_rank
+        self.bounds = chunk_bounds(rows_per_rank, chunks)
+        if mode is None:
+            mode = "allgather" if len(self.bounds) <= 2 else "p2p"
+        self.ex = ShardExchange(y, rank, world, rows_per_rank, mode)
+        self.compute = compute or self._launch
+        self.is_hll = hasattr(mat, "num_blocks")
+
+    # product compute: the HIP kernel on torch's current stream
+    def _launch(self, a, b):
+        st = self.torch.cuda.current_stream().cuda_stream
+        d_x = self.x.data_ptr()
+        d_y = self.y.data_ptr() + 8 * self.row0
+        if a == 0 and b == self.rows:
+            self.mat.launch(self.kernel, d_x, d_y,
+                            waves_per_block=self.waves, stream=st)
+        elif self.is_hll:
+            self.mat.launch(self.kernel, d_x, d_y, waves_per_block=self.waves,
+                            stream=st, blocks=(a // HACK, -(-b // HACK)))
+        else:
+            self.mat.launch(self.kernel, d_x, d_y, waves_per_block=self.waves,
+                            stream=st, rows=(a, b))
+
+    def step(self, events=None):
+        """one SpMV (+ exchange).  events = (start, stop) torch events
+        recorded around the kernel launches on the current stream."""
+        if events:
+            events[0].record()
+        if self.world == 1:
+            self.compute(0, self.rows)
+            if events:
+                events[1].record()
+            return
+        pending = []
+        nb = len(self.bounds) - 1
+        for c in range(nb):
+            a, b = self.bounds[c], self.bounds[c + 1]
+            self.compute(a, b)
+            if c == nb - 1 and events:
+                events[1].record()
+            # torch's NCCL ops wait for the current stream's work enqueued so
+            # far (the kernel of this chunk) and run on the communicator's
+            # own stream: the next chunk's kernel overlaps with them
+            if nb == 1:
+                pending.append(self.ex.gather_all())
+            else:
+                pending.append(self.ex.send_chunk(a, b))
+        for w in pending:
+            wait_all(w)
+
+
+def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
+    """Secondary numbers for the same JSON line: the other kernels on the
+    headline matrix, other column windows, and config 2 (banded CSR)."""
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+
+    def med(v):
+        return float(np.median(v))
+
+    def row(tag, m, k, ms):
+        b = m.algorithmic_bytes
+        out[tag] = {"kernel_ms": round(ms, 5),
+                    "gflops": round(2.0 * m.NZ / (ms * 1e6), 1),
+                    "gbps": round(b / (ms * 1e6), 1),
+                    "roofline_frac": round(b / (ms * 1e6) / 8000.0, 4)}
+
+    if hasattr(mat, "num_blocks"):
+        for k in (1, 2):
+            if S.HLL_KERNEL_COL_MAJOR[k] == mat.col_major:
+                ms = med(mat.time(k, x.data_ptr(), y.data_ptr(), 2, 10, 0,
+                                  args.waves, stream=st))
+                row("headline_hll_%s" % S.HLL_KERNEL_NAMES[k], mat, k, ms)
+    # other column windows of the same 10M x 10M, 32/row family
+    for wname, W in (("W=2^20", 1 << 20), ("W=2^14", 1 << 14)):
+        try:
+            dA = S.CsrDevice.generate(kind, Mloc, Nglob, K, W, 0, 42)
+            dH = dA.to_hll(True)
+            for k in (1, 2):
+                ms = med(dH.time(k, x.data_ptr(), y.data_ptr(), 2, 10, 0,
+                                 args.waves, stream=st))
+                row("hll_%s_%s" % (S.HLL_KERNEL_NAMES[k], wname), dH, k, ms)
+            ms = med(dA.time(2, x.data_ptr(), y.data_ptr(), 2, 10, 0,
+                             args.waves, stream=st))
+            row("csr_subwave_row_%s" % wname, dA, 2, ms)
+            dH.release()
+            dA.release()
+        except OSError as e:  # out of memory on a small card, etc.
+            out["error_" + wname] = str(e)
+    # config 2: 1M x 1M banded CSR, 16/row; 212 MB working set < 256 MiB
+    # Infinity Cache, so every timed launch is preceded by a 512 MiB flush
+    try:
+        dB = S.CsrDevice.generate(S.SYNTH_BANDED, 1_000_000, 1_000_000, 16, 0,
+                                  0, 42)
+        for k in (1, 2, 4):
+            ms = med(dB.time(k, x.data_ptr(), y.data_ptr(), 2, 10, 512 << 20,
+                             args.waves, stream=st))
+            row("config2_banded_csr_%s_flushed" % S.CSR_KERNEL_NAMES[k], dB, k,
+                ms)
+        ms = med(dB.time(2, x.data_ptr(), y.data_ptr(), 2, 10, 0, args.waves,
+                         stream=st))
+        row("config2_banded_csr_subwave_row_cached", dB, 2, ms)
+        dB.release()
+    except OSError as e:
+        out["error_config2"] = str(e)
+    return out

@@ -1,0 +1,58 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-N gloo job.
+
+Exercises the product's partition + exchange logic (spmv_scpa_amd/dist.py)
+on CPU tensors.  The local compute is the CPU oracle -- test infrastructure,
+allowed here -- because the product has no CPU compute path."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import _oracle as O  # noqa: E402
+from spmv_scpa_amd import dist as D  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    mode, chunks, rows_per_rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kind, K, W = 2, 12, 500  # ragged family
+    M = N = rows_per_rank * world
+    starts = D.even_row_partition(M, world)
+    assert starts[rank + 1] - starts[rank] == rows_per_rank
+    row0 = starts[rank]
+    # each rank generates ONLY its shard (global columns), as bench.py does
+    IRP, JA, AS = O.synth_csr(kind, rows_per_rank, N, K, W, 42, row0=row0)
+    x = torch.from_numpy(O.synth_x(7, 0, N))
+    y = torch.full((M,), float("nan"), dtype=torch.float64)
+
+    def compute(a, b):
+        sub = IRP[a:b + 1] - IRP[a]
+        lo, hi = IRP[a], IRP[b]
+        y[row0 + a:row0 + b] = torch.from_numpy(
+            O.csr_spmv(np.ascontiguousarray(sub), JA[lo:hi], AS[lo:hi],
+                       x.numpy()))
+
+    sh = D.ShardedSpmv(None, 0, rank, world, rows_per_rank, x, y,
+                       chunks=chunks, mode=mode, compute=compute)
+    for it in range(3):  # iterate: y of step k feeds nothing here, but the
+        y.fill_(float("nan"))  # exchange must complete every time
+        sh.step()
+        fI, fJ, fA = O.synth_csr(kind, M, N, K, W, 42)
+        want = O.csr_spmv(fI, fJ, fA, x.numpy())
+        got = y.numpy()
+        assert not np.isnan(got).any(), (rank, it)
+        assert np.array_equal(got, want), (rank, it)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,298 @@
+"""GPU parity: every HIP kernel, called through the C-ABI, against the CPU
+oracle (oracle/liboracle.so) and the reference-built golden vectors.
+
+Tolerance (BASELINE.json north_star): 1e-6 relative fp64 against the serial
+CSR path.  Written out below as REL_TOL; the kernels are additionally held to
+TIGHT = 1e-12 of the row scale sum_j |a_ij x_j| (summation order differs from
+the serial loop, nothing else may).
+"""
+import numpy as np
+import pytest
+
+import _golden as G
+import _oracle as O
+import spmv_scpa_amd as S
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+TIGHT = 1e-12
+WPB = (2, 4, 8)  # the reference's sweep (main.c:265-269)
+
+
+def assert_parity(y, y_ref, scale, what):
+    assert y.shape == y_ref.shape, what
+    assert np.all(np.isfinite(y)), what
+    den = np.maximum(np.abs(y_ref), 1e-3 * scale)
+    den = np.maximum(den, 1e-300)
+    rel = np.max(np.abs(y - y_ref) / den) if len(y) else 0.0
+    assert rel <= REL_TOL, (what, rel)
+    nrm = np.linalg.norm(y_ref)
+    if nrm > 0:
+        assert np.linalg.norm(y - y_ref) / nrm <= REL_TOL, what
+    tight = np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) if len(y) else 0
+    assert tight <= TIGHT, (what, tight)
+    assert S.validation_vec_result(y_ref, y) == 0, what  # reference's -d check
+
+
+def run_all_kernels(A, x, y_ref, scale, tag):
+    for k in range(S.NUM_CSR_KERNELS):
+        for w in WPB:
+            y, ms = S.csr_spmv_hip(A, x, kernel=k, waves_per_block=w)
+            assert ms >= 0
+            assert_parity(y, y_ref, scale, (tag, "csr", k, w))
+    for g in (2, 4, 8, 16, 32):
+        y, _ = S.csr_spmv_hip(A, x, kernel=2, waves_per_block=4, group=g)
+        assert_parity(y, y_ref, scale, (tag, "csr subwave G", g))
+    for k in range(S.NUM_HLL_KERNELS):
+        H = S.csr_to_hll(A, S.HLL_KERNEL_COL_MAJOR[k])
+        for w in WPB:
+            y, ms = S.hll_spmv_hip(H, x, kernel=k, waves_per_block=w)
+            assert ms >= 0
+            assert_parity(y, y_ref, scale, (tag, "hll", k, w))
+        S.hll_free(H)
+
+
+@pytest.mark.parametrize("name", G.MTX_CASES)
+def test_golden_mtx_all_kernels(name):
+    """Same .mtx, same glibc x as the reference run; expected y is the
+    reference's serial CSR output stored in tests/golden."""
+    ref = G.load_ref(name)
+    A = S.io_load_csr(G.mtx_path(name))
+    x = S.vec_random(A.contents.N)
+    y_ref = ref["y_csr_serial"]
+    IRP, JA, AS = S.csr_arrays(A)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    assert np.array_equal(O.csr_spmv(IRP, JA, AS, x), y_ref)
+    run_all_kernels(A, x, y_ref, scale, name)
+    S.csr_free(A)
+
+
+SYNTH_SMALL = [
+    ("banded", S.SYNTH_BANDED, 50_000, 16, 0),
+    ("random_narrow", S.SYNTH_RANDOM, 40_000, 32, 512),
+    ("random_wide", S.SYNTH_RANDOM, 33_333, 32, 1 << 30),
+    ("ragged", S.SYNTH_RAGGED, 20_011, 32, 4096),
+    ("kkt", S.SYNTH_KKT, 30_000, 16, 30_000),
+    ("one_row", S.SYNTH_RANDOM, 1, 32, 64),
+    ("31_rows", S.SYNTH_RANDOM, 31, 5, 64),
+    ("33_rows", S.SYNTH_RAGGED, 33, 8, 64),
+    ("long_rows", S.SYNTH_RANDOM, 300, 5000, 1 << 30),
+]
+
+
+@pytest.mark.parametrize("tag,kind,M,K,W", SYNTH_SMALL)
+def test_synthetic_all_kernels(tag, kind, M, K, W):
+    N = max(M, K, 64)
+    IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays(tag, M, N, IRP, JA, AS)
+    run_all_kernels(A, x, y_ref, scale, tag)
+    S.csr_free(A)
+
+
+def test_empty_and_degenerate_matrices():
+    # all rows empty; and a matrix with zero rows
+    IRP = np.zeros(71, dtype=np.int32)
+    A = S.csr_from_arrays("empty", 70, 9, IRP, np.zeros(0, np.int32),
+                          np.zeros(0))
+    x = np.ones(9)
+    for k in range(S.NUM_CSR_KERNELS):
+        y, _ = S.csr_spmv_hip(A, x, kernel=k)
+        assert np.array_equal(y, np.zeros(70))
+    for k in range(S.NUM_HLL_KERNELS):
+        H = S.csr_to_hll(A, S.HLL_KERNEL_COL_MAJOR[k])
+        y, _ = S.hll_spmv_hip(H, x, kernel=k)
+        assert np.array_equal(y, np.zeros(70))
+        S.hll_free(H)
+    S.csr_free(A)
+    A0 = S.csr_from_arrays("norows", 0, 4, np.zeros(1, np.int32),
+                           np.zeros(0, np.int32), np.zeros(0))
+    y, _ = S.csr_spmv_hip(A0, np.ones(4), kernel=2)
+    assert len(y) == 0
+    S.csr_free(A0)
+
+
+def test_bench_wrappers_and_reference_abi_names():
+    """The bench_* layer (reference csr.c:382-415 / hll.c:226-256 shape) and
+    the reference's own 11 plugin symbols run the HIP kernels."""
+    import ctypes as C
+    name = "ragged100"
+    ref = G.load_ref(name)
+    A = S.io_load_csr(G.mtx_path(name))
+    x = S.vec_random(A.contents.N)
+    IRP, JA, AS = S.csr_arrays(A)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    y_ref = ref["y_csr_serial"]
+    for k in range(S.NUM_CSR_KERNELS):
+        y, ms, gf = S.bench_csr_hip(A, x, k, 4)
+        assert_parity(y, y_ref, scale, ("bench csr", k))
+        assert gf == S.compute_gflops(ms, A.contents.NZ)
+    Hs = {False: S.csr_to_hll(A, False), True: S.csr_to_hll(A, True)}
+    for k in range(S.NUM_HLL_KERNELS):
+        y, ms, gf = S.bench_hll_hip(Hs[S.HLL_KERNEL_COL_MAJOR[k]], x, k, 8)
+        assert_parity(y, y_ref, scale, ("bench hll", k))
+    dp = C.POINTER(C.c_double)
+    xs = np.ascontiguousarray(x)
+    lib = S._lib
+    lib.set_csr_warps_per_block(4)
+    lib.set_hll_warps_per_block(2)
+    for sym in ("csr_spmv_cuda_thread_row", "csr_spmv_cuda_warp_row",
+                "csr_spmv_cuda_halfwarp_row", "csr_spmv_cuda_block_row",
+                "csr_spmv_cuda_halfwarp_row_text"):
+        fn = getattr(lib, sym)
+        fn.restype = C.c_double
+        y = np.zeros(A.contents.M)
+        ms = fn(A, xs.ctypes.data_as(dp), y.ctypes.data_as(dp), None)
+        assert ms >= 0
+        assert_parity(y, y_ref, scale, sym)
+    for sym, cm in (("hll_spmv_cuda_threads_row_major", False),
+                    ("hll_spmv_cuda_threads_col_major", True),
+                    ("hll_spmv_cuda_warp_block", True),
+                    ("hll_spmv_cuda_halfwarp_row", False)):
+        fn = getattr(lib, sym)
+        fn.restype = C.c_double
+        y = np.zeros(A.contents.M)
+        ms = fn(Hs[cm], xs.ctypes.data_as(dp), y.ctypes.data_as(dp), None)
+        assert ms >= 0
+        assert_parity(y, y_ref, scale, sym)
+    for H in Hs.values():
+        S.hll_free(H)
+    S.csr_free(A)
+
+
+def test_persistent_handles_and_device_generation():
+    """upload once / launch many; device-side generation and device-side
+    CSR->HLL agree bit-for-bit with the host path."""
+    kind, M, N, K, W = S.SYNTH_RAGGED, 50_021, 60_000, 32, 2048
+    IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    dA = S.CsrDevice.generate(kind, M, N, K, W, 0, 42)
+    assert (dA.M, dA.N, dA.NZ) == (M, N, len(JA))
+    back = dA.download()
+    bI, bJ, bA = S.csr_arrays(back)
+    assert np.array_equal(bI, IRP) and np.array_equal(bJ, JA)
+    assert np.array_equal(bA.view(np.uint64), AS.view(np.uint64))
+    S.csr_free(back)
+    d_x = S.DevBuffer(N * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    S.stream_sync()
+    assert np.array_equal(d_x.to_numpy(np.float64, N).view(np.uint64),
+                          x.view(np.uint64))
+    d_y = S.DevBuffer(M * 8)
+    assert dA.algorithmic_bytes == 12 * len(JA) + 4 * (M + 1) + 8 * M + 8 * N
+    for k in range(S.NUM_CSR_KERNELS):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        for _ in range(3):
+            dA.launch(k, d_x.ptr, d_y.ptr, waves_per_block=4)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, ("dev csr", k))
+    # row sub-ranges (the chunked multi-GPU overlap path)
+    S._lib.spmv_dev_memset(d_y.ptr, 0, M * 8, None)
+    cut = 20_000
+    dA.launch(2, d_x.ptr, d_y.ptr, rows=(0, cut))
+    dA.launch(4, d_x.ptr, d_y.ptr, rows=(cut, M))
+    S.stream_sync()
+    assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, "csr row ranges")
+    for cm in (False, True):
+        dH = dA.to_hll(cm)
+        off, maxnz, _, HJA, HAS = O.csr_to_hll(IRP, JA, AS, cm)
+        assert dH.slots == off[-1] and dH.num_blocks == len(maxnz)
+        assert dH.algorithmic_bytes == (12 * dH.slots + 12 * dH.num_blocks
+                                        + 8 * M + 8 * N)
+        for k in range(S.NUM_HLL_KERNELS):
+            if S.HLL_KERNEL_COL_MAJOR[k] != cm:
+                with pytest.raises(OSError):
+                    dH.launch(k, d_x.ptr, d_y.ptr)
+                continue
+            S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+            dH.launch(k, d_x.ptr, d_y.ptr, waves_per_block=4)
+            S.stream_sync()
+            assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                          ("dev hll", cm, k))
+            # hack-block sub-ranges
+            S._lib.spmv_dev_memset(d_y.ptr, 0, M * 8, None)
+            nb = dH.num_blocks
+            for b0, b1 in ((0, 7), (7, nb // 2), (nb // 2, nb)):
+                dH.launch(k, d_x.ptr, d_y.ptr, blocks=(b0, b1))
+            S.stream_sync()
+            assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                          ("dev hll blocks", cm, k))
+        dH.release()
+    # event-timed loop returns one positive time per iteration
+    ms = dA.time(2, d_x.ptr, d_y.ptr, warmup=1, iters=5,
+                 flush_bytes=64 << 20)
+    assert len(ms) == 5 and np.all(ms > 0)
+    dA.release()
+
+
+def test_config2_banded_full_size_properties():
+    """BASELINE config 2: 1M x 1M banded, 16/row.  Host-generated, so the
+    whole y is compared with the oracle; plus linearity."""
+    M = N = 1_000_000
+    A = S.csr_generate(S.SYNTH_BANDED, M, N, 16, 0, 0, 42)
+    IRP, JA, AS = S.csr_arrays(A)
+    x = S.vec_synth(N, 7)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    dA = S.CsrDevice.upload(A)
+    assert dA.algorithmic_bytes == 212_000_004
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+    for k in (1, 2, 4):
+        dA.launch(k, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, ("cfg2", k))
+    z = S.vec_synth(N, 11)
+    d_z = S.DevBuffer.from_numpy(2.0 * x - 0.5 * z)
+    dA.launch(2, d_z.ptr, d_y.ptr)
+    S.stream_sync()
+    y_lin = d_y.to_numpy(np.float64, M)
+    y_z = O.csr_spmv(IRP, JA, AS, z)
+    assert np.max(np.abs(y_lin - (2.0 * y_ref - 0.5 * y_z))
+                  / np.maximum(scale + O.csr_abs_spmv(IRP, JA, AS, z), 1e-300)) < 1e-12
+    dA.release()
+    S.csr_free(A)
+
+
+@pytest.mark.parametrize("W", [1 << 20, 1 << 30])
+def test_config3_random_hll_full_size_properties(W):
+    """BASELINE config 3: 10M x 10M, 32/row, hack 32, generated and converted
+    on the device.  Size-independent checks: 20k sampled rows regenerated by
+    the oracle from the counter-based definition; x = 1 gives row sums;
+    CSR and HLL kernels agree with each other."""
+    M = N = 10_000_000
+    K = 32
+    dA = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, K, W, 0, 42)
+    assert dA.NZ == M * K
+    dH = dA.to_hll(True)
+    assert dH.slots == M * K and dH.num_blocks == 312_500
+    assert dH.algorithmic_bytes == 4_003_750_000
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    rng = np.random.default_rng(5)
+    rows = np.unique(np.concatenate([[0, 1, 31, 32, M - 1, M - 32],
+                                     rng.integers(0, M, 20_000)]))
+    want = np.array([O.synth_row_dot(S.SYNTH_RANDOM, M, N, K, W, 0, 42, 7,
+                                     int(g)) for g in rows])
+    ys = {}
+    for tag, fn in (("hll1", lambda: dH.launch(1, d_x.ptr, d_y.ptr)),
+                    ("hll2", lambda: dH.launch(2, d_x.ptr, d_y.ptr)),
+                    ("csr2", lambda: dA.launch(2, d_x.ptr, d_y.ptr))):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        fn()
+        S.stream_sync()
+        y = d_y.to_numpy(np.float64, M)
+        assert np.all(np.isfinite(y))
+        got = y[rows]
+        assert np.max(np.abs(got - want[:, 0]) / want[:, 1]) <= TIGHT, tag
+        den = np.maximum(np.abs(want[:, 0]), 1e-3 * want[:, 1])
+        assert np.max(np.abs(got - want[:, 0]) / den) <= REL_TOL, tag
+        ys[tag] = y
+    assert np.max(np.abs(ys["hll1"] - ys["csr2"])) < 1e-11
+    assert np.array_equal(ys["hll1"], ys["hll2"])  # same order of operations
+    dH.release()
+    dA.release()

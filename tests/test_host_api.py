@@ -1,0 +1,280 @@
+"""Host C API (loader, HLL converter, CPU benches, logger, partitions) against
+the reference-built goldens and the oracle.  CPU only."""
+import ctypes as C
+import errno
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _golden as G
+import _oracle as O
+import spmv_scpa_amd as S
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+REF_ABI = ["set_csr_warps_per_block", "csr_spmv_cuda_thread_row",
+           "csr_spmv_cuda_warp_row", "csr_spmv_cuda_halfwarp_row",
+           "csr_spmv_cuda_block_row", "csr_spmv_cuda_halfwarp_row_text",
+           "set_hll_warps_per_block", "hll_spmv_cuda_threads_row_major",
+           "hll_spmv_cuda_threads_col_major", "hll_spmv_cuda_warp_block",
+           "hll_spmv_cuda_halfwarp_row"]
+
+
+def test_library_exports_every_declared_symbol():
+    names = S.declared_symbols()
+    assert len(names) >= 90
+    for n in REF_ABI + ["io_load_csr", "csr_to_hll", "spmv_hll_launch",
+                        "csr_spmv_hip_subwave_row",
+                        "hll_spmv_hip_threads_col_major"]:
+        assert n in names, n
+    assert S.check_symbols()
+    assert "gfx950" in S.version()
+
+
+@pytest.mark.parametrize("name", G.MTX_CASES)
+def test_io_load_csr_matches_reference(name):
+    ref = G.load_ref(name)
+    A = S.io_load_csr(G.mtx_path(name))
+    a = A.contents
+    assert [a.M, a.N, a.NZ] == list(ref["shape"])
+    assert a.name.decode() == ref["name"]
+    IRP, JA, AS = S.csr_arrays(A)
+    assert np.array_equal(IRP, ref["IRP"])
+    assert np.array_equal(JA, ref["JA"])
+    assert np.array_equal(bits(AS), bits(ref["AS"]))
+    for arr in (a.IRP, a.JA, a.AS):  # 64 B alignment (reference utils.h:14)
+        assert C.cast(arr, C.c_void_p).value % 64 == 0
+    S.csr_free(A)
+
+
+def test_io_load_csr_error_codes_match_reference():
+    for fname, code in G.load_errors().items():
+        path = os.path.join(G.GOLDEN, fname.replace("err_missing_file",
+                                                    "does_not_exist"))
+        with pytest.raises(OSError) as ei:
+            S.io_load_csr(path)
+        assert ei.value.errno == -code, (fname, ei.value.errno, code)
+
+
+def test_matrix_name_extraction():
+    assert S.extract_matrix_name("/a/b/cage4.mtx") == "cage4"
+    assert S.extract_matrix_name("plain") == "plain"
+    assert S.extract_matrix_name(".mtx") == ".mtx"
+    long = "x" * 100 + ".mtx"
+    assert S.extract_matrix_name(long) == "x" * 63 == O.matrix_name(long)
+
+
+@pytest.mark.parametrize("name", G.MTX_CASES)
+@pytest.mark.parametrize("col_major", [False, True])
+def test_csr_to_hll_matches_reference(name, col_major):
+    ref = G.load_ref(name)
+    A = S.io_load_csr(G.mtx_path(name))
+    H = S.csr_to_hll(A, col_major)
+    hdr, blocks = G.hll_blocks(ref, "hll_col" if col_major else "hll_row")
+    h = H.contents
+    assert [h.M, h.N, h.NZ, h.hack_size, h.num_blocks] == list(hdr)
+    assert h.name == A.contents.name
+    got = S.hll_blocks(H)
+    assert len(got) == len(blocks)
+    slots = 0
+    for (gm, gn, gnz, gmax, gja, gas), (rm, rn, rnz, rmax, rja, ras) in zip(
+            got, blocks):
+        assert (gm, gn, gnz, gmax) == (rm, rn, rnz, rmax)
+        assert np.array_equal(gja, rja)
+        assert np.array_equal(bits(gas), bits(ras))
+        slots += gm * gmax
+    assert S.hll_num_slots(H) == slots
+    assert S._lib.hll_is_contiguous(H) == 1  # slab-backed
+    S.hll_free(H)
+    S.csr_free(A)
+
+
+@pytest.mark.parametrize("name", G.MTX_CASES)
+def test_cpu_benchmarks_match_reference_bits(name):
+    ref = G.load_ref(name)
+    A = S.io_load_csr(G.mtx_path(name))
+    x = S.vec_random(A.contents.N)
+    assert np.array_equal(bits(x), bits(ref["x"]))
+    y, ms, gf = S.bench_csr_serial(A, x)
+    assert np.array_equal(bits(y), bits(ref["y_csr_serial"]))
+    assert ms >= 0 and gf == S.compute_gflops(ms, A.contents.NZ)
+    Hr, Hc = S.csr_to_hll(A, False), S.csr_to_hll(A, True)
+    assert np.array_equal(bits(S.bench_hll_serial(Hr, x)[0]),
+                          bits(ref["y_hll_serial"]))
+    assert np.array_equal(bits(S.bench_hll_serial(Hc, x, col_major=True)[0]),
+                          bits(ref["y_hll_serial"]))
+    yg, _, _, nm, thr = S.bench_csr_omp_guided(A, x, 2)
+    assert nm == ref["omp_names"][0] == "omp_guided" and thr == 2
+    assert np.array_equal(bits(yg), bits(ref["y_csr_omp_guided"]))
+    yn, _, _, nm, thr = S.bench_csr_omp_nnz_balancing(A, x, 2)
+    assert nm == ref["omp_names"][1] == "omp_nnz"
+    assert thr == int(ref["omp_nnz_threads"][0])
+    assert np.array_equal(bits(yn), bits(ref["y_csr_omp_nnz"]))
+    yh, _, _, nm, _ = S.bench_hll_omp(Hr, x, 2)
+    assert nm == ref["omp_names"][2]
+    assert np.array_equal(bits(yh), bits(ref["y_hll_omp"]))
+    assert S.validation_vec_result(y, yh) == 0
+    assert S.max_rel_err(y, yh) == 0.0
+    S.hll_free(Hr)
+    S.hll_free(Hc)
+    S.csr_free(A)
+
+
+def test_validation_and_rel_err_semantics():
+    a = np.array([1.0, 2.0, 3.0])
+    assert S.validation_vec_result(a, a + 0.05) == 0      # L2 = 0.087
+    assert S.validation_vec_result(a, a + 0.06) == -1     # L2 = 0.104
+    assert S.validation_vec_result(a, a[:2]) == -1
+    assert S.max_rel_err(a, a[:2]) == -1.0
+    assert abs(S.max_rel_err(a, a * (1 + 1e-9)) - 1e-9) < 1e-12
+    # cancelling row: |y| tiny, row scale large -> judged against the scale
+    e = S.max_rel_err(np.array([1e-20]), np.array([3e-17]),
+                      scale=np.array([1.0]))
+    assert e < 1e-13
+    assert S.compute_gflops(2.0, 7) == O.gflops(2.0, 7)
+    assert S.compute_gflops(0.0, 7) == 0.0
+
+
+@pytest.mark.parametrize("name", G.SYNTH_CASES)
+def test_csr_generate_matches_oracle_and_reference(name):
+    ref = G.load_ref(name)
+    kind, M, N, K, W, seed, xseed, _ = [int(v) for v in ref["spec"]]
+    A = S.csr_generate(kind, M, N, K, W, 0, seed)
+    IRP, JA, AS = S.csr_arrays(A)
+    oI, oJ, oA = O.synth_csr(kind, M, N, K, W, seed)
+    assert np.array_equal(IRP, oI) and np.array_equal(JA, oJ)
+    assert np.array_equal(bits(AS), bits(oA))
+    x = S.vec_synth(N, xseed)
+    assert np.array_equal(bits(x), bits(O.synth_x(xseed, 0, N)))
+    y = S.bench_csr_serial(A, x)[0]
+    st = int(ref["stride"][0])
+    assert np.array_equal(bits(y[::st]), bits(ref["y_csr_serial_sample"]))
+    # a shard generated with row0 equals the same rows of the whole matrix
+    r0 = (M // 3) // 32 * 32
+    B = S.csr_generate(kind, M - r0, N, K, W, r0, seed)
+    bI, bJ, bA = S.csr_arrays(B)
+    assert np.array_equal(bJ, JA[IRP[r0]:]) and np.array_equal(bA, AS[IRP[r0]:])
+    Sl = S.csr_row_slice(A, r0, M)
+    sI, sJ, sA = S.csr_arrays(Sl)
+    assert np.array_equal(sI, bI) and np.array_equal(sJ, bJ)
+    for p in (A, B, Sl):
+        S.csr_free(p)
+
+
+def test_partitions():
+    r = G.load_ref("ragged100")
+    A = S.io_load_csr(G.mtx_path("ragged100"))
+    IRP = r["IRP"].astype(np.int32)
+    for parts in (1, 2, 3, 8, 40):
+        got = S.partition_rows_nnz(A, parts)
+        assert np.array_equal(got, O.partition_rows(IRP, parts)), parts
+        assert got[0] == 0 and got[-1] == 100
+    S.csr_free(A)
+    ev = S.partition_rows_even(10_000_000, 8, 32)
+    assert list(np.diff(ev)) == [1250016] * 7 + [10_000_000 - 7 * 1250016]
+    assert all(v % 32 == 0 for v in ev[:-1])
+    ev = S.partition_rows_even(100, 8, 32)
+    assert list(ev) == [0, 32, 64, 96, 100, 100, 100, 100, 100]
+    ev = S.partition_rows_even(80_000_000, 8, 32)
+    assert list(np.diff(ev)) == [10_000_000] * 8
+
+
+def test_csv_logger_schema_is_byte_exact(tmp_path):
+    d = str(tmp_path)
+    A = S.io_load_csr(G.mtx_path("tail40"))
+    H = S.csr_to_hll(A, False)
+    assert S._lib.logger_init(d.encode()) == 0
+    b = S.Bench(1.5, 0.25, S.Vec(0, None))
+    S._lib.log_csr_serial_benchmark(A, b)
+    S._lib.log_hll_serial_benchmark(H, b)
+    bo = S.BenchOmp(b, b"omp_guided", 8)
+    S._lib.log_csr_omp_benchmark(A, bo)
+    S._lib.log_hll_omp_benchmark(H, bo)
+    bh = S.BenchHip(b, 4)
+    S._lib.log_csr_hip_benchmark(A, bh, 2)
+    S._lib.log_hll_hip_benchmark(H, bh, 1)
+    S._lib.logger_close()
+    # re-open: append, no second header (reference logger.c:21-51)
+    assert S._lib.logger_init(d.encode()) == 0
+    S._lib.log_csr_serial_benchmark(A, b)
+    S._lib.logger_close()
+    assert open(os.path.join(d, "serial.csv")).read() == (
+        "matrix,format,rows,cols,nnz,num_blocks,duration_ms,gflops\n"
+        "tail40,CSR,40,40,3,,1.500000,0.250000\n"
+        "tail40,HLL,40,40,3,2,1.500000,0.250000\n"
+        "tail40,CSR,40,40,3,,1.500000,0.250000\n")
+    assert open(os.path.join(d, "omp.csv")).read() == (
+        "matrix,format,bench,rows,cols,nnz,num_blocks,num_threads,duration_ms,"
+        "gflops\n"
+        "tail40,CSR,omp_guided,40,40,3,,8,1.500000,0.250000\n"
+        "tail40,HLL,omp_guided,40,40,3,2,8,1.500000,0.250000\n")
+    assert open(os.path.join(d, "cuda.csv")).read() == (
+        "matrix,format,kernel,warps_per_block,rows,cols,nnz,num_blocks,"
+        "duration_ms,gflops\n"
+        "tail40,CSR,2,4,40,40,3,,1.500000,0.250000\n"
+        "tail40,HLL,1,4,40,40,3,2,1.500000,0.250000\n")
+    assert S._lib.logger_init(b"/nonexistent/dir") == -1
+    S.hll_free(H)
+    S.csr_free(A)
+
+
+def test_gpu_entry_points_fail_loudly_without_a_gpu():
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    A = S.io_load_csr(G.mtx_path("gen"))
+    x = S.vec_random(5)
+    for k in range(S.NUM_CSR_KERNELS):
+        with pytest.raises(OSError) as ei:
+            S.csr_spmv_hip(A, x, kernel=k)
+        assert ei.value.errno == errno.ENODEV
+        with pytest.raises(OSError) as ei:
+            S.bench_csr_hip(A, x, k)
+        assert ei.value.errno == errno.ENODEV
+    H = S.csr_to_hll(A, True)
+    with pytest.raises(OSError) as ei:
+        S.hll_spmv_hip(H, x, kernel=1)
+    assert ei.value.errno == errno.ENODEV
+    with pytest.raises(OSError):
+        S.CsrDevice.upload(A)
+    with pytest.raises(OSError):
+        S.DevBuffer(1024)
+    S.hll_free(H)
+    S.csr_free(A)
+
+
+DRIVER = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
+
+
+def test_driver_cli_cpu_path(tmp_path):
+    out = str(tmp_path)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run([DRIVER, "-m", G.mtx_path("sym70"), "-o", out, "-d",
+                        "--iters", "2"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    serial = open(os.path.join(out, "serial.csv")).read().splitlines()
+    assert serial[0] == "matrix,format,rows,cols,nnz,num_blocks,duration_ms,gflops"
+    assert serial[1].startswith("sym70,CSR,70,70,") and serial[2].startswith(
+        "sym70,HLL,70,70,")
+    omp = open(os.path.join(out, "omp.csv")).read().splitlines()
+    assert len(omp) == 1 + 3 * 2  # threads 2 and 4 x {omp_nnz, omp_guided, hll}
+    # errors are reported, not crashed on (the reference segfaults: main.c:79)
+    r = subprocess.run([DRIVER, "-m", "/no/such.mtx", "-o", out],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "No such file" in r.stderr
+    r = subprocess.run([DRIVER, "-m", G.mtx_path("err_complex"), "-o", out],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "err -22" in r.stderr
+    r = subprocess.run([DRIVER, "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage:" in r.stderr
+    r = subprocess.run([DRIVER], capture_output=True, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([DRIVER, "-s", "random", "--rows", "4096", "--nnz-row",
+                        "8", "--window", "256", "-o", out, "-d", "--iters", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr

@@ -1,0 +1,185 @@
+/*
+ * microbench.hip -- MI355X memory-path probes that size the SpMV kernels.
+ *   stream   bytes/s of coalesced reads at 4 / 8 / 16 B per lane, plain and
+ *            non-temporal
+ *   spmvmix  the HLL stream without gathers: int32 + fp64 per slot
+ *   gather   random 8-byte gathers from a table of T bytes (L1 / L2 /
+ *            Infinity Cache / HBM resident), indices computed in-register
+ * Build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench
+ */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <typename T, bool NT>
+__global__ void k_stream(const T *__restrict__ p, size_t n, int *sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    int acc = 0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        T a, b, c, d;
+        if (NT) {
+            a = __builtin_nontemporal_load(p + i);
+            b = __builtin_nontemporal_load(p + i + stride);
+            c = __builtin_nontemporal_load(p + i + 2 * stride);
+            d = __builtin_nontemporal_load(p + i + 3 * stride);
+        } else {
+            a = p[i]; b = p[i + stride]; c = p[i + 2 * stride]; d = p[i + 3 * stride];
+        }
+        acc += ((const int *)&a)[0] + ((const int *)&b)[0] +
+               ((const int *)&c)[0] + ((const int *)&d)[0];
+    }
+    if (acc == 0x7fffffff)
+        *sink = acc;
+}
+
+/* HLL-like stream: lane reads one int and one double per step */
+template <bool NT>
+__global__ void k_spmvmix(const int *__restrict__ ja, const double *__restrict__ as,
+                          size_t n, double *sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        int c0, c1, c2, c3; double a0, a1, a2, a3;
+        if (NT) {
+            c0 = __builtin_nontemporal_load(ja + i); c1 = __builtin_nontemporal_load(ja + i + stride);
+            c2 = __builtin_nontemporal_load(ja + i + 2 * stride); c3 = __builtin_nontemporal_load(ja + i + 3 * stride);
+            a0 = __builtin_nontemporal_load(as + i); a1 = __builtin_nontemporal_load(as + i + stride);
+            a2 = __builtin_nontemporal_load(as + i + 2 * stride); a3 = __builtin_nontemporal_load(as + i + 3 * stride);
+        } else {
+            c0 = ja[i]; c1 = ja[i + stride]; c2 = ja[i + 2 * stride]; c3 = ja[i + 3 * stride];
+            a0 = as[i]; a1 = as[i + stride]; a2 = as[i + 2 * stride]; a3 = as[i + 3 * stride];
+        }
+        acc += a0 * c0 + a1 * c1 + a2 * c2 + a3 * c3;
+    }
+    if (acc == 1.2345e300)
+        *sink = acc;
+}
+
+__device__ __forceinline__ uint64_t mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* each lane does `per` random 8-byte gathers inside a window of `win`
+ * elements that slides with the lane id (win == n: anywhere) */
+__global__ void k_gather(const double *__restrict__ t, size_t n, size_t win,
+                         int per, double *sink) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)gridDim.x * blockDim.x;
+    size_t base = win >= n ? 0 : (size_t)((double)gid / total * (double)(n - win));
+    double acc = 0;
+    uint64_t h = mix(gid);
+    for (int j = 0; j < per; j += 8) {
+        size_t i0 = base + (mix(h + j) % win), i1 = base + (mix(h + j + 1) % win);
+        size_t i2 = base + (mix(h + j + 2) % win), i3 = base + (mix(h + j + 3) % win);
+        size_t i4 = base + (mix(h + j + 4) % win), i5 = base + (mix(h + j + 5) % win);
+        size_t i6 = base + (mix(h + j + 6) % win), i7 = base + (mix(h + j + 7) % win);
+        acc += t[i0] + t[i1] + t[i2] + t[i3] + t[i4] + t[i5] + t[i6] + t[i7];
+    }
+    if (acc == 1.2345e300)
+        *sink = acc;
+}
+
+/* the same index arithmetic without the loads: cost of the hash itself */
+__global__ void k_gather_null(size_t n, size_t win, int per, double *sink) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)gridDim.x * blockDim.x;
+    size_t base = win >= n ? 0 : (size_t)((double)gid / total * (double)(n - win));
+    size_t acc = 0;
+    uint64_t h = mix(gid);
+    for (int j = 0; j < per; ++j)
+        acc += base + (mix(h + j) % win);
+    if (acc == 0x7fffffffffffull)
+        *sink = (double)acc;
+}
+
+template <typename F> static double time_ms(F f, int reps = 7) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    std::vector<double> v;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); v.push_back(ms);
+    }
+    std::sort(v.begin(), v.end());
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return v[v.size() / 2];
+}
+
+int main() {
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    printf("device: %s %s CUs=%d clock=%d MHz L2=%d KB\n", p.name, p.gcnArchName,
+           p.multiProcessorCount, p.clockRate / 1000, p.l2CacheSize / 1024);
+    const size_t bytes = (size_t)4 << 30;
+    void *buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 1, bytes));
+    int *isink; CK(hipMalloc((void **)&isink, 64));
+    double *dsink = (double *)isink;
+    const int grids[] = {2048, 8192, 32768};
+    printf("== stream (4 GiB) GB/s\n");
+    for (int g : grids) {
+        double t;
+        t = time_ms([&] { k_stream<int, false><<<g, 256>>>((int *)buf, bytes / 4, isink); });
+        printf("grid %6d dword    plain %8.1f", g, bytes / t * 1e-6);
+        t = time_ms([&] { k_stream<int, true><<<g, 256>>>((int *)buf, bytes / 4, isink); });
+        printf("  nt %8.1f\n", bytes / t * 1e-6);
+        t = time_ms([&] { k_stream<v2i, false><<<g, 256>>>((v2i *)buf, bytes / 8, isink); });
+        printf("grid %6d dwordx2  plain %8.1f", g, bytes / t * 1e-6);
+        t = time_ms([&] { k_stream<v2i, true><<<g, 256>>>((v2i *)buf, bytes / 8, isink); });
+        printf("  nt %8.1f\n", bytes / t * 1e-6);
+        t = time_ms([&] { k_stream<v4i, false><<<g, 256>>>((v4i *)buf, bytes / 16, isink); });
+        printf("grid %6d dwordx4  plain %8.1f", g, bytes / t * 1e-6);
+        t = time_ms([&] { k_stream<v4i, true><<<g, 256>>>((v4i *)buf, bytes / 16, isink); });
+        printf("  nt %8.1f\n", bytes / t * 1e-6);
+    }
+    printf("== spmvmix: int32+fp64 per slot, 320M slots (3.84 GB) GB/s\n");
+    {
+        size_t n = 320000000;
+        int *ja = (int *)buf; double *as = (double *)((char *)buf + ((size_t)2 << 30));
+        for (int g : grids) {
+            double t = time_ms([&] { k_spmvmix<false><<<g, 256>>>(ja, as, n, dsink); });
+            printf("grid %6d plain %8.1f", g, 12.0 * n / t * 1e-6);
+            t = time_ms([&] { k_spmvmix<true><<<g, 256>>>(ja, as, n, dsink); });
+            printf("  nt %8.1f\n", 12.0 * n / t * 1e-6);
+        }
+    }
+    printf("== gather: 32 random fp64 gathers per lane, 10M lanes (320M gathers)\n");
+    printf("   needed for config 3 at 60%% roofline: 384 Ggather/s\n");
+    {
+        const int per = 32; const int lanes = 10000000; const int g = lanes / 256;
+        double tn = time_ms([&] { k_gather_null<<<g, 256>>>((size_t)1 << 20, (size_t)1 << 20, per, dsink); });
+        printf("index arithmetic alone: %.3f ms\n", tn);
+        const size_t tabs[] = {(size_t)16 << 10, (size_t)256 << 10, (size_t)2 << 20, (size_t)8 << 20,
+                               (size_t)32 << 20, (size_t)80 << 20, (size_t)200 << 20, (size_t)640 << 20,
+                               (size_t)2 << 30};
+        for (size_t tb : tabs) {
+            size_t n = tb / 8;
+            double t = time_ms([&] { k_gather<<<g, 256>>>((double *)buf, n, n, per, dsink); });
+            printf("table %8.2f MB uniform          : %7.3f ms  %7.1f Ggather/s  (useful %6.1f GB/s)\n",
+                   tb / 1048576.0, t, (double)lanes * per / t * 1e-6, 8.0 * lanes * per / t * 1e-6);
+        }
+        /* sliding windows over an 80 MB table: what XCD-contiguous row ranges see */
+        const size_t wins[] = {(size_t)1 << 9, (size_t)1 << 11, (size_t)1 << 14, (size_t)1 << 17,
+                               (size_t)1 << 20, (size_t)1 << 22};
+        for (size_t w : wins) {
+            size_t n = 10000000;
+            double t = time_ms([&] { k_gather<<<g, 256>>>((double *)buf, n, w, per, dsink); });
+            printf("table 76.29 MB window %8zu cols: %7.3f ms  %7.1f Ggather/s\n", w, t,
+                   (double)lanes * per / t * 1e-6);
+        }
+    }
+    return 0;
+}
