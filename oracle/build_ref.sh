@@ -8,6 +8,8 @@
 # never need resolving.  Outputs (git-ignored, but they DO travel to the GPU
 # box with gpurun):
 #   oracle/_ref/ref_strict  -O2, strict IEEE: generates the golden vectors
+#   oracle/_ref/ref_dropin  the reference's unmodified driver + host layer
+#                           linked against libspmv_scpa_amd.so (drop-in proof)
 #   oracle/_ref/ref_fast    the reference's flags (CMakeLists.txt:11-18:
 #                           -O3 -fopenmp -ffast-math -funroll-loops) with
 #                           -march=x86-64-v3 instead of -march=native, since
@@ -32,3 +34,17 @@ gcc "${common[@]}" -O2 "$here/ref_harness.c" "${srcs[@]}" -lm \
 gcc "${common[@]}" -O3 -march=x86-64-v3 -ffast-math -funroll-loops \
     "$here/ref_harness.c" "${srcs[@]}" -lm -o "$out/ref_fast"
 echo "build_ref: built $out/ref_strict $out/ref_fast"
+
+# Drop-in proof: the reference's UNMODIFIED driver and host
+# layer (main.c, csr.c, hll.c, ...) linked against libspmv_scpa_amd.so, which
+# exports the reference's own 11 plugin symbols (include/spmv_ref_abi.h) in
+# place of its CUDA translation units.  Run on the GPU box by
+# tests/test_gpu_dropin.py.
+lib="$here/../spmv_scpa_amd/lib"
+if [ -f "$lib/libspmv_scpa_amd.so" ]; then
+    gcc -std=c99 -D_GNU_SOURCE -fopenmp -I"$REF/include" -w -O3 \
+        "$REF/src/main.c" "$REF/src/logger.c" "${srcs[@]}" \
+        -L"$lib" -lspmv_scpa_amd -Wl,-rpath,'$ORIGIN/../../spmv_scpa_amd/lib' \
+        -Wl,-rpath,/opt/rocm/lib -lm -o "$out/ref_dropin"
+    echo "build_ref: built $out/ref_dropin (reference driver + MI355X kernels)"
+fi

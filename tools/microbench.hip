@@ -121,6 +121,7 @@ template <typename F> static double time_ms(F f, int reps = 7) {
 }
 
 int main() {
+    setvbuf(stdout, NULL, _IOLBF, 0);
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s %s CUs=%d clock=%d MHz L2=%d KB\n", p.name, p.gcnArchName,
            p.multiProcessorCount, p.clockRate / 1000, p.l2CacheSize / 1024);
@@ -145,10 +146,10 @@ int main() {
         t = time_ms([&] { k_stream<v4i, true><<<g, 256>>>((v4i *)buf, bytes / 16, isink); });
         printf("  nt %8.1f\n", bytes / t * 1e-6);
     }
-    printf("== spmvmix: int32+fp64 per slot, 320M slots (3.84 GB) GB/s\n");
+    printf("== spmvmix: int32+fp64 per slot, 300M slots (3.6 GB) GB/s\n");
     {
-        size_t n = 320000000;
-        int *ja = (int *)buf; double *as = (double *)((char *)buf + ((size_t)2 << 30));
+        size_t n = 300000000; /* 1.2 GB of JA at offset 0, 2.4 GB of AS at 1.5 GiB: inside the 4 GiB buffer */
+        int *ja = (int *)buf; double *as = (double *)((char *)buf + ((size_t)3 << 29));
         for (int g : grids) {
             double t = time_ms([&] { k_spmvmix<false><<<g, 256>>>(ja, as, n, dsink); });
             printf("grid %6d plain %8.1f", g, 12.0 * n / t * 1e-6);

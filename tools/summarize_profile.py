@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into profiles/<name>.md.
+
+    python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>.md
+
+Keeps: the bench JSON line of the kernel-trace pass, the rocprofv3
+--kernel-trace --stats table (top kernels), and per-kernel averages of the
+FETCH_SIZE / WRITE_SIZE PMC passes converted to bytes per launch with the
+gfx950 corrections of MI355X_MICROARCH.md (both counters are in KiB;
+FETCH_SIZE tallies 128-B requests at 64 B -> x2, calibrated on
+tools/microbench: 4 GiB streamed reads report 2,097,164 KiB for 4/8/16 B per
+lane, plain and non-temporal alike)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def first(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    return hits[0] if hits else None
+
+
+def pmc(path):
+    d = collections.defaultdict(list)
+    if not path:
+        return d
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    out = ["# rocprofv3 summary: %s" % os.path.basename(src.rstrip("/")), ""]
+    bj = os.path.join(src, "bench_kt.json")
+    if os.path.exists(bj) and os.path.getsize(bj):
+        line = open(bj).read().strip().splitlines()[-1]
+        try:
+            j = json.loads(line)
+            j.pop("extras", None)
+            out += ["## bench.py line (kernel-trace pass; profiled runs clock lower)",
+                    "", "```json", json.dumps(j), "```", ""]
+        except ValueError:
+            pass
+    ks = first(os.path.join(src, "kt", "**", "*kernel_stats.csv"))
+    if ks:
+        out += ["## rocprofv3 --kernel-trace --stats", "",
+                "| kernel | calls | avg us | min us | max us | % |",
+                "|---|---|---|---|---|---|"]
+        for r in list(csv.DictReader(open(ks)))[:8]:
+            out.append("| `%s` | %s | %.2f | %.2f | %.2f | %s |" % (
+                r["Name"].split("(")[0][:60], r["Calls"],
+                float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+                float(r["MaxNs"]) / 1e3, r["Percentage"]))
+        out.append("")
+    f = pmc(first(os.path.join(src, "fetch", "**", "*counter_collection.csv")))
+    w = pmc(first(os.path.join(src, "write", "**", "*counter_collection.csv")))
+    if f or w:
+        out += ["## HBM-side traffic per launch (separate --pmc passes)", "",
+                "| kernel | launches | FETCH_SIZE KiB (raw) | read bytes (x2 x1024) "
+                "| WRITE_SIZE KiB | write bytes | total bytes |",
+                "|---|---|---|---|---|---|---|"]
+        for k in f:
+            if len(f[k]) < 4 and not k.startswith("k_"):
+                continue
+            fa = sum(f[k]) / len(f[k])
+            wa = sum(w[k]) / len(w[k]) if k in w else 0.0
+            out.append("| `%s` | %d | %.1f | %.4g | %.1f | %.4g | %.4g |" % (
+                k.split("(")[0][:60], len(f[k]), fa, fa * 2048, wa, wa * 1024,
+                fa * 2048 + wa * 1024))
+        out.append("")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    open(dst, "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
