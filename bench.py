@@ -106,6 +106,23 @@ def cpu_baseline(family, K, W):
             "note": err, "host_cores": host}
 
 
+def measured_traffic(workload, kname):
+    """HBM-side bytes per launch of the dominant kernel from the committed
+    rocprofv3 PMC passes (profiles/*.traffic.json, written by
+    tools/summarize_profile.py from `tools/profile.sh` runs of THIS command);
+    None when no profile of the same workload + kernel is committed."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.traffic.json"))):
+        try:
+            t = json.load(open(fn))
+        except ValueError:
+            continue
+        if t.get("workload") == workload and kname[4:] in t.get("kernel", ""):
+            best = t
+    return best
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -213,6 +230,12 @@ def main():
             dist.destroy_process_group()
         return
 
+    workload = ("%s %s %dx%d per GPU (%dx%d global), hack 32, %d nnz/row, "
+                "column window W=%s, seed %d"
+                % (args.family, args.format.upper(), Mloc, Nglob, Mglob, Nglob,
+                   K, "N (anywhere)" if args.window <= 0 else str(W),
+                   MATRIX_SEED))
+    traffic = measured_traffic(workload, kname) if world == 1 else None
     out = {
         "metric": "fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), "
                   "1/2/4/8 MI355X",
@@ -228,11 +251,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "%s %s %dx%d per GPU (%dx%d global), hack 32, "
-                        "%d nnz/row, column window W=%s, seed %d"
-                        % (args.family, args.format.upper(), Mloc, Nglob, Mglob,
-                           Nglob, K, "N (anywhere)" if args.window <= 0
-                           else str(W), MATRIX_SEED),
+            "workload": workload,
             "kernel": kname,
             "rows_per_gpu": Mloc, "nnz_per_row": K, "nnz_global": nnz_global,
             "stored_slots_per_gpu": slots,
@@ -246,7 +265,11 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": round(traffic["bytes_per_launch"]) if traffic else None,
+            "traffic_source": ("profiles/" + traffic["source"]
+                               + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                               "separate passes, FETCH_SIZE x2)") if traffic
+            else None,
             "kernel": kname,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms_avg": round(kavg, 5),

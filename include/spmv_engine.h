@@ -41,7 +41,10 @@ extern "C" {
 typedef struct spmv_launch_opts {
     int waves_per_block; /* 1..16; 0 = process default (set_*_waves_per_block) */
     int group;           /* lanes per row of the sub-wave kernels; 0 = auto */
-    int reserved[6];     /* must be 0 */
+    int variant;         /* tuning bit-field, 0 = default; bit 0: keep the
+                            hardware's round-robin workgroup->XCD order
+                            instead of the XCD-contiguous remap */
+    int reserved[5];     /* must be 0 */
 } spmv_launch_opts;
 
 /* ---- devices ---- */

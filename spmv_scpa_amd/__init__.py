@@ -81,7 +81,7 @@ class BenchHip(C.Structure):
 
 class LaunchOpts(C.Structure):
     _fields_ = [("waves_per_block", C.c_int), ("group", C.c_int),
-                ("reserved", C.c_int * 6)]
+                ("variant", C.c_int), ("reserved", C.c_int * 5)]
 
 
 _CSRp = C.POINTER(SparseCSR)
@@ -246,10 +246,11 @@ def _take_vec(v):
     return out
 
 
-def _opts(waves_per_block=0, group=0):
+def _opts(waves_per_block=0, group=0, variant=0):
     o = LaunchOpts()
     o.waves_per_block = int(waves_per_block)
     o.group = int(group)
+    o.variant = int(variant)
     return o
 
 
@@ -551,8 +552,8 @@ class CsrDevice:
         return _lib.spmv_csr_algorithmic_bytes(self.h)
 
     def launch(self, kernel, d_x, d_y, waves_per_block=0, group=0,
-               stream=None, rows=None):
-        o = _opts(waves_per_block, group)
+               stream=None, rows=None, variant=0):
+        o = _opts(waves_per_block, group, variant)
         if rows is None:
             rc = _lib.spmv_csr_launch(self.h, kernel, C.byref(o), d_x, d_y,
                                       stream)
@@ -562,8 +563,8 @@ class CsrDevice:
         _check(rc, "spmv_csr_launch")
 
     def time(self, kernel, d_x, d_y, warmup=3, iters=20, flush_bytes=0,
-             waves_per_block=0, group=0, stream=None):
-        o = _opts(waves_per_block, group)
+             waves_per_block=0, group=0, stream=None, variant=0):
+        o = _opts(waves_per_block, group, variant)
         ms = np.zeros(max(iters, 1))
         _check(_lib.spmv_csr_time(self.h, kernel, C.byref(o), d_x, d_y, warmup,
                                   iters, flush_bytes, ms.ctypes.data_as(_dp),
@@ -617,8 +618,8 @@ class HllDevice:
         return _lib.spmv_hll_algorithmic_bytes(self.h)
 
     def launch(self, kernel, d_x, d_y, waves_per_block=0, stream=None,
-               blocks=None):
-        o = _opts(waves_per_block)
+               blocks=None, variant=0):
+        o = _opts(waves_per_block, 0, variant)
         if blocks is None:
             rc = _lib.spmv_hll_launch(self.h, kernel, C.byref(o), d_x, d_y,
                                       stream)
@@ -628,8 +629,8 @@ class HllDevice:
         _check(rc, "spmv_hll_launch")
 
     def time(self, kernel, d_x, d_y, warmup=3, iters=20, flush_bytes=0,
-             waves_per_block=0, stream=None):
-        o = _opts(waves_per_block)
+             waves_per_block=0, stream=None, variant=0, group=0):
+        o = _opts(waves_per_block, group, variant)
         ms = np.zeros(max(iters, 1))
         _check(_lib.spmv_hll_time(self.h, kernel, C.byref(o), d_x, d_y, warmup,
                                   iters, flush_bytes, ms.ctypes.data_as(_dp),

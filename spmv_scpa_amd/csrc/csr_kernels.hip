@@ -70,28 +70,69 @@ __global__ void k_csr_wave_row(int r0, int r1, const int *__restrict__ irp,
 }
 
 /* ------------------------------------------------------------------ */
-template <int G>
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    /* contiguous range of the grid per XCD (bijective for any nblk): row
+     * tiles that share an x window then meet in the same L2 */
+    const int nx = 8;
+    int q = nblk / nx, r = nblk % nx;
+    int x = bid % nx, k = bid / nx;
+    return x * q + (x < r ? x : r) + k;
+}
+
+/*
+ * G lanes per row, P rows per lane group: a wavefront owns P*(64/G)
+ * consecutive rows.  The P passes are independent, so their IRP, JA/AS and x
+ * loads are all in flight together (P x 768 B of stream per wavefront
+ * instead of 768 B): the kernel is latency-bound otherwise.
+ */
+template <int G, int P, bool REMAP>
 __global__ void k_csr_subwave_row(int r0, int r1,
                                   const int *__restrict__ irp,
                                   const int *__restrict__ ja,
                                   const double *__restrict__ as,
                                   const double *__restrict__ x,
                                   double *__restrict__ y) {
-    const int sub = threadIdx.x & (G - 1);
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long row = (long long)r0 + gid / G;
-    const bool live = row < r1;
-    double acc = 0.0;
-    if (live) {
-        const int beg = irp[row], end = irp[row + 1];
-        for (int k = beg + sub; k < end; k += G)
-            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+    constexpr int RPP = WAVE / G; /* rows per pass */
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = lane & (G - 1);
+    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const long long wave_global =
+        ((long long)bid * blockDim.x + threadIdx.x) / WAVE;
+    const long long rbase = (long long)r0 + wave_global * (P * RPP) + lane / G;
+
+    int beg[P], end[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const long long row = rbase + p * RPP;
+        const bool live = row < r1;
+        beg[p] = live ? irp[row] : 0;
+        end[p] = live ? irp[row + 1] : 0;
+    }
+    int c[P];
+    double a[P], acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int k = beg[p] + sub;
+        const bool has = k < end[p];
+        c[p] = has ? ld_stream(ja + k) : -1;
+        a[p] = has ? ld_stream(as + k) : 0.0;
     }
 #pragma unroll
-    for (int d = G / 2; d > 0; d >>= 1)
-        acc += __shfl_down(acc, d, G);
-    if (live && sub == 0)
-        y[row] = acc;
+    for (int p = 0; p < P; ++p)
+        acc[p] = c[p] >= 0 ? a[p] * x[c[p]] : 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        for (int k = beg[p] + sub + G; k < end[p]; k += G)
+            acc[p] += ld_stream(as + k) * x[ld_stream(ja + k)];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int d = G / 2; d > 0; d >>= 1)
+            acc[p] += __shfl_down(acc[p], d, G);
+        const long long row = rbase + p * RPP;
+        if (sub == 0 && row < r1)
+            y[row] = acc[p];
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -166,9 +207,24 @@ __global__ void __launch_bounds__(STREAM_THREADS)
         return;
     }
 
-    /* phase 1: coalesced stream of the workgroup's entries -> products */
-    for (int k = tid; k < cnt; k += STREAM_THREADS)
-        prod[k] = ld_stream(as + beg + k) * x[ld_stream(ja + beg + k)];
+    /* phase 1: coalesced stream of the workgroup's entries -> products;
+     * all STREAM_NNZ/STREAM_THREADS loads of a lane are issued together */
+    {
+        constexpr int E = STREAM_NNZ / STREAM_THREADS;
+        int c[E];
+        double a[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = tid + e * STREAM_THREADS;
+            const bool has = k < cnt;
+            c[e] = has ? ld_stream(ja + beg + k) : -1;
+            a[e] = has ? ld_stream(as + beg + k) : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (c[e] >= 0)
+                prod[tid + e * STREAM_THREADS] = a[e] * x[c[e]];
+    }
     __syncthreads();
 
     /* phase 2: G lanes per row, G from the mean row length of this range */
@@ -206,18 +262,28 @@ static int pick_group(const spmv_csr_dev *A, int group) {
 }
 
 template <int G>
-static void launch_subwave(int r0, int r1, int threads,
+static void launch_subwave(int r0, int r1, int threads, bool remap,
                            const spmv_csr_dev *A, const double *x, double *y,
                            hipStream_t s) {
-    long long lanes = (long long)(r1 - r0) * G;
-    unsigned grid = (unsigned)((lanes + threads - 1) / threads);
-    hipLaunchKernelGGL(k_csr_subwave_row<G>, dim3(grid), dim3(threads), 0, s,
-                       r0, r1, A->irp, A->ja, A->as, x, y);
+    constexpr int P = 4;
+    const int rows_per_wave = P * (WAVE / G);
+    long long waves = ((long long)(r1 - r0) + rows_per_wave - 1) / rows_per_wave;
+    long long wpb = threads / WAVE;
+    unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+    if (remap)
+        hipLaunchKernelGGL((k_csr_subwave_row<G, P, true>), dim3(grid),
+                           dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
+                           x, y);
+    else
+        hipLaunchKernelGGL((k_csr_subwave_row<G, P, false>), dim3(grid),
+                           dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
+                           x, y);
 }
 
 int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
-                      const double *x, double *y, int r0, int r1,
+                      int variant, const double *x, double *y, int r0, int r1,
                       hipStream_t s) {
+    const bool remap = !(variant & 1);
     if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
         return -EINVAL;
     if (r0 == r1)
@@ -242,19 +308,19 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     case 2:
         switch (pick_group(A, group)) {
         case 2:
-            launch_subwave<2>(r0, r1, threads, A, x, y, s);
+            launch_subwave<2>(r0, r1, threads, remap, A, x, y, s);
             break;
         case 4:
-            launch_subwave<4>(r0, r1, threads, A, x, y, s);
+            launch_subwave<4>(r0, r1, threads, remap, A, x, y, s);
             break;
         case 8:
-            launch_subwave<8>(r0, r1, threads, A, x, y, s);
+            launch_subwave<8>(r0, r1, threads, remap, A, x, y, s);
             break;
         case 16:
-            launch_subwave<16>(r0, r1, threads, A, x, y, s);
+            launch_subwave<16>(r0, r1, threads, remap, A, x, y, s);
             break;
         default:
-            launch_subwave<32>(r0, r1, threads, A, x, y, s);
+            launch_subwave<32>(r0, r1, threads, remap, A, x, y, s);
             break;
         }
         break;

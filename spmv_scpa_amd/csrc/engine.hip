@@ -401,7 +401,8 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
     if (!A)
         return -EINVAL;
     return csr_launch_kernel(A, kernel, pick_waves(opts, g_csr_waves),
-                             opts ? opts->group : 0, d_x, d_y, row_begin,
+                             opts ? opts->group : 0, opts ? opts->variant : 0,
+                             d_x, d_y, row_begin,
                              row_end, (hipStream_t)stream);
 }
 
@@ -580,8 +581,8 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
     int waves = pick_waves(opts, g_hll_waves);
     if (kernel == 1 && waves > 8)
         waves = 8; /* 6 KiB of LDS per wavefront, stay under 64 KiB */
-    return hll_launch_kernel(H, kernel, waves, d_x, d_y, blk_begin, blk_end,
-                             (hipStream_t)stream);
+    return hll_launch_kernel(H, kernel, waves, opts ? opts->variant : 0, d_x,
+                             d_y, blk_begin, blk_end, (hipStream_t)stream);
 }
 
 int spmv_hll_launch(const spmv_hll_dev *H, int kernel,

@@ -91,10 +91,10 @@ static inline int pick_waves(const spmv_launch_opts *o, int dflt) {
 
 /* kernel launchers (csr_kernels.hip / hll_kernels.hip) */
 int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
-                      const double *x, double *y, int r0, int r1,
+                      int variant, const double *x, double *y, int r0, int r1,
                       hipStream_t s);
 int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
-                      const double *x, double *y, int b0, int b1,
+                      int variant, const double *x, double *y, int b0, int b1,
                       hipStream_t s);
 int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s);
 

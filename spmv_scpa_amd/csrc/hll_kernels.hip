@@ -85,7 +85,7 @@ __global__ void k_hll_row_major(int M, int b0, int b1,
     if (i >= rows)
         return;
     int64_t o = off[b];
-    int w = (int)((off[b + 1] - o) / rows);
+    int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
     const int *rj = ja + o + (int64_t)i * w;
     const double *ra = as + o + (int64_t)i * w;
     double acc = 0.0;
@@ -96,44 +96,74 @@ __global__ void k_hll_row_major(int M, int b0, int b1,
 
 /* ------------------------------------------------------------------ */
 /* 2: wavefront per pair of hack blocks, col-major, direct loads        */
+/*    Software pipelined: while the x gathers of columns [j, j+U) are    */
+/*    in flight the JA/AS loads of [j+U, j+2U) are already issued, so    */
+/*    the stream never waits behind a gather round trip.                 */
 /* ------------------------------------------------------------------ */
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    /* workgroups are dealt round-robin over the 8 XCDs; give each XCD a
+     * contiguous range of the grid so neighbouring row tiles (which share
+     * their x window) meet in the same L2.  Bijective for any nblk. */
+    const int nx = 8;
+    int q = nblk / nx, r = nblk % nx;
+    int x = bid % nx, k = bid / nx;
+    return x * q + (x < r ? x : r) + k;
+}
+
+template <int U, bool REMAP>
 __global__ void k_hll_col_direct(int M, int b0, int b1,
                                  const int64_t *__restrict__ off,
                                  const int *__restrict__ ja,
                                  const double *__restrict__ as,
                                  const double *__restrict__ x,
                                  double *__restrict__ y) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    long long t = (long long)bid * blockDim.x + threadIdx.x;
     int b = b0 + (int)(t / HACK), i = (int)(t % HACK);
     if (b >= b1)
         return;
     int rows = min(HACK, M - b * HACK);
     if (i >= rows)
         return;
-    int64_t o = off[b];
-    int w = (int)((off[b + 1] - o) / rows);
+    const int64_t o = off[b];
+    const unsigned len = (unsigned)(off[b + 1] - o);
+    const int w = rows == HACK ? (int)(len >> 5) : (int)(len / (unsigned)rows);
     const int *cj = ja + o + i;
     const double *ca = as + o + i;
     double acc = 0.0;
-    int j = 0;
-    for (; j + 4 <= w; j += 4) {
-        int c0 = ld_stream(cj + (int64_t)(j + 0) * rows);
-        int c1 = ld_stream(cj + (int64_t)(j + 1) * rows);
-        int c2 = ld_stream(cj + (int64_t)(j + 2) * rows);
-        int c3 = ld_stream(cj + (int64_t)(j + 3) * rows);
-        double a0 = ld_stream(ca + (int64_t)(j + 0) * rows);
-        double a1 = ld_stream(ca + (int64_t)(j + 1) * rows);
-        double a2 = ld_stream(ca + (int64_t)(j + 2) * rows);
-        double a3 = ld_stream(ca + (int64_t)(j + 3) * rows);
-        double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        acc += a0 * x0;
-        acc += a1 * x1;
-        acc += a2 * x2;
-        acc += a3 * x3;
+    int cJ[U];
+    double cA[U];
+    const int nfull = w / U;
+    if (nfull > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cJ[u] = ld_stream(cj + u * rows);
+            cA[u] = ld_stream(ca + u * rows);
+        }
     }
-    for (; j < w; ++j)
-        acc += ld_stream(ca + (int64_t)j * rows) *
-               x[ld_stream(cj + (int64_t)j * rows)];
+    for (int c = 0; c < nfull; ++c) {
+        double xv[U], av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u] = x[cJ[u]];
+            av[u] = cA[u];
+        }
+        if (c + 1 < nfull) {
+            const int *nj = cj + (size_t)(c + 1) * U * rows;
+            const double *na = ca + (size_t)(c + 1) * U * rows;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cJ[u] = ld_stream(nj + u * rows);
+                cA[u] = ld_stream(na + u * rows);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc += av[u] * xv[u];
+    }
+    for (int j = nfull * U; j < w; ++j)
+        acc += ld_stream(ca + (size_t)j * rows) *
+               x[ld_stream(cj + (size_t)j * rows)];
     y[(int64_t)b * HACK + i] = acc;
 }
 
@@ -145,6 +175,31 @@ __global__ void k_hll_col_direct(int M, int b0, int b1,
 #define CH 8                     /* columns per staged chunk */
 #define CH_SLOTS (CH * HACK)     /* 256 slots: 1 KiB of JA, 2 KiB of AS */
 
+struct hll_chunk {
+    v4i jA, jB;
+    v2d aA0, aA1, aB0, aB1;
+};
+
+/* coalesced 16 B/lane loads of slots [s0, s0+256) of the wavefront's two
+ * blocks (predicated past the end of each block) */
+__device__ __forceinline__ void hll_chunk_load(hll_chunk &c, int s0, int lane,
+                                               const int *gjA, const int *gjB,
+                                               const double *gaA,
+                                               const double *gaB, int nA,
+                                               int nB) {
+    const int sj = s0 + 4 * lane; /* 4 ints */
+    const int sa = s0 + 2 * lane; /* 2 doubles, twice */
+    const v4i zi = {0, 0, 0, 0};
+    const v2d zd = {0, 0};
+    c.jA = sj < nA ? ld_stream((const v4i *)(gjA + sj)) : zi;
+    c.jB = sj < nB ? ld_stream((const v4i *)(gjB + sj)) : zi;
+    c.aA0 = sa < nA ? ld_stream((const v2d *)(gaA + sa)) : zd;
+    c.aA1 = sa + 128 < nA ? ld_stream((const v2d *)(gaA + sa + 128)) : zd;
+    c.aB0 = sa < nB ? ld_stream((const v2d *)(gaB + sa)) : zd;
+    c.aB1 = sa + 128 < nB ? ld_stream((const v2d *)(gaB + sa + 128)) : zd;
+}
+
+template <bool REMAP>
 __global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
                               const int *__restrict__ ja,
                               const double *__restrict__ as,
@@ -159,7 +214,8 @@ __global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
     int *s_ja = (int *)((double *)lds_raw + (size_t)waves * 2 * CH_SLOTS) +
                 (size_t)wave * 2 * CH_SLOTS;
 
-    const int bA = b0 + 2 * (blockIdx.x * waves + wave); /* wave-uniform */
+    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bA = b0 + 2 * (bid * waves + wave); /* wave-uniform */
     if (bA >= b1)
         return;
     const bool hasB = bA + 1 < b1;
@@ -172,46 +228,44 @@ __global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
 
     const int *gjA = ja + oA, *gjB = ja + oB;
     const double *gaA = as + oA, *gaB = as + oB;
+    const int *lj = s_ja + half * CH_SLOTS + i;
+    const double *la = s_as + half * CH_SLOTS + i;
     double acc = 0.0;
 
+    /* register-staged pipeline: chunk c+1 is in flight from HBM while chunk
+     * c is consumed out of LDS */
+    hll_chunk cur;
+    hll_chunk_load(cur, 0, lane, gjA, gjB, gaA, gaB, nA, nB);
     for (int s0 = 0; s0 < nmax; s0 += CH_SLOTS) {
-        /* coalesced 16 B/lane copies of the chunk [s0, s0+256) of each block */
-        const int sj = s0 + 4 * lane;       /* 4 ints   */
-        const int sa = s0 + 2 * lane;       /* 2 doubles, twice */
-        v4i jA = {0, 0, 0, 0}, jB = {0, 0, 0, 0};
-        v2d aA0 = {0, 0}, aA1 = {0, 0}, aB0 = {0, 0}, aB1 = {0, 0};
-        if (sj < nA)
-            jA = ld_stream((const v4i *)(gjA + sj));
-        if (sj < nB)
-            jB = ld_stream((const v4i *)(gjB + sj));
-        if (sa < nA)
-            aA0 = ld_stream((const v2d *)(gaA + sa));
-        if (sa + 128 < nA)
-            aA1 = ld_stream((const v2d *)(gaA + sa + 128));
-        if (sa < nB)
-            aB0 = ld_stream((const v2d *)(gaB + sa));
-        if (sa + 128 < nB)
-            aB1 = ld_stream((const v2d *)(gaB + sa + 128));
-        *(v4i *)(s_ja + 4 * lane) = jA;
-        *(v4i *)(s_ja + CH_SLOTS + 4 * lane) = jB;
-        *(v2d *)(s_as + 2 * lane) = aA0;
-        *(v2d *)(s_as + 128 + 2 * lane) = aA1;
-        *(v2d *)(s_as + CH_SLOTS + 2 * lane) = aB0;
-        *(v2d *)(s_as + CH_SLOTS + 128 + 2 * lane) = aB1;
+        *(v4i *)(s_ja + 4 * lane) = cur.jA;
+        *(v4i *)(s_ja + CH_SLOTS + 4 * lane) = cur.jB;
+        *(v2d *)(s_as + 2 * lane) = cur.aA0;
+        *(v2d *)(s_as + 128 + 2 * lane) = cur.aA1;
+        *(v2d *)(s_as + CH_SLOTS + 2 * lane) = cur.aB0;
+        *(v2d *)(s_as + CH_SLOTS + 128 + 2 * lane) = cur.aB1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        /* this lane's 8 columns out of LDS, their x gathers issued first */
         const int c0 = s0 >> 5;
-        const int *lj = s_ja + half * CH_SLOTS + i;
-        const double *la = s_as + half * CH_SLOTS + i;
+        int cc[CH];
+        double av[CH], xv[CH];
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
-            if (c0 + jj < w) {
-                int c = lj[jj * HACK];
-                acc += la[jj * HACK] * x[c];
-            }
+            cc[jj] = lj[jj * HACK];
+            av[jj] = la[jj * HACK];
         }
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj)
+            xv[jj] = (c0 + jj < w) ? x[cc[jj]] : 0.0;
+        if (s0 + CH_SLOTS < nmax)
+            hll_chunk_load(cur, s0 + CH_SLOTS, lane, gjA, gjB, gaA, gaB, nA,
+                           nB);
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj)
+            if (c0 + jj < w)
+                acc += av[jj] * xv[jj];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -238,7 +292,7 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1,
         if (i < rows) {
             live = true;
             int64_t o = off[b];
-            int w = (int)((off[b + 1] - o) / rows);
+            int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
             const int *rj = ja + o + (int64_t)i * w;
             const double *ra = as + o + (int64_t)i * w;
             for (int j = sub; j < w; j += 16)
@@ -254,8 +308,9 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1,
 
 /* ------------------------------------------------------------------ */
 int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
-                      const double *x, double *y, int b0, int b1,
+                      int variant, const double *x, double *y, int b0, int b1,
                       hipStream_t s) {
+    const bool remap = !(variant & 1);
     if (!H || !x || !y || b0 < 0 || b1 > H->nb || b0 > b1)
         return -EINVAL;
     if ((kernel == 0 || kernel == 3) == (H->col_major != 0))
@@ -279,21 +334,33 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         if (full_end > b0) {
             int pairs = (full_end - b0 + 1) / 2;
             size_t lds = (size_t)waves * 2 * CH_SLOTS * (sizeof(double) + sizeof(int));
-            hipLaunchKernelGGL(k_hll_col_lds,
-                               dim3((pairs + waves - 1) / waves),
-                               dim3(threads), lds, s, b0, full_end, H->off,
-                               H->ja, H->as, x, y);
+            if (remap)
+                hipLaunchKernelGGL(k_hll_col_lds<true>,
+                                   dim3((pairs + waves - 1) / waves),
+                                   dim3(threads), lds, s, b0, full_end, H->off,
+                                   H->ja, H->as, x, y);
+            else
+                hipLaunchKernelGGL(k_hll_col_lds<false>,
+                                   dim3((pairs + waves - 1) / waves),
+                                   dim3(threads), lds, s, b0, full_end, H->off,
+                                   H->ja, H->as, x, y);
         }
         if (full_end < b1)
-            hipLaunchKernelGGL(k_hll_col_direct, dim3(1), dim3(WAVE), 0, s,
+            hipLaunchKernelGGL((k_hll_col_direct<8, false>), dim3(1), dim3(WAVE), 0, s,
                                H->M, full_end, b1, H->off, H->ja, H->as, x, y);
         break;
     }
     case 2:
-        hipLaunchKernelGGL(k_hll_col_direct,
-                           dim3((unsigned)((lanes + threads - 1) / threads)),
-                           dim3(threads), 0, s, H->M, b0, b1, H->off, H->ja,
-                           H->as, x, y);
+        if (remap)
+            hipLaunchKernelGGL((k_hll_col_direct<8, true>),
+                               dim3((unsigned)((lanes + threads - 1) / threads)),
+                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+                               H->ja, H->as, x, y);
+        else
+            hipLaunchKernelGGL((k_hll_col_direct<8, false>),
+                               dim3((unsigned)((lanes + threads - 1) / threads)),
+                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+                               H->ja, H->as, x, y);
         break;
     case 3:
         hipLaunchKernelGGL(

@@ -167,57 +167,83 @@ class ShardedSpmv:
 
 
 def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
-    """Secondary numbers for the same JSON line: the other kernels on the
-    headline matrix, other column windows, and config 2 (banded CSR)."""
+    """Secondary numbers for the same JSON line (1 GPU only): the column-
+    window sweep of the headline family (W = N is the worst case: every 8 B
+    gather of x pulls a 128 B line through the fabric), both HLL kernels and
+    the CSR sub-wave kernel, BASELINE config 2 (banded CSR, flushed) and the
+    KKT-like stand-in for config 4."""
     st = torch.cuda.current_stream().cuda_stream
     out = {}
 
     def med(v):
         return float(np.median(v))
 
-    def row(tag, m, k, ms):
+    def row(tag, m, ms):
         b = m.algorithmic_bytes
         out[tag] = {"kernel_ms": round(ms, 5),
                     "gflops": round(2.0 * m.NZ / (ms * 1e6), 1),
                     "gbps": round(b / (ms * 1e6), 1),
                     "roofline_frac": round(b / (ms * 1e6) / 8000.0, 4)}
 
+    dx, dy = x.data_ptr(), y.data_ptr()
     if hasattr(mat, "num_blocks"):
         for k in (1, 2):
             if S.HLL_KERNEL_COL_MAJOR[k] == mat.col_major:
-                ms = med(mat.time(k, x.data_ptr(), y.data_ptr(), 2, 10, 0,
-                                  args.waves, stream=st))
-                row("headline_hll_%s" % S.HLL_KERNEL_NAMES[k], mat, k, ms)
-    # other column windows of the same 10M x 10M, 32/row family
-    for wname, W in (("W=2^20", 1 << 20), ("W=2^14", 1 << 14)):
+                row("W=N hll_%s" % S.HLL_KERNEL_NAMES[k], mat,
+                    med(mat.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+    for wname, W in (("W=2^20", 1 << 20), ("W=2^17", 1 << 17),
+                     ("W=2^14", 1 << 14), ("W=2^11", 1 << 11)):
         try:
             dA = S.CsrDevice.generate(kind, Mloc, Nglob, K, W, 0, 42)
             dH = dA.to_hll(True)
             for k in (1, 2):
-                ms = med(dH.time(k, x.data_ptr(), y.data_ptr(), 2, 10, 0,
-                                 args.waves, stream=st))
-                row("hll_%s_%s" % (S.HLL_KERNEL_NAMES[k], wname), dH, k, ms)
-            ms = med(dA.time(2, x.data_ptr(), y.data_ptr(), 2, 10, 0,
-                             args.waves, stream=st))
-            row("csr_subwave_row_%s" % wname, dA, 2, ms)
+                row("%s hll_%s" % (wname, S.HLL_KERNEL_NAMES[k]), dH,
+                    med(dH.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+            row("%s csr_subwave_row" % wname, dA,
+                med(dA.time(2, dx, dy, 2, 10, 0, args.waves, stream=st)))
             dH.release()
             dA.release()
-        except OSError as e:  # out of memory on a small card, etc.
-            out["error_" + wname] = str(e)
-    # config 2: 1M x 1M banded CSR, 16/row; 212 MB working set < 256 MiB
-    # Infinity Cache, so every timed launch is preceded by a 512 MiB flush
+        except OSError as e:  # e.g. out of memory on a smaller card
+            out["error " + wname] = str(e)
+    # 10M x 10M banded, 32/row: gathers fully coalesced (stream-bound case)
+    try:
+        dA = S.CsrDevice.generate(S.SYNTH_BANDED, Mloc, Nglob, K, 0, 0, 42)
+        dH = dA.to_hll(True)
+        row("banded10M hll_threads_col_major", dH,
+            med(dH.time(1, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        row("banded10M csr_subwave_row", dA,
+            med(dA.time(2, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        dH.release()
+        dA.release()
+    except OSError as e:
+        out["error banded10M"] = str(e)
+    # config 2: 1M x 1M banded CSR, 16/row; the 212 MB working set fits the
+    # 256 MiB Infinity Cache, so each timed launch follows a 512 MiB flush
     try:
         dB = S.CsrDevice.generate(S.SYNTH_BANDED, 1_000_000, 1_000_000, 16, 0,
                                   0, 42)
         for k in (1, 2, 4):
-            ms = med(dB.time(k, x.data_ptr(), y.data_ptr(), 2, 10, 512 << 20,
-                             args.waves, stream=st))
-            row("config2_banded_csr_%s_flushed" % S.CSR_KERNEL_NAMES[k], dB, k,
-                ms)
-        ms = med(dB.time(2, x.data_ptr(), y.data_ptr(), 2, 10, 0, args.waves,
-                         stream=st))
-        row("config2_banded_csr_subwave_row_cached", dB, 2, ms)
+            row("config2 banded1M csr_%s flushed" % S.CSR_KERNEL_NAMES[k], dB,
+                med(dB.time(k, dx, dy, 2, 20, 512 << 20, args.waves,
+                            stream=st)))
+        row("config2 banded1M csr_subwave_row cached", dB,
+            med(dB.time(2, dx, dy, 2, 20, 0, args.waves, stream=st)))
+        dHb = dB.to_hll(True)
+        row("config2 banded1M hll_threads_col_major flushed", dHb,
+            med(dHb.time(1, dx, dy, 2, 20, 512 << 20, args.waves, stream=st)))
+        dHb.release()
         dB.release()
     except OSError as e:
-        out["error_config2"] = str(e)
+        out["error config2"] = str(e)
+    # config 4 stand-in: KKT-like irregular rows (nlpkkt160 itself cannot be
+    # downloaded here): 8.3M rows, short rows + one 128-entry row in 64
+    try:
+        dK = S.CsrDevice.generate(S.SYNTH_KKT, 8_345_600, Nglob, 16, 1 << 16,
+                                  0, 42)
+        for k in (1, 2, 4):
+            row("config4-like kkt8.3M csr_%s" % S.CSR_KERNEL_NAMES[k], dK,
+                med(dK.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        dK.release()
+    except OSError as e:
+        out["error config4"] = str(e)
     return out

@@ -93,6 +93,69 @@ __global__ void k_gather(const double *__restrict__ t, size_t n, size_t win,
         *sink = acc;
 }
 
+/* gathers through a buffer descriptor with explicit cache-policy bits
+ * (gfx940+: aux bit0 = sc0, bit1 = nt, bit4 = sc1) */
+template <int AUX>
+__global__ void k_gather_buf(const double *__restrict__ t, size_t n, int per,
+                             double *sink) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)t, 0, (int)(n * 8 > 0xffffffffu ? 0xffffffffu : n * 8), 0x00020000);
+    double acc = 0;
+    uint64_t h = mix(gid);
+    for (int j = 0; j < per; j += 4) {
+        unsigned o0 = (unsigned)(mix(h + j) % n) * 8u, o1 = (unsigned)(mix(h + j + 1) % n) * 8u;
+        unsigned o2 = (unsigned)(mix(h + j + 2) % n) * 8u, o3 = (unsigned)(mix(h + j + 3) % n) * 8u;
+        v2i a = __builtin_amdgcn_raw_buffer_load_b64(rs, o0, 0, AUX);
+        v2i b = __builtin_amdgcn_raw_buffer_load_b64(rs, o1, 0, AUX);
+        v2i c = __builtin_amdgcn_raw_buffer_load_b64(rs, o2, 0, AUX);
+        v2i d = __builtin_amdgcn_raw_buffer_load_b64(rs, o3, 0, AUX);
+        acc += __builtin_bit_cast(double, a) + __builtin_bit_cast(double, b) +
+               __builtin_bit_cast(double, c) + __builtin_bit_cast(double, d);
+    }
+    if (acc == 1.2345e300)
+        *sink = acc;
+}
+
+/* divergent-gather issue rate with cheap index math: lane stride `ls`
+ * doubles inside a table of `mask`+1 doubles (L1/L2 resident) */
+__global__ void k_gather_cheap(const double *__restrict__ t, unsigned mask,
+                               unsigned ls, int per, double *sink) {
+    unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned b = gid * ls;
+    double acc = 0;
+    for (int j = 0; j < per; j += 8) {
+        unsigned o = b + j * 1031u;
+        acc += t[(o) & mask] + t[(o + 1031u) & mask] + t[(o + 2062u) & mask] +
+               t[(o + 3093u) & mask] + t[(o + 4124u) & mask] +
+               t[(o + 5155u) & mask] + t[(o + 6186u) & mask] +
+               t[(o + 7217u) & mask];
+    }
+    if (acc == 1.2345e300)
+        *sink = acc;
+}
+
+/* the same out of LDS (16 Ki doubles = 128 KiB), random-ish bank pattern */
+__global__ void k_gather_lds(const double *__restrict__ t, unsigned ls, int per,
+                             double *sink) {
+    extern __shared__ double lds[];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x)
+        lds[i] = t[i];
+    __syncthreads();
+    unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned b = gid * ls;
+    double acc = 0;
+    for (int j = 0; j < per; j += 8) {
+        unsigned o = b + j * 1031u;
+        acc += lds[(o) & 16383] + lds[(o + 1031u) & 16383] +
+               lds[(o + 2062u) & 16383] + lds[(o + 3093u) & 16383] +
+               lds[(o + 4124u) & 16383] + lds[(o + 5155u) & 16383] +
+               lds[(o + 6186u) & 16383] + lds[(o + 7217u) & 16383];
+    }
+    if (acc == 1.2345e300)
+        *sink = acc;
+}
+
 /* the same index arithmetic without the loads: cost of the hash itself */
 __global__ void k_gather_null(size_t n, size_t win, int per, double *sink) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,6 +234,31 @@ int main() {
             double t = time_ms([&] { k_gather<<<g, 256>>>((double *)buf, n, n, per, dsink); });
             printf("table %8.2f MB uniform          : %7.3f ms  %7.1f Ggather/s  (useful %6.1f GB/s)\n",
                    tb / 1048576.0, t, (double)lanes * per / t * 1e-6, 8.0 * lanes * per / t * 1e-6);
+        }
+        printf("== divergent gather issue rate, cheap indices (320M gathers)\n");
+        {
+            const unsigned strides[] = {1, 2, 16, 17, 67};
+            for (unsigned ls : strides) {
+                double t1 = time_ms([&] { k_gather_cheap<<<g, 256>>>((double *)buf, 2047u, ls, per, dsink); });
+                double t2 = time_ms([&] { k_gather_cheap<<<g, 256>>>((double *)buf, 262143u, ls, per, dsink); });
+                printf("lane stride %3u doubles: 16 KB table %7.3f ms %7.1f G/s | 2 MB table %7.3f ms %7.1f G/s\n",
+                       ls, t1, (double)lanes * per / t1 * 1e-6, t2, (double)lanes * per / t2 * 1e-6);
+            }
+            CK(hipFuncSetAttribute((const void *)k_gather_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            for (unsigned ls : strides) {
+                double t1 = time_ms([&] { k_gather_lds<<<g / 4, 1024, 131072>>>((double *)buf, ls, per, dsink); });
+                printf("LDS gather lane stride %3u: %7.3f ms %7.1f G/s\n", ls, t1, (double)lanes * per / t1 * 1e-6);
+            }
+        }
+        printf("== gather cache-policy bits (buffer_load_dwordx2), 2 MB and 512 MB tables\n");
+        {
+            const size_t ts[] = {(size_t)2 << 20, (size_t)512 << 20};
+            for (size_t tb : ts) {
+                size_t n = tb / 8;
+#define GB(AUX) { double t = time_ms([&] { k_gather_buf<AUX><<<g, 256>>>((double *)buf, n, per, dsink); }); \
+                  printf("table %7.1f MB aux=%2d : %7.3f ms %7.1f Ggather/s\n", tb / 1048576.0, AUX, t, (double)lanes * per / t * 1e-6); }
+                GB(0) GB(1) GB(2) GB(3) GB(16) GB(17) GB(18) GB(19)
+            }
         }
         /* sliding windows over an 80 MB table: what XCD-contiguous row ranges see */
         const size_t wins[] = {(size_t)1 << 9, (size_t)1 << 11, (size_t)1 << 14, (size_t)1 << 17,

@@ -73,6 +73,27 @@ def main():
                 fa * 2048 + wa * 1024))
         out.append("")
     os.makedirs(os.path.dirname(dst), exist_ok=True)
+    # machine-readable traffic of the dominant kernel: bench.py quotes it as
+    # roofline.traffic when its workload matches
+    if f and ks:
+        top = list(csv.DictReader(open(ks)))[0]["Name"]
+        if top in f:
+            fa = sum(f[top]) / len(f[top])
+            wa = sum(w[top]) / len(w[top]) if top in w else 0.0
+            tj = {"kernel": top.split("(")[0], "launches": len(f[top]),
+                  "fetch_size_kib_raw": fa, "write_size_kib": wa,
+                  "read_bytes": fa * 2048, "write_bytes": wa * 1024,
+                  "bytes_per_launch": fa * 2048 + wa * 1024,
+                  "source": os.path.basename(dst),
+                  "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests "
+                                "at 64 B; calibrated on tools/microbench)"}
+            if os.path.exists(bj) and os.path.getsize(bj):
+                try:
+                    tj["workload"] = json.loads(open(bj).read().strip()
+                                                .splitlines()[-1])["config"]["workload"]
+                except (ValueError, KeyError):
+                    pass
+            json.dump(tj, open(dst[:-3] + ".traffic.json", "w"), indent=1)
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
