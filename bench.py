@@ -118,7 +118,7 @@ def measured_traffic(workload, kname):
             t = json.load(open(fn))
         except ValueError:
             continue
-        if t.get("workload") == workload and kname[4:] in t.get("kernel", ""):
+        if t.get("workload") == workload and t.get("bench_kernel") == kname:
             best = t
     return best
 

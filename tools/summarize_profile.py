@@ -89,8 +89,10 @@ def main():
                                 "at 64 B; calibrated on tools/microbench)"}
             if os.path.exists(bj) and os.path.getsize(bj):
                 try:
-                    tj["workload"] = json.loads(open(bj).read().strip()
-                                                .splitlines()[-1])["config"]["workload"]
+                    cfg = json.loads(open(bj).read().strip()
+                                     .splitlines()[-1])["config"]
+                    tj["workload"] = cfg["workload"]
+                    tj["bench_kernel"] = cfg["kernel"]
                 except (ValueError, KeyError):
                     pass
             json.dump(tj, open(dst[:-3] + ".traffic.json", "w"), indent=1)
