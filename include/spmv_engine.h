@@ -66,6 +66,17 @@ int spmv_stream_sync(void *stream);
 int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
                         void *stream);
 
+/*
+ * Extra kernel id of both formats: the column-panel path (no reference
+ * counterpart).  The entries are additionally stored sorted by (column panel
+ * of 2^18 columns = 2 MiB of x, row); one launch per panel keeps the x
+ * gathers inside the XCD L2s.  Pays off when rows reach far beyond 4 MiB of
+ * x; costs 16 B per entry of extra HBM.  Build with spmv_*_build_panels()
+ * first (panel_cols = 0: default width), then launch this id.
+ */
+#define SPMV_CSR_KERNEL_PANELS 5
+#define SPMV_HLL_KERNEL_PANELS 4
+
 /* ---- CSR handle ---- */
 typedef struct spmv_csr_dev spmv_csr_dev;
 
@@ -82,6 +93,7 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          const spmv_launch_opts *opts, const double *d_x,
                          double *d_y, int row_begin, int row_end,
                          void *stream);
+int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols);
 int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ);
 int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A);
 /* download the device arrays into a host CSR (tests; generated matrices) */
@@ -106,6 +118,8 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                            const spmv_launch_opts *opts, const double *d_x,
                            double *d_y, int blk_begin, int blk_end,
                            void *stream);
+/* HLL source: slots whose value is exactly 0.0 (all pads) are dropped */
+int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols);
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major);
 int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H);

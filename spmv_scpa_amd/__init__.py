@@ -33,6 +33,9 @@ HACK_SIZE = 32
 SYNTH_BANDED, SYNTH_RANDOM, SYNTH_RAGGED, SYNTH_KKT = 0, 1, 2, 3
 NUM_CSR_KERNELS = 5
 NUM_HLL_KERNELS = 4
+#: extra kernel ids: the column-panel path (spmv_engine.h)
+CSR_KERNEL_PANELS = 5
+HLL_KERNEL_PANELS = 4
 CSR_KERNEL_NAMES = ["thread_row", "wave_row", "subwave_row", "block_row",
                     "stream"]
 HLL_KERNEL_NAMES = ["threads_row_major", "threads_col_major", "wave_block",
@@ -184,6 +187,8 @@ _sig("spmv_csr_launch", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
 _sig("spmv_csr_launch_rows", C.c_int, C.c_void_p, C.c_int,
      C.POINTER(LaunchOpts), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
      C.c_void_p)
+_sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_hll_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_csr_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64))
 _sig("spmv_csr_algorithmic_bytes", C.c_int64, C.c_void_p)
 _sig("spmv_csr_download", C.c_int, C.c_void_p, C.POINTER(_CSRp))
@@ -571,6 +576,10 @@ class CsrDevice:
                                   stream), "spmv_csr_time")
         return ms[:iters]
 
+    def build_panels(self, panel_cols=0):
+        _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
+               "spmv_csr_build_panels")
+
     def download(self):
         p = _CSRp()
         _check(_lib.spmv_csr_download(self.h, C.byref(p)), "spmv_csr_download")
@@ -612,6 +621,10 @@ class HllDevice:
         _check(_lib.spmv_hll_upload(H, int(col_major), C.byref(h)),
                "spmv_hll_upload")
         return cls(h)
+
+    def build_panels(self, panel_cols=0):
+        _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
+               "spmv_hll_build_panels")
 
     @property
     def algorithmic_bytes(self):

@@ -252,6 +252,7 @@ void spmv_csr_release(spmv_csr_dev *d) {
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
+    panels_free(d->panels);
     free(d);
 }
 
@@ -394,12 +395,35 @@ fail:
     return rc;
 }
 
+int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols) {
+    if (!A)
+        return -EINVAL;
+    panels_free(A->panels);
+    A->panels = NULL;
+    return panels_from_csr(A, panel_cols, &A->panels);
+}
+
+int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
+    if (!H)
+        return -EINVAL;
+    panels_free(H->panels);
+    H->panels = NULL;
+    return panels_from_hll(H, panel_cols, &H->panels);
+}
+
 int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          const spmv_launch_opts *opts, const double *d_x,
                          double *d_y, int row_begin, int row_end,
                          void *stream) {
     if (!A)
         return -EINVAL;
+    if (kernel == SPMV_CSR_KERNEL_PANELS) {
+        if (!A->panels || row_begin != 0 || row_end != A->M)
+            return -EINVAL; /* build panels first; whole matrix only */
+        return panels_launch(A->panels, A->M, pick_waves(opts, g_csr_waves),
+                             opts ? opts->variant : 0, d_x, d_y,
+                             (hipStream_t)stream);
+    }
     return csr_launch_kernel(A, kernel, pick_waves(opts, g_csr_waves),
                              opts ? opts->group : 0, opts ? opts->variant : 0,
                              d_x, d_y, row_begin,
@@ -424,6 +448,7 @@ void spmv_hll_release(spmv_hll_dev *d) {
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->off);
+    panels_free(d->panels);
     free(d);
 }
 
@@ -579,6 +604,13 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
     if (!H)
         return -EINVAL;
     int waves = pick_waves(opts, g_hll_waves);
+    if (kernel == SPMV_HLL_KERNEL_PANELS) {
+        if (!H->panels || blk_begin != 0 || blk_end != H->nb)
+            return -EINVAL; /* build panels first; whole matrix only */
+        return panels_launch(H->panels, H->M, waves,
+                             opts ? opts->variant : 0, d_x, d_y,
+                             (hipStream_t)stream);
+    }
     if (kernel == 1 && waves > 8)
         waves = 8; /* 6 KiB of LDS per wavefront, stay under 64 KiB */
     return hll_launch_kernel(H, kernel, waves, opts ? opts->variant : 0, d_x,

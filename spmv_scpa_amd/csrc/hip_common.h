@@ -53,6 +53,8 @@ static inline int hip_errno(hipError_t e) {
 #define STREAM_NNZ 2048
 #define STREAM_THREADS 256
 
+struct spmv_panels; /* panels.hip */
+
 struct spmv_csr_dev {
     int M, N;
     int64_t NZ;
@@ -64,6 +66,7 @@ struct spmv_csr_dev {
     int *rowblk;
     int n_rowblk;
     int max_row_len;
+    spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };
 
 struct spmv_hll_dev {
@@ -77,6 +80,7 @@ struct spmv_hll_dev {
     int *ja;       /* [S] pads already rewritten */
     double *as;    /* [S] */
     int64_t *off;  /* [nb+1] slot offset of each block */
+    spmv_panels *panels; /* optional column-panel copy (kernel 4) */
 };
 
 /* clamp the launch knob: waves per workgroup */
@@ -97,6 +101,15 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
                       int variant, const double *x, double *y, int b0, int b1,
                       hipStream_t s);
 int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s);
+
+/* column-panel path (panels.hip) */
+int panels_from_csr(const spmv_csr_dev *A, int panel_cols, spmv_panels **out);
+int panels_from_hll(const spmv_hll_dev *H, int panel_cols, spmv_panels **out);
+int panels_launch(const spmv_panels *P, int M, int waves, int variant,
+                  const double *x, double *y, hipStream_t s);
+void panels_free(spmv_panels *p);
+int64_t panels_nnz(const spmv_panels *P);
+int panels_count(const spmv_panels *P);
 
 extern int g_csr_waves; /* process defaults behind set_*_waves_per_block */
 extern int g_hll_waves;

@@ -296,3 +296,51 @@ def test_config3_random_hll_full_size_properties(W):
     assert np.array_equal(ys["hll1"], ys["hll2"])  # same order of operations
     dH.release()
     dA.release()
+
+
+PANEL_CASES = [
+    # tag, kind, M, N, K, W, panel_cols
+    ("wide_small_panels", S.SYNTH_RANDOM, 20_000, 20_000, 32, 1 << 30, 512),
+    ("wide_default", S.SYNTH_RANDOM, 300_000, 300_000, 32, 1 << 30, 0),
+    ("ragged", S.SYNTH_RAGGED, 5_003, 7_000, 24, 3000, 64),
+    ("kkt_long_rows", S.SYNTH_KKT, 9_000, 9_000, 16, 9000, 256),
+    ("very_long_rows", S.SYNTH_RANDOM, 70, 4_000, 3000, 1 << 30, 1024),
+    ("one_panel", S.SYNTH_RANDOM, 1_000, 1_000, 8, 100, 0),
+    ("tiny", S.SYNTH_RANDOM, 3, 64, 5, 64, 16),
+]
+
+
+@pytest.mark.parametrize("tag,kind,M,N,K,W,pc", PANEL_CASES)
+def test_column_panel_path(tag, kind, M, N, K, W, pc):
+    """Extra kernel (spmv_engine.h): entries re-ordered by (column panel,
+    row), one launch per panel, segmented scan + plain/atomic y updates."""
+    IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays(tag, M, N, IRP, JA, AS)
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(max(M, 1) * 8)
+    dA = S.CsrDevice.upload(A)
+    with pytest.raises(OSError):  # not built yet
+        dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
+    dA.build_panels(pc)
+    for w in (1, 4, 8):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        for _ in range(2):  # repeated launches must not accumulate
+            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, waves_per_block=w)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                      (tag, "csr panels", w))
+    for cm in (True, False):
+        H = S.csr_to_hll(A, cm)
+        dH = S.HllDevice.upload(H, cm)
+        dH.build_panels(pc)
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        dH.launch(S.HLL_KERNEL_PANELS, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                      (tag, "hll panels", cm))
+        dH.release()
+        S.hll_free(H)
+    dA.release()
+    S.csr_free(A)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--waves", default="4")
     ap.add_argument("--groups", default="0")
     ap.add_argument("--variants", default="0")
+    ap.add_argument("--panel-cols", default="0")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--flush", type=int, default=0)
     ap.add_argument("--out", default="")
@@ -45,18 +46,28 @@ def main():
         dA = S.CsrDevice.generate(kind, M, N, a.k, Weff, 0, 42)
         mats = {}
         for k in ints(a.hll_kernels):
-            cm = S.HLL_KERNEL_COL_MAJOR[k]
+            cm = True if k == 4 else S.HLL_KERNEL_COL_MAJOR[k]
             if cm not in mats:
                 mats[cm] = dA.to_hll(cm)
-        runs = [("hll", k, mats[S.HLL_KERNEL_COL_MAJOR[k]], 0)
-                for k in ints(a.hll_kernels)]
+        runs = [("hll", k, mats[True if k == 4 else S.HLL_KERNEL_COL_MAJOR[k]],
+                 pc if k == 4 else 0)
+                for k in ints(a.hll_kernels)
+                for pc in (ints(a.panel_cols) if k == 4 else [0])]
         runs += [("csr", k, dA, g) for k in ints(a.csr_kernels)
-                 for g in (ints(a.groups) if k == 2 else [0])]
+                 for g in (ints(a.groups) if k == 2 else
+                           ints(a.panel_cols) if k == 5 else [0])]
         for fmt, k, m, g in runs:
+            if (fmt, k) in (("hll", 4), ("csr", 5)):
+                import time as _t
+                t0 = _t.time()
+                m.build_panels(g)
+                S.stream_sync()
+                print("   panels built in %.2f s (panel_cols=%d)"
+                      % (_t.time() - t0, g), flush=True)
             for w, v in [(w, v) for w in ints(a.waves) for v in ints(a.variants)]:
                 kw = dict(warmup=2, iters=a.iters, flush_bytes=a.flush,
                           waves_per_block=w, variant=v)
-                if fmt == "csr":
+                if fmt == "csr" and k == 2:
                     kw["group"] = g
                 ms = float(np.median(m.time(k, d_x.ptr, d_y.ptr, **kw)))
                 b = m.algorithmic_bytes
