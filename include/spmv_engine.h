@@ -67,12 +67,15 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
                         void *stream);
 
 /*
- * Extra kernel id of both formats: the column-panel path (no reference
- * counterpart).  The entries are additionally stored sorted by (column panel
- * of 2^18 columns = 2 MiB of x, row); one launch per panel keeps the x
- * gathers inside the XCD L2s.  Pays off when rows reach far beyond 4 MiB of
- * x; costs 16 B per entry of extra HBM.  Build with spmv_*_build_panels()
- * first (panel_cols = 0: default width), then launch this id.
+ * Extra kernel id of both formats: the 2-D blocked path (no reference
+ * counterpart, panels.hip).  The entries are additionally stored bucketed by
+ * (row tile of <= 8192 rows, column panel of 2^19 columns = 4 MiB of x);
+ * one launch per panel keeps the x gathers inside the XCD L2s while the
+ * tile's slice of y accumulates in LDS.  Pays off only when rows reach far
+ * beyond an L2 of x (1.9x on config 3 with columns anywhere; slower on
+ * matrices with locality); costs 14 B per entry of extra HBM.  Build with
+ * spmv_*_build_panels() first (panel_cols = 0: default width), then launch
+ * this id.  opts.variant bit 3 selects the single-launch persistent form.
  */
 #define SPMV_CSR_KERNEL_PANELS 5
 #define SPMV_HLL_KERNEL_PANELS 4

@@ -312,8 +312,8 @@ PANEL_CASES = [
 
 @pytest.mark.parametrize("tag,kind,M,N,K,W,pc", PANEL_CASES)
 def test_column_panel_path(tag, kind, M, N, K, W, pc):
-    """Extra kernel (spmv_engine.h): entries re-ordered by (column panel,
-    row), one launch per panel, segmented scan + plain/atomic y updates."""
+    """Extra kernel (spmv_engine.h, panels.hip): entries bucketed by (row
+    tile, column panel), y tile accumulated in LDS with ds_add_f64."""
     IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
     x = O.synth_x(7, 0, N)
     y_ref = O.csr_spmv(IRP, JA, AS, x)
@@ -324,13 +324,13 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc):
     with pytest.raises(OSError):  # not built yet
         dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
     dA.build_panels(pc)
-    for w in (1, 4, 8):
+    for variant in (0, 8):  # per-panel launches / one persistent launch
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         for _ in range(2):  # repeated launches must not accumulate
-            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, waves_per_block=w)
+            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant)
         S.stream_sync()
         assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
-                      (tag, "csr panels", w))
+                      (tag, "csr panels", variant))
     for cm in (True, False):
         H = S.csr_to_hll(A, cm)
         dH = S.HllDevice.upload(H, cm)

@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# PMC counters for an arbitrary python command on the GPU box:
+#   tools/pmc.sh <tag> "<counters space separated>" <python args...>
+set -uo pipefail
+tag="$1"; ctr="$2"; shift 2
+root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+out="$root/gpurun_out/pmc_$tag"
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out" -- python3 "$@" > "$out/stdout.txt" 2> "$out/stderr.txt"
+echo "rc=$?"
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(f[0])):
+    d[(r["Kernel_Name"].split("(")[0][:50], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for k, v in sorted(d.items()):
+    if len(v) >= 3:
+        print("%-52s %-16s n=%3d avg=%.4g" % (k[0], k[1], len(v), sum(v) / len(v)))
+PY
