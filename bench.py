@@ -158,28 +158,47 @@ def main():
     # ---- build the shard in HBM (device-side generator + converter) ----
     t_setup = time.time()
     dA = S.CsrDevice.generate(kind, Mloc, Nglob, K, W, row0, MATRIX_SEED)
-    if args.format == "hll":
-        kernel = args.kernel if args.kernel >= 0 else 1
-        mat = dA.to_hll(S.HLL_KERNEL_COL_MAJOR[kernel])
-        nnz_local, slots = dA.NZ, mat.slots
-        dA.release()
-        kname = "hll_" + S.HLL_KERNEL_NAMES[kernel]
-    else:
-        kernel = args.kernel if args.kernel >= 0 else 2
-        mat = dA
-        nnz_local, slots = dA.NZ, dA.NZ
-        kname = "csr_" + S.CSR_KERNEL_NAMES[kernel]
-    alg_bytes = mat.algorithmic_bytes  # per launch, per GPU (SURVEY 8d)
-
     x = torch.empty(Nglob, dtype=torch.float64, device=dev)
     y = torch.zeros(Mglob, dtype=torch.float64, device=dev)
     S.dev_fill_synth(x.data_ptr(), Nglob, X_SEED, 0,
                      torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    tuned = None
+    if args.format == "hll":
+        col_major = True if args.kernel in (-1, 4) else \
+            S.HLL_KERNEL_COL_MAJOR[args.kernel]
+        mat = dA.to_hll(col_major)
+        nnz_local, slots = dA.NZ, mat.slots
+        dA.release()
+        labels, prefix = S.HLL_KERNEL_LABELS, "hll_"
+    else:
+        mat = dA
+        nnz_local, slots = dA.NZ, dA.NZ
+        labels, prefix = S.CSR_KERNEL_LABELS, "csr_"
+    if args.kernel >= 0:
+        kernel = args.kernel
+        if labels[kernel] == "tile_panels":
+            mat.build_panels(0)
+    else:
+        # kernel chosen by measurement (spmv_*_autotune): the coalesced
+        # kernels and, if they run far below the stream rate, the 2-D
+        # blocked path.  Every rank must take the same decision.
+        kernel, tuned = mat.autotune(x.data_ptr(), y.data_ptr() + 8 * row0)
+        if world > 1:
+            kk = torch.tensor([kernel], device=dev)
+            dist.broadcast(kk, 0)
+            if int(kk.item()) != kernel:
+                kernel = int(kk.item())
+                if labels[kernel] == "tile_panels":
+                    mat.build_panels(0)
+    kname = prefix + labels[kernel]
+    alg_bytes = mat.algorithmic_bytes  # per launch, per GPU (SURVEY 8d)
+    torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
+    chunks = 1 if labels[kernel] == "tile_panels" else args.chunks
     sharded = D.ShardedSpmv(mat, kernel, rank, world, Mloc, x, y,
-                            waves_per_block=args.waves, chunks=args.chunks)
+                            waves_per_block=args.waves, chunks=chunks)
 
     # ---- correctness spot check against the counter-based definition ----
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -253,11 +272,13 @@ def main():
         "config": {
             "workload": workload,
             "kernel": kname,
+            "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
+            if tuned is not None else "fixed by --kernel",
             "rows_per_gpu": Mloc, "nnz_per_row": K, "nnz_global": nnz_global,
             "stored_slots_per_gpu": slots,
             "partition": "contiguous row ranges, x replicated, in-place "
                          "all-gather(y) over RCCL" if world > 1 else "single GPU",
-            "chunks": args.chunks,
+            "chunks": chunks,
         },
         "roofline": {
             "bound": "hbm",

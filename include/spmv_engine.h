@@ -69,10 +69,10 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
 /*
  * Extra kernel id of both formats: the 2-D blocked path (no reference
  * counterpart, panels.hip).  The entries are additionally stored bucketed by
- * (row tile of <= 8192 rows, column panel of 2^19 columns = 4 MiB of x);
+ * (row tile of 1024 rows, column panel of 2^18 columns = 2 MiB of x);
  * one launch per panel keeps the x gathers inside the XCD L2s while the
  * tile's slice of y accumulates in LDS.  Pays off only when rows reach far
- * beyond an L2 of x (1.9x on config 3 with columns anywhere; slower on
+ * beyond an L2 of x (2.2x on config 3 with columns anywhere; slower on
  * matrices with locality); costs 14 B per entry of extra HBM.  Build with
  * spmv_*_build_panels() first (panel_cols = 0: default width), then launch
  * this id.  opts.variant bit 3 selects the single-launch persistent form.
@@ -143,6 +143,17 @@ int spmv_hll_time(const spmv_hll_dev *H, int kernel,
                   const spmv_launch_opts *opts, const double *d_x, double *d_y,
                   int warmup, int iters, size_t flush_bytes, double *ms_each,
                   void *stream);
+
+/*
+ * Pick the fastest kernel for this matrix by measurement (5 launches each):
+ * the coalesced kernels of the handle's layout and, when allow_panels != 0
+ * and those run well below the stream rate, the 2-D blocked path (built on
+ * demand, released again if it loses).  d_y is scratch.
+ */
+int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
+                      int allow_panels, int *best_kernel, double *best_ms);
+int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
+                      int allow_panels, int *best_kernel, double *best_ms);
 
 /* Library self-description: "spmv_scpa_amd <version> gfx950". */
 const char *spmv_version(void);

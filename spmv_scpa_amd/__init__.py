@@ -40,6 +40,9 @@ CSR_KERNEL_NAMES = ["thread_row", "wave_row", "subwave_row", "block_row",
                     "stream"]
 HLL_KERNEL_NAMES = ["threads_row_major", "threads_col_major", "wave_block",
                     "subwave_row"]
+#: names including the extra 2-D blocked path
+CSR_KERNEL_LABELS = CSR_KERNEL_NAMES + ["tile_panels"]
+HLL_KERNEL_LABELS = HLL_KERNEL_NAMES + ["tile_panels"]
 #: layout each HLL kernel expects (reference main.c:324-325)
 HLL_KERNEL_COL_MAJOR = [False, True, True, False]
 
@@ -187,6 +190,10 @@ _sig("spmv_csr_launch", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
 _sig("spmv_csr_launch_rows", C.c_int, C.c_void_p, C.c_int,
      C.POINTER(LaunchOpts), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
      C.c_void_p)
+_sig("spmv_csr_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+     _ip, _dp)
+_sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+     _ip, _dp)
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_hll_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_csr_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64))
@@ -580,6 +587,14 @@ class CsrDevice:
         _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
                "spmv_csr_build_panels")
 
+    def autotune(self, d_x, d_y, allow_panels=True):
+        """-> (kernel id, median ms) of the fastest kernel for this matrix"""
+        k, ms = C.c_int(), C.c_double()
+        _check(_lib.spmv_csr_autotune(self.h, d_x, d_y, int(allow_panels),
+                                      C.byref(k), C.byref(ms)),
+               "spmv_csr_autotune")
+        return k.value, ms.value
+
     def download(self):
         p = _CSRp()
         _check(_lib.spmv_csr_download(self.h, C.byref(p)), "spmv_csr_download")
@@ -625,6 +640,14 @@ class HllDevice:
     def build_panels(self, panel_cols=0):
         _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
                "spmv_hll_build_panels")
+
+    def autotune(self, d_x, d_y, allow_panels=True):
+        """-> (kernel id, median ms) of the fastest kernel for this matrix"""
+        k, ms = C.c_int(), C.c_double()
+        _check(_lib.spmv_hll_autotune(self.h, d_x, d_y, int(allow_panels),
+                                      C.byref(k), C.byref(ms)),
+               "spmv_hll_autotune")
+        return k.value, ms.value
 
     @property
     def algorithmic_bytes(self):

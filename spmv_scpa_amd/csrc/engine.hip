@@ -420,7 +420,8 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
     if (kernel == SPMV_CSR_KERNEL_PANELS) {
         if (!A->panels || row_begin != 0 || row_end != A->M)
             return -EINVAL; /* build panels first; whole matrix only */
-        return panels_launch(A->panels, A->M, pick_waves(opts, g_csr_waves),
+        return panels_launch(A->panels, A->M,
+                             opts ? opts->waves_per_block : 0,
                              opts ? opts->variant : 0, d_x, d_y,
                              (hipStream_t)stream);
     }
@@ -607,7 +608,8 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
     if (kernel == SPMV_HLL_KERNEL_PANELS) {
         if (!H->panels || blk_begin != 0 || blk_end != H->nb)
             return -EINVAL; /* build panels first; whole matrix only */
-        return panels_launch(H->panels, H->M, waves,
+        return panels_launch(H->panels, H->M,
+                             opts ? opts->waves_per_block : 0,
                              opts ? opts->variant : 0, d_x, d_y,
                              (hipStream_t)stream);
     }
@@ -691,6 +693,111 @@ int spmv_hll_time(const spmv_hll_dev *H, int kernel,
     return timed_loop(
         [&]() { return spmv_hll_launch(H, kernel, opts, d_x, d_y, stream); },
         warmup, iters, flush_bytes, ms_each, (hipStream_t)stream);
+}
+
+/* ------------------------------------------------------------------ */
+/* kernel selection by measurement                                      */
+/* ------------------------------------------------------------------ */
+
+static double median_of(std::vector<double> v) {
+    std::sort(v.begin(), v.end());
+    return v.empty() ? 0.0 : v[v.size() / 2];
+}
+
+int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
+                      int allow_panels, int *best_kernel, double *best_ms) {
+    if (!H || !best_kernel)
+        return -EINVAL;
+    const int cand_cm[2] = {1, 2}, cand_rm[2] = {3, 0};
+    const int *cand = H->col_major ? cand_cm : cand_rm;
+    int best = -1;
+    double bms = 1e300;
+    std::vector<double> ms(5);
+    for (int k = 0; k < 2; ++k) {
+        int rc = spmv_hll_time(H, cand[k], NULL, d_x, d_y, 1, 5, 0, ms.data(),
+                               NULL);
+        if (rc)
+            return rc;
+        double m = median_of(ms);
+        if (m < bms) {
+            bms = m;
+            best = cand[k];
+        }
+    }
+    /* the blocked path only pays when the gathers leave the L2: skip the
+     * build when the direct kernels already run near the stream rate */
+    const double stream_ms =
+        (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
+    if (allow_panels && bms > 2.5 * stream_ms) {
+        int rc = H->panels ? 0 : spmv_hll_build_panels(H, 0);
+        if (rc == 0) {
+            rc = spmv_hll_time(H, SPMV_HLL_KERNEL_PANELS, NULL, d_x, d_y, 1, 5,
+                               0, ms.data(), NULL);
+            if (rc)
+                return rc;
+            double m = median_of(ms);
+            if (m < bms) {
+                bms = m;
+                best = SPMV_HLL_KERNEL_PANELS;
+            } else {
+                panels_free(H->panels); /* give the 14 B/entry back */
+                H->panels = NULL;
+            }
+        } else if (rc != -ENOMEM && rc != -EOVERFLOW) {
+            return rc;
+        }
+    }
+    *best_kernel = best;
+    if (best_ms)
+        *best_ms = bms;
+    return 0;
+}
+
+int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
+                      int allow_panels, int *best_kernel, double *best_ms) {
+    if (!A || !best_kernel)
+        return -EINVAL;
+    const int cand[3] = {2, 4, 1};
+    int best = -1;
+    double bms = 1e300;
+    std::vector<double> ms(5);
+    for (int k = 0; k < 3; ++k) {
+        if (cand[k] == 1 && A->M > 0 && (double)A->NZ / A->M < 48.0)
+            continue; /* a wavefront per row wastes lanes on short rows */
+        int rc = spmv_csr_time(A, cand[k], NULL, d_x, d_y, 1, 5, 0, ms.data(),
+                               NULL);
+        if (rc)
+            return rc;
+        double m = median_of(ms);
+        if (m < bms) {
+            bms = m;
+            best = cand[k];
+        }
+    }
+    const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
+    if (allow_panels && bms > 2.5 * stream_ms) {
+        int rc = A->panels ? 0 : spmv_csr_build_panels(A, 0);
+        if (rc == 0) {
+            rc = spmv_csr_time(A, SPMV_CSR_KERNEL_PANELS, NULL, d_x, d_y, 1, 5,
+                               0, ms.data(), NULL);
+            if (rc)
+                return rc;
+            double m = median_of(ms);
+            if (m < bms) {
+                bms = m;
+                best = SPMV_CSR_KERNEL_PANELS;
+            } else {
+                panels_free(A->panels);
+                A->panels = NULL;
+            }
+        } else if (rc != -ENOMEM && rc != -EOVERFLOW) {
+            return rc;
+        }
+    }
+    *best_kernel = best;
+    if (best_ms)
+        *best_ms = bms;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ */

@@ -10,8 +10,8 @@
  * anywhere spends 5.8 ms on its 320 M gathers whatever the kernel does.
  *
  * What: at upload the entries are bucketed by (row tile, column panel): a
- * tile is <= 8192 consecutive rows (its slice of y fits LDS, 64 KiB), a
- * panel is 2^19 columns (4 MiB of x).  Entries are stored tile-major and,
+ * tile is 1024 consecutive rows (its slice of y fits LDS, 8 KiB), a
+ * panel is 2^18 columns (2 MiB of x).  Entries are stored tile-major and,
  * inside a tile, in panel order (col int32, row-in-tile uint16, value f64:
  * 14 B).  Products are added into the LDS tile with the hardware LDS fp64
  * atomic (ds_add_f64): no segmented reduction, no ordering inside a bucket.
@@ -21,8 +21,8 @@
  * tile has one owner per launch, launches are stream-ordered, y is zeroed
  * first).  Every CU gathers from the same panel by construction.  Cost:
  * y is re-read and re-written once per panel that touches the tile.
- * Measured on config 3 with columns anywhere: 3.04 ms vs 5.81 ms for the
- * direct kernels (1.9x).  It LOSES on matrices with locality (most
+ * Measured on config 3 with columns anywhere: 2.62 ms vs 5.81 ms for the
+ * direct kernels (2.2x).  It LOSES on matrices with locality (most
  * (tile, panel) buckets empty -> few workgroups per launch), so it is
  * opt-in and bench.py picks it only when it measures faster.
  *
@@ -203,32 +203,22 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    int shift = 19; /* 2^19 columns = 4 MiB of x, one XCD's L2: measured
-                       best (3.04 ms vs 3.29 ms at 2^18 on config 3, W = N) */
+    int shift = 18; /* 2^18 columns = 2 MiB of x: half of an XCD's L2 */
     if (panel_cols > 0) {
         shift = 0;
         while ((1 << (shift + 1)) <= panel_cols && shift < 30)
             ++shift;
     }
     const int panels = (int)((((int64_t)(N > 0 ? N : 1) - 1) >> shift) + 1);
-    /* tiles: an integral number of rounds of the persistent grid, so all
-     * workgroups finish together */
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipGetDeviceProperties(&prop, dev) != hipSuccess)
-        return -ENODEV;
-    const long long grid = (long long)prop.multiProcessorCount * 2;
-    long long rounds = ((long long)M + grid * TILE_ROWS_MAX - 1) /
-                       (grid * TILE_ROWS_MAX);
-    if (rounds < 1)
-        rounds = 1;
-    long long tr = ((long long)M + grid * rounds - 1) / (grid * rounds);
-    tr = (tr + 31) / 32 * 32;
-    if (tr < 32)
-        tr = 32;
-    if (tr > TILE_ROWS_MAX)
-        tr = TILE_ROWS_MAX;
+    /* tile height: 1024 rows (8 KiB of LDS) measured best for the default
+     * one-launch-per-panel schedule on config 3 (2.62 ms; 3.3 ms at 8192):
+     * many small workgroups overlap their load / gather / store phases */
+    long long tr = 1024;
+    if (const char *ev = getenv("SPMV_TILE_ROWS")) { /* tuning override */
+        long long o = atoll(ev);
+        if (o >= 32 && o <= TILE_ROWS_MAX)
+            tr = o / 32 * 32;
+    }
     const int tiles = (int)(((long long)M + tr - 1) / tr);
     if ((uint64_t)(tiles > 0 ? tiles : 1) * (uint64_t)panels >= 0xffffffffull)
         return -EOVERFLOW;
@@ -396,7 +386,8 @@ __global__ void __launch_bounds__(TILE_THREADS)
  * launch and launches are stream-ordered).  All CUs gather from one panel by
  * construction, at the price of re-reading and re-writing y once per panel.
  */
-__global__ void __launch_bounds__(TILE_THREADS)
+template <int NT>
+__global__ void __launch_bounds__(NT)
     k_tiles_one_panel(int M, int tile_rows, int panels, int panel,
                       const int64_t *__restrict__ bptr,
                       const int *__restrict__ tcol,
@@ -411,16 +402,16 @@ __global__ void __launch_bounds__(TILE_THREADS)
     if (b >= e)
         return; /* nothing of this tile in this panel: y untouched */
     const int64_t row0 = (int64_t)t * tile_rows;
-    for (int i = tid; i < tile_rows; i += TILE_THREADS)
+    for (int i = tid; i < tile_rows; i += NT)
         ytile[i] = row0 + i < M ? y[row0 + i] : 0.0;
     __syncthreads();
-    for (int64_t k0 = b + tid; k0 < e; k0 += TILE_THREADS * TILE_UNROLL) {
+    for (int64_t k0 = b + tid; k0 < e; k0 += NT * TILE_UNROLL) {
         int c[TILE_UNROLL];
         unsigned short rl[TILE_UNROLL];
         double v[TILE_UNROLL], xv[TILE_UNROLL];
 #pragma unroll
         for (int u = 0; u < TILE_UNROLL; ++u) {
-            const int64_t k = k0 + (int64_t)u * TILE_THREADS;
+            const int64_t k = k0 + (int64_t)u * NT;
             const bool ok = k < e;
             c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
             rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
@@ -435,13 +426,12 @@ __global__ void __launch_bounds__(TILE_THREADS)
                 unsafeAtomicAdd(&ytile[rl[u]], v[u] * xv[u]);
     }
     __syncthreads();
-    for (int i = tid; i < tile_rows && row0 + i < M; i += TILE_THREADS)
+    for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
         y[row0 + i] = ytile[i];
 }
 
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s) {
-    (void)waves; /* fixed geometry: TILE_THREADS lanes, tile_rows*8 B of LDS */
     if (!P)
         return -EINVAL;
     if (M == 0)
@@ -456,11 +446,19 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     const size_t lds = (size_t)P->tile_rows * sizeof(double);
     if (!(variant & 8)) { /* default: one launch per panel */
         HIP_RET(hipMemsetAsync(y, 0, (size_t)M * sizeof(double), s));
-        for (int p = 0; p < P->panels; ++p)
-            hipLaunchKernelGGL(k_tiles_one_panel, dim3(P->tiles),
-                               dim3(TILE_THREADS), lds, s, M, P->tile_rows,
-                               P->panels, p, P->bptr, P->col, P->rloc, P->val,
-                               x, y);
+        const bool small = (waves > 0 && waves < 8);
+        for (int p = 0; p < P->panels; ++p) {
+            if (small)
+                hipLaunchKernelGGL(k_tiles_one_panel<256>, dim3(P->tiles),
+                                   dim3(256), lds, s, M, P->tile_rows,
+                                   P->panels, p, P->bptr, P->col, P->rloc,
+                                   P->val, x, y);
+            else
+                hipLaunchKernelGGL(k_tiles_one_panel<512>, dim3(P->tiles),
+                                   dim3(512), lds, s, M, P->tile_rows,
+                                   P->panels, p, P->bptr, P->col, P->rloc,
+                                   P->val, x, y);
+        }
         return hip_errno(hipGetLastError());
     }
 #define TL(A) hipLaunchKernelGGL(k_tiles_spmv<A>, dim3(grid), dim3(TILE_THREADS), \

@@ -186,11 +186,17 @@ def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
                     "roofline_frac": round(b / (ms * 1e6) / 8000.0, 4)}
 
     dx, dy = x.data_ptr(), y.data_ptr()
-    if hasattr(mat, "num_blocks"):
+    if hasattr(mat, "num_blocks") and mat.col_major:
         for k in (1, 2):
-            if S.HLL_KERNEL_COL_MAJOR[k] == mat.col_major:
-                row("W=N hll_%s" % S.HLL_KERNEL_NAMES[k], mat,
-                    med(mat.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+            row("W=N hll_%s" % S.HLL_KERNEL_NAMES[k], mat,
+                med(mat.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        try:
+            mat.build_panels(0)
+            row("W=N hll_tile_panels", mat,
+                med(mat.time(S.HLL_KERNEL_PANELS, dx, dy, 2, 10, 0, args.waves,
+                             stream=st)))
+        except OSError as e:
+            out["error W=N tile_panels"] = str(e)
     for wname, W in (("W=2^20", 1 << 20), ("W=2^17", 1 << 17),
                      ("W=2^14", 1 << 14), ("W=2^11", 1 << 11)):
         try:
