@@ -16,8 +16,8 @@
  * 14 B).  Products are added into the LDS tile with the hardware LDS fp64
  * atomic (ds_add_f64): no segmented reduction, no ordering inside a bucket.
  *
- * Default schedule: ONE LAUNCH PER PANEL.  Workgroup t adds bucket
- * (t, panel) into its y slice (coalesced read-modify-write through LDS; a
+ * Default schedule: ONE LAUNCH PER STEP; in step s workgroup t adds the
+ * s-th non-empty bucket of tile t into its y slice (coalesced read-modify-write through LDS; a
  * tile has one owner per launch, launches are stream-ordered, y is zeroed
  * first).  Every CU gathers from the same panel by construction.  Cost:
  * y is re-read and re-written once per panel that touches the tile.
@@ -55,6 +55,10 @@ struct spmv_panels {
     double *val;     /* [nnz] */
     int64_t *tptr;   /* DEVICE [tiles+1] entry range of each tile */
     int64_t *bptr;   /* DEVICE [tiles*panels+1] start of bucket (tile, panel) */
+    int64_t *cb;     /* DEVICE [tiles*panels*2] (begin,end) of the s-th NON-EMPTY
+                        bucket of each tile, tile-major */
+    int *nbk;        /* DEVICE [tiles] non-empty buckets per tile */
+    int max_nbk;     /* launches needed = max over tiles */
 };
 
 void panels_free(spmv_panels *p) {
@@ -65,6 +69,8 @@ void panels_free(spmv_panels *p) {
     (void)hipFree(p->val);
     (void)hipFree(p->tptr);
     (void)hipFree(p->bptr);
+    (void)hipFree(p->cb);
+    (void)hipFree(p->nbk);
     free(p);
 }
 
@@ -195,6 +201,34 @@ __global__ void k_bucket_bounds(int64_t buckets, int64_t n,
     bptr[b] = lo;
 }
 
+/* compact every tile's non-empty buckets; one thread per tile */
+__global__ void k_compact_buckets(int tiles, int panels,
+                                  const int64_t *__restrict__ bptr,
+                                  int64_t *cb, int *nbk) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles)
+        return;
+    int n = 0;
+    for (int p = 0; p < panels; ++p) {
+        int64_t b = bptr[(int64_t)t * panels + p];
+        int64_t e = bptr[(int64_t)t * panels + p + 1];
+        if (e > b) {
+            cb[((int64_t)t * panels + n) * 2] = b;
+            cb[((int64_t)t * panels + n) * 2 + 1] = e;
+            ++n;
+        }
+    }
+    nbk[t] = n;
+}
+
+__global__ void k_max_int(int n, const int *__restrict__ v, int *out) {
+    int m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += gridDim.x * blockDim.x)
+        m = max(m, v[i]);
+    atomicMax(out, m);
+}
+
 static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
                         const int *irp_or_null, const int64_t *off_or_null,
                         int col_major, const int *ja, const double *as,
@@ -288,6 +322,20 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
                            dim3((unsigned)((buckets + 256) / 256)), dim3(256),
                            0, 0, buckets, slots, skey, P->bptr);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMalloc((void **)&P->cb,
+                          ((size_t)buckets + 1) * 2 * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&P->nbk, ((size_t)tiles + 1) * sizeof(int)));
+        HIP_TRY(hipMemset(P->nbk + tiles, 0, sizeof(int)));
+        if (tiles > 0) {
+            hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
+                               dim3(256), 0, 0, tiles, panels, P->bptr, P->cb,
+                               P->nbk);
+            hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, 0, tiles,
+                               P->nbk, P->nbk + tiles);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpy(&P->max_nbk, P->nbk + tiles, sizeof(int),
+                          hipMemcpyDeviceToHost));
     }
     HIP_TRY(hipMemcpy(&total, P->tptr + tiles, sizeof total,
                       hipMemcpyDeviceToHost));
@@ -388,19 +436,27 @@ __global__ void __launch_bounds__(TILE_THREADS)
  */
 template <int NT>
 __global__ void __launch_bounds__(NT)
-    k_tiles_one_panel(int M, int tile_rows, int panels, int panel,
-                      const int64_t *__restrict__ bptr,
+    k_tiles_one_panel(int M, int tile_rows, int panels, int step,
+                      const int64_t *__restrict__ cb,
+                      const int *__restrict__ nbk,
                       const int *__restrict__ tcol,
                       const unsigned short *__restrict__ trow,
                       const double *__restrict__ tval,
                       const double *__restrict__ x, double *__restrict__ y) {
     extern __shared__ double ytile[];
     const int tid = threadIdx.x;
-    const int t = blockIdx.x;
-    const int64_t b = bptr[(int64_t)t * panels + panel];
-    const int64_t e = bptr[(int64_t)t * panels + panel + 1];
-    if (b >= e)
-        return; /* nothing of this tile in this panel: y untouched */
+    /* XCD-contiguous tile ranges: the tiles an XCD runs at one time are
+     * neighbours, so their step-th panels coincide or are adjacent */
+    int t;
+    {
+        const int nx = 8, nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk / nx, r = nblk % nx, xx = bid % nx, kk = bid / nx;
+        t = xx * q + (xx < r ? xx : r) + kk;
+    }
+    if (step >= nbk[t])
+        return; /* this tile has fewer non-empty buckets: y untouched */
+    const int64_t b = cb[((int64_t)t * panels + step) * 2];
+    const int64_t e = cb[((int64_t)t * panels + step) * 2 + 1];
     const int64_t row0 = (int64_t)t * tile_rows;
     for (int i = tid; i < tile_rows; i += NT)
         ytile[i] = row0 + i < M ? y[row0 + i] : 0.0;
@@ -447,17 +503,20 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     if (!(variant & 8)) { /* default: one launch per panel */
         HIP_RET(hipMemsetAsync(y, 0, (size_t)M * sizeof(double), s));
         const bool small = (waves > 0 && waves < 8);
-        for (int p = 0; p < P->panels; ++p) {
+        /* launch `step` handles the step-th NON-EMPTY bucket of every tile:
+         * a matrix whose rows reach over k panels needs k launches, all
+         * tiles busy in each of them */
+        for (int p = 0; p < P->max_nbk; ++p) {
             if (small)
                 hipLaunchKernelGGL(k_tiles_one_panel<256>, dim3(P->tiles),
                                    dim3(256), lds, s, M, P->tile_rows,
-                                   P->panels, p, P->bptr, P->col, P->rloc,
-                                   P->val, x, y);
+                                   P->panels, p, P->cb, P->nbk, P->col,
+                                   P->rloc, P->val, x, y);
             else
                 hipLaunchKernelGGL(k_tiles_one_panel<512>, dim3(P->tiles),
                                    dim3(512), lds, s, M, P->tile_rows,
-                                   P->panels, p, P->bptr, P->col, P->rloc,
-                                   P->val, x, y);
+                                   P->panels, p, P->cb, P->nbk, P->col,
+                                   P->rloc, P->val, x, y);
         }
         return hip_errno(hipGetLastError());
     }

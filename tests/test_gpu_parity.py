@@ -344,3 +344,31 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc):
         S.hll_free(H)
     dA.release()
     S.csr_free(A)
+
+
+def test_autotune_picks_a_valid_kernel_and_stays_correct():
+    """spmv_*_autotune: measured choice between the coalesced kernels and the
+    2-D blocked path; whatever it picks must still match the oracle."""
+    M = N = 400_000
+    for W in (256, 1 << 30):
+        IRP, JA, AS = O.synth_csr(S.SYNTH_RANDOM, M, N, 32, W, 42)
+        x = O.synth_x(7, 0, N)
+        y_ref = O.csr_spmv(IRP, JA, AS, x)
+        scale = O.csr_abs_spmv(IRP, JA, AS, x)
+        A = S.csr_from_arrays("auto", M, N, IRP, JA, AS)
+        dA = S.CsrDevice.upload(A)
+        d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+        k, ms = dA.autotune(d_x.ptr, d_y.ptr)
+        assert k in (1, 2, 4, S.CSR_KERNEL_PANELS) and ms > 0
+        dA.launch(k, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, ("auto csr", W, k))
+        dH = dA.to_hll(True)
+        k, ms = dH.autotune(d_x.ptr, d_y.ptr)
+        assert k in (1, 2, S.HLL_KERNEL_PANELS) and ms > 0
+        dH.launch(k, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, ("auto hll", W, k))
+        dH.release()
+        dA.release()
+        S.csr_free(A)
