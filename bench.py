@@ -192,6 +192,8 @@ def main():
                 if labels[kernel] == "tile_panels":
                     mat.build_panels(0)
     kname = prefix + labels[kernel]
+    pinfo = mat.panels_info() if labels[kernel] == "tile_panels" else None
+    launches_per_step = pinfo["steps"] if pinfo else 1
     alg_bytes = mat.algorithmic_bytes  # per launch, per GPU
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -274,6 +276,7 @@ def main():
             "kernel": kname,
             "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
             if tuned is not None else "fixed by --kernel",
+            "kernel_launches_per_step": launches_per_step,
             "rows_per_gpu": Mloc, "nnz_per_row": K, "nnz_global": nnz_global,
             "stored_slots_per_gpu": slots,
             "partition": "contiguous row ranges, x replicated, in-place "

@@ -41,7 +41,7 @@ extern "C" {
 #define SPMV_NUM_CSR_KERNELS 5
 
 /* Wavefronts (64 lanes) per workgroup for subsequent one-shot calls;
- * valid 1..16, default 4.  (reference: set_csr_warps_per_block) */
+ * valid 1..16, default 8.  (reference: set_csr_warps_per_block) */
 void set_csr_waves_per_block(int waves);
 
 double csr_spmv_hip_thread_row(const sparse_csr *A, const double *x, double *y,

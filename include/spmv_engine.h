@@ -97,6 +97,10 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          double *d_y, int row_begin, int row_end,
                          void *stream);
 int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols);
+/* geometry of the blocked copy: kernel launches per SpMV (steps), row
+ * tiles, column panels, entries kept; -ENOENT when it is not built */
+int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
+                         int *panels, int64_t *entries);
 int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ);
 int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A);
 /* download the device arrays into a host CSR (tests; generated matrices) */
@@ -123,6 +127,8 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                            void *stream);
 /* HLL source: slots whose value is exactly 0.0 (all pads) are dropped */
 int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols);
+int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
+                         int *panels, int64_t *entries);
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major);
 int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H);

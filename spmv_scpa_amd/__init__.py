@@ -190,6 +190,10 @@ _sig("spmv_csr_launch", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
 _sig("spmv_csr_launch_rows", C.c_int, C.c_void_p, C.c_int,
      C.POINTER(LaunchOpts), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
      C.c_void_p)
+_sig("spmv_csr_panels_info", C.c_int, C.c_void_p, _ip, _ip, _ip,
+     C.POINTER(C.c_int64))
+_sig("spmv_hll_panels_info", C.c_int, C.c_void_p, _ip, _ip, _ip,
+     C.POINTER(C.c_int64))
 _sig("spmv_csr_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -587,6 +591,14 @@ class CsrDevice:
         _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
                "spmv_csr_build_panels")
 
+    def panels_info(self):
+        """-> dict(steps, tiles, panels, entries) or None when not built"""
+        a, b, c, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        rc = _lib.spmv_csr_panels_info(self.h, C.byref(a), C.byref(b),
+                                       C.byref(c), C.byref(n))
+        return None if rc else dict(steps=a.value, tiles=b.value,
+                                    panels=c.value, entries=n.value)
+
     def autotune(self, d_x, d_y, allow_panels=True):
         """-> (kernel id, median ms) of the fastest kernel for this matrix"""
         k, ms = C.c_int(), C.c_double()
@@ -640,6 +652,14 @@ class HllDevice:
     def build_panels(self, panel_cols=0):
         _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
                "spmv_hll_build_panels")
+
+    def panels_info(self):
+        """-> dict(steps, tiles, panels, entries) or None when not built"""
+        a, b, c, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        rc = _lib.spmv_hll_panels_info(self.h, C.byref(a), C.byref(b),
+                                       C.byref(c), C.byref(n))
+        return None if rc else dict(steps=a.value, tiles=b.value,
+                                    panels=c.value, entries=n.value)
 
     def autotune(self, d_x, d_y, allow_panels=True):
         """-> (kernel id, median ms) of the fastest kernel for this matrix"""

@@ -31,6 +31,38 @@ template <typename T> __device__ __forceinline__ T ld_stream(const T *p) {
     return __builtin_nontemporal_load(p);
 }
 
+/*
+ * Segmented reduction inside a wavefront: sum over groups of G consecutive
+ * lanes, result in the first lane of each group (what a __shfl_down(width G)
+ * tree gives).  Offsets 8,4,2,1 stay inside a 16-lane DPP row and run on the
+ * VALU as row_shl moves (no LDS-crossbar ds_bpermute); only the 16- and
+ * 32-lane steps use __shfl_down.
+ */
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi =
+        __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(
+        double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+template <int G> __device__ __forceinline__ double group_sum(double v) {
+    if (G >= 64)
+        v += __shfl_down(v, 32, 64);
+    if (G >= 32)
+        v += __shfl_down(v, 16, G >= 64 ? 64 : 32);
+    if (G >= 16)
+        v += dpp_f64<0x108>(v); /* row_shl:8 */
+    if (G >= 8)
+        v += dpp_f64<0x104>(v); /* row_shl:4 */
+    if (G >= 4)
+        v += dpp_f64<0x102>(v); /* row_shl:2 */
+    if (G >= 2)
+        v += dpp_f64<0x101>(v); /* row_shl:1 */
+    return v;
+}
+
 /* ------------------------------------------------------------------ */
 __global__ void k_csr_thread_row(int r0, int r1, const int *__restrict__ irp,
                                  const int *__restrict__ ja,
@@ -62,9 +94,7 @@ __global__ void k_csr_wave_row(int r0, int r1, const int *__restrict__ irp,
     const int beg = irp[row], end = irp[row + 1];
     for (int k = beg + lane; k < end; k += WAVE)
         acc += ld_stream(as + k) * x[ld_stream(ja + k)];
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1)
-        acc += __shfl_down(acc, d, WAVE);
+    acc = group_sum<WAVE>(acc);
     if (lane == 0)
         y[row] = acc;
 }
@@ -83,7 +113,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
  * G lanes per row, P rows per lane group: a wavefront owns P*(64/G)
  * consecutive rows.  The P passes are independent, so their IRP, JA/AS and x
  * loads are all in flight together (P x 768 B of stream per wavefront
- * instead of 768 B): the kernel is latency-bound otherwise.
+ * instead of 768 B): the kernel is latency-bound otherwise (1 pass 1.30 ms,
+ * 4 passes 0.83 ms, 8 passes 0.79 ms on banded 10M x 32).
  */
 template <int G, int P, bool REMAP>
 __global__ void k_csr_subwave_row(int r0, int r1,
@@ -126,9 +157,7 @@ __global__ void k_csr_subwave_row(int r0, int r1,
             acc[p] += ld_stream(as + k) * x[ld_stream(ja + k)];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-#pragma unroll
-        for (int d = G / 2; d > 0; d >>= 1)
-            acc[p] += __shfl_down(acc[p], d, G);
+        acc[p] = group_sum<G>(acc[p]);
         const long long row = rbase + p * RPP;
         if (sub == 0 && row < r1)
             y[row] = acc[p];
@@ -261,11 +290,10 @@ static int pick_group(const spmv_csr_dev *A, int group) {
     return g;
 }
 
-template <int G>
-static void launch_subwave(int r0, int r1, int threads, bool remap,
-                           const spmv_csr_dev *A, const double *x, double *y,
-                           hipStream_t s) {
-    constexpr int P = 4;
+template <int G, int P>
+static void launch_subwave_p(int r0, int r1, int threads, bool remap,
+                             const spmv_csr_dev *A, const double *x, double *y,
+                             hipStream_t s) {
     const int rows_per_wave = P * (WAVE / G);
     long long waves = ((long long)(r1 - r0) + rows_per_wave - 1) / rows_per_wave;
     long long wpb = threads / WAVE;
@@ -280,10 +308,30 @@ static void launch_subwave(int r0, int r1, int threads, bool remap,
                            x, y);
 }
 
+static int g_subwave_passes = 8; /* tuning knob (variant bits 2-3) */
+
+template <int G>
+static void launch_subwave(int r0, int r1, int threads, bool remap,
+                           const spmv_csr_dev *A, const double *x, double *y,
+                           hipStream_t s) {
+    switch (g_subwave_passes) {
+    case 2:
+        launch_subwave_p<G, 2>(r0, r1, threads, remap, A, x, y, s);
+        break;
+    case 4:
+        launch_subwave_p<G, 4>(r0, r1, threads, remap, A, x, y, s);
+        break;
+    default: /* 8 passes: 0.79 ms vs 0.83 ms (4) on banded 10M x 32 */
+        launch_subwave_p<G, 8>(r0, r1, threads, remap, A, x, y, s);
+        break;
+    }
+}
+
 int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                       int variant, const double *x, double *y, int r0, int r1,
                       hipStream_t s) {
     const bool remap = !(variant & 1);
+    g_subwave_passes = (variant & 4) ? 4 : (variant & 8) ? 2 : 8;
     if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
         return -EINVAL;
     if (r0 == r1)

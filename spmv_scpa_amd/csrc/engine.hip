@@ -19,8 +19,8 @@
 #include "hip_hll.h"
 #include "spmv_synth.h"
 
-int g_csr_waves = 4;
-int g_hll_waves = 4;
+int g_csr_waves = 8; /* 512-lane workgroups measured best on MI355X */
+int g_hll_waves = 8;
 
 extern "C" {
 
@@ -409,6 +409,31 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
     panels_free(H->panels);
     H->panels = NULL;
     return panels_from_hll(H, panel_cols, &H->panels);
+}
+
+static int panels_info(const spmv_panels *P, int *steps, int *tiles,
+                       int *panels, int64_t *entries) {
+    if (!P)
+        return -ENOENT; /* not built */
+    if (steps)
+        *steps = panels_steps(P);
+    if (tiles)
+        *tiles = panels_tiles(P);
+    if (panels)
+        *panels = panels_count(P);
+    if (entries)
+        *entries = panels_nnz(P);
+    return 0;
+}
+
+int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
+                         int *panels, int64_t *entries) {
+    return A ? panels_info(A->panels, steps, tiles, panels, entries) : -EINVAL;
+}
+
+int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
+                         int *panels, int64_t *entries) {
+    return H ? panels_info(H->panels, steps, tiles, panels, entries) : -EINVAL;
 }
 
 int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,

@@ -110,6 +110,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
 void panels_free(spmv_panels *p);
 int64_t panels_nnz(const spmv_panels *P);
 int panels_count(const spmv_panels *P);
+int panels_steps(const spmv_panels *P);
+int panels_tiles(const spmv_panels *P);
 
 extern int g_csr_waves; /* process defaults behind set_*_waves_per_block */
 extern int g_hll_waves;

@@ -546,3 +546,5 @@ int panels_from_hll(const spmv_hll_dev *H, int panel_cols, spmv_panels **out) {
 
 int64_t panels_nnz(const spmv_panels *P) { return P ? P->nnz : 0; }
 int panels_count(const spmv_panels *P) { return P ? P->panels : 0; }
+int panels_steps(const spmv_panels *P) { return P ? P->max_nbk : 0; }
+int panels_tiles(const spmv_panels *P) { return P ? P->tiles : 0; }
