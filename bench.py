@@ -53,6 +53,10 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=1,
                     help="N>1: split each shard into row chunks and overlap "
                          "the all-gather of chunk c with the kernel of c+1")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="initialise RCCL and run the y exchange even with "
+                         "one rank (exercises the multi-GPU path on a "
+                         "1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
@@ -143,8 +147,12 @@ def main():
     torch.cuda.set_device(local_rank)
     S.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_exchange
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     Mloc, K = args.rows_per_gpu, args.nnz_row
@@ -200,7 +208,8 @@ def main():
 
     chunks = 1 if labels[kernel] == "tile_panels" else args.chunks
     sharded = D.ShardedSpmv(mat, kernel, rank, world, Mloc, x, y,
-                            waves_per_block=args.waves, chunks=chunks)
+                            waves_per_block=args.waves, chunks=chunks,
+                            force_exchange=args.force_exchange)
 
     # ---- correctness spot check against the counter-based definition ----
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -223,21 +232,21 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True),
            torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         sharded.step(events=ev[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in ev]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
@@ -247,7 +256,7 @@ def main():
     achieved = alg_bytes / (kavg * 1e6)  # GB/s, this rank's kernel
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -308,7 +317,7 @@ def main():
         out["extras"] = D.extra_measurements(S, torch, mat, args, x, y, Mloc,
                                              Nglob, K, kind)
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

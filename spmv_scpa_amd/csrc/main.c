@@ -236,6 +236,33 @@ static void run_gpu(void) {
                          hll_num_slots(H_row), spmv_hll_algorithmic_bytes(dH),
                          median_of(ms, opt.iters));
     }
+    /* measured kernel choice; the 2-D blocked path is built only if the
+     * coalesced kernels run far below the stream rate */
+    if (!rc) {
+        int best = -1;
+        double best_ms = 0.0;
+        rc = spmv_csr_autotune(dA, d_x, d_y, 1, &best, &best_ms);
+        if (!rc) {
+            LOG_INFO("CSR autotune: kernel %d, %.4f ms, %.1f GFLOP/s", best,
+                     best_ms, compute_gflops64(best_ms, A->NZ));
+            if (best == SPMV_CSR_KERNEL_PANELS)
+                log_roofline(A->name, "CSR", best, 8, 1, A->M, A->N, A->NZ,
+                             A->NZ, spmv_csr_algorithmic_bytes(dA), best_ms);
+        }
+    }
+    if (!rc) {
+        int best = -1;
+        double best_ms = 0.0;
+        rc = spmv_hll_autotune(dHc, d_x, d_y, 1, &best, &best_ms);
+        if (!rc) {
+            LOG_INFO("HLL autotune: kernel %d, %.4f ms, %.1f GFLOP/s", best,
+                     best_ms, compute_gflops64(best_ms, A->NZ));
+            if (best == SPMV_HLL_KERNEL_PANELS)
+                log_roofline(A->name, "HLL", best, 8, 1, A->M, A->N, A->NZ,
+                             hll_num_slots(H_col),
+                             spmv_hll_algorithmic_bytes(dHc), best_ms);
+        }
+    }
     spmv_hll_release(dHc);
     spmv_hll_release(dHr);
     spmv_csr_release(dA);

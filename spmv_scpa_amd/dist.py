@@ -61,9 +61,9 @@ class ShardExchange:
         assert y.numel() == rows_per_rank * world
         self.mine = y[rank * rows_per_rank:(rank + 1) * rows_per_rank]
 
-    def gather_all(self):
+    def gather_all(self, force=False):
         """whole fragments, in place"""
-        if self.world == 1:
+        if self.world == 1 and not force:
             return None
         if self.mode == "allgather":
             return self.dist.all_gather_into_tensor(self.y, self.mine,
@@ -108,7 +108,8 @@ class ShardedSpmv:
     """
 
     def __init__(self, mat, kernel, rank, world, rows_per_rank, x, y,
-                 waves_per_block=0, chunks=1, mode=None, compute=None):
+                 waves_per_block=0, chunks=1, mode=None, compute=None,
+                 force_exchange=False):
         import torch
         self.torch = torch
         self.mat, self.kernel = mat, kernel
@@ -122,6 +123,7 @@ class ShardedSpmv:
         self.ex = ShardExchange(y, rank, world, rows_per_rank, mode)
         self.compute = compute or self._launch
         self.is_hll = hasattr(mat, "num_blocks")
+        self.force_exchange = force_exchange
 
     # product compute: the HIP kernel on torch's current stream
     def _launch(self, a, b):
@@ -143,7 +145,7 @@ class ShardedSpmv:
         recorded around the kernel launches on the current stream."""
         if events:
             events[0].record()
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             self.compute(0, self.rows)
             if events:
                 events[1].record()
@@ -159,7 +161,7 @@ class ShardedSpmv:
             # far (the kernel of this chunk) and run on the communicator's
             # own stream: the next chunk's kernel overlaps with them
             if nb == 1:
-                pending.append(self.ex.gather_all())
+                pending.append(self.ex.gather_all(self.force_exchange))
             else:
                 pending.append(self.ex.send_chunk(a, b))
         for w in pending:

@@ -1,0 +1,32 @@
+"""The multi-GPU code path on a 1-GPU box: bench.py launched through
+torch.distributed.run with one rank and --force-exchange initialises RCCL
+(backend "nccl"), runs the partition logic and the in-place all-gather of y
+(a world of one), and must still pass its own parity spot check."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import spmv_scpa_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [[], ["--chunks", "4"]])
+def test_bench_through_torchrun_one_rank(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(S.ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu",
+           "320000", "--window", "4096", "--kernel", "2", "--force-exchange",
+           "--no-cpu-baseline", "--no-extras"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "GFLOP/s"
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["frac"] > 0
