@@ -39,3 +39,30 @@ def test_reference_driver_runs_on_mi355x_kernels(name, tmp_path):
         f = line.split(",")
         assert f[0] == name and f[1] in ("CSR", "HLL")
         assert float(f[-2]) > 0.0  # a real kernel time, not an error code
+
+
+PRODUCT_DRIVER = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
+
+
+def test_product_driver_full_grid_on_gpu(tmp_path):
+    """This repo's own driver (same flags and CSV files as the reference's):
+    CPU grid + 27-row one-shot GPU grid with -d validation + resident timing
+    with roofline.csv + measured kernel choice."""
+    out = str(tmp_path)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    for args in (["-m", G.mtx_path("ragged100")],
+                 ["-s", "random", "--rows", "300000", "--nnz-row", "32",
+                  "--window", "100000"]):
+        r = subprocess.run([PRODUCT_DRIVER] + args + ["-o", out, "-d",
+                                                      "--iters", "5"],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "autotune" in r.stdout
+    gpu = open(os.path.join(out, "cuda.csv")).read().splitlines()
+    assert len(gpu) == 1 + 2 * 27
+    roof = open(os.path.join(out, "roofline.csv")).read().splitlines()
+    assert roof[0].startswith("matrix,format,kernel,waves_per_block,gpus,")
+    assert len(roof) >= 1 + 2 * 9
+    for line in roof[1:]:
+        f = line.split(",")
+        assert float(f[-4]) > 0 and 0 < float(f[-1]) < 1.0
