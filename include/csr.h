@@ -52,9 +52,20 @@ static inline void init_csr(sparse_csr *A, const char *name, int M, int N,
  *  - more than INT_MAX stored entries -> -EOVERFLOW (the reference
  *    silently truncates, csr.c:153).
  * Single pass over an in-memory image of the file (the reference parses the
- * text twice with fscanf).  Returns ERR_PTR(code) on failure, never NULL.
+ * text twice with fscanf); files of >= 100k entries whose tokens are all
+ * plain numbers are tokenised and converted by all OpenMP threads.
+ * Returns ERR_PTR(code) on failure, never NULL.
  */
 sparse_csr *io_load_csr(const char *path);
+
+/*
+ * Binary sidecar of a loaded matrix (new): header + the three
+ * CSR arrays.  io_load_csr_cached(path) reads "<path>.bin" when it is at
+ * least as new as the text file, else parses the text and writes it.
+ */
+int csr_save_bin(const sparse_csr *A, const char *path);
+sparse_csr *csr_load_bin(const char *path);
+sparse_csr *io_load_csr_cached(const char *path);
 
 /* basename without a trailing ".mtx", at most MAX_NAME-1 chars. */
 void extract_matrix_name(const char *path, char *name_out);

@@ -126,6 +126,9 @@ def _ptr_or_raise(p, what):
 # ---------------------------------------------------------------- host API
 _sig("io_load_csr", _CSRp, C.c_char_p)
 _sig("csr_free", None, _CSRp)
+_sig("csr_save_bin", C.c_int, _CSRp, C.c_char_p)
+_sig("csr_load_bin", _CSRp, C.c_char_p)
+_sig("io_load_csr_cached", _CSRp, C.c_char_p)
 _sig("csr_alloc", _CSRp, C.c_char_p, C.c_int, C.c_int, C.c_int)
 _sig("csr_generate", _CSRp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
      C.c_int64, C.c_uint64)
@@ -297,6 +300,19 @@ _keepalive = {}
 
 def io_load_csr(path):
     return _ptr_or_raise(_lib.io_load_csr(os.fsencode(path)), "io_load_csr")
+
+
+def io_load_csr_cached(path):
+    return _ptr_or_raise(_lib.io_load_csr_cached(os.fsencode(path)),
+                         "io_load_csr_cached")
+
+
+def csr_save_bin(A, path):
+    _check(_lib.csr_save_bin(A, os.fsencode(path)), "csr_save_bin")
+
+
+def csr_load_bin(path):
+    return _ptr_or_raise(_lib.csr_load_bin(os.fsencode(path)), "csr_load_bin")
 
 
 def csr_free(A):

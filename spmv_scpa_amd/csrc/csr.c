@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include "csr.h"
 #include "err.h"
@@ -156,6 +157,98 @@ static int read_whole_file(const char *path, char **buf, size_t *len) {
     return 0;
 }
 
+/*
+ * Parallel parse of the entry list: the text is cut into one piece per
+ * thread at token boundaries, tokens are counted, then every thread converts
+ * its own tokens (token g belongs to entry g / fields, field g % fields).
+ * Only "clean" files take this path -- every token is consumed entirely by
+ * its field's parser.  Anything else (a token like "1-2" that fscanf would
+ * split, garbage, ...) makes the function return 0 and the caller runs the
+ * sequential scanner, whose behaviour is the reference's by construction.
+ * Returns 1 when it parsed `*complete` whole entries (<= nz0).
+ */
+static int parse_entries_parallel(const char *text, size_t off, size_t len,
+                                  int nz0, int pattern, int *ei, int *ej,
+                                  double *ev, int *complete) {
+    int T = omp_get_max_threads();
+    if (T > 64)
+        T = 64;
+    if (T < 2 || nz0 < 100000)
+        return 0;
+    const int fields = pattern ? 2 : 3;
+    size_t start[65];
+    long long ntok[65], first[66];
+    for (int t = 0; t <= T; ++t) {
+        size_t s = off + (len - off) / (size_t)T * (size_t)t;
+        if (t == T)
+            s = len;
+        else if (t > 0) /* a token belongs to the piece it starts in */
+            while (s < len && !is_space((unsigned char)text[s]) &&
+                   !is_space((unsigned char)text[s - 1]))
+                ++s;
+        start[t] = s;
+    }
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; ++t) {
+        long long n = 0;
+        int in = 0;
+        for (size_t k = start[t]; k < start[t + 1]; ++k) {
+            int sp = is_space((unsigned char)text[k]);
+            n += (!sp && !in);
+            in = !sp;
+        }
+        ntok[t] = n;
+    }
+    first[0] = 0;
+    for (int t = 0; t < T; ++t)
+        first[t + 1] = first[t] + ntok[t];
+    long long whole = first[T] / fields;
+    if (whole > nz0)
+        whole = nz0;
+    const long long need = whole * fields;
+    int dirty = 0;
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(| : dirty)
+    for (int t = 0; t < T; ++t) {
+        long long g = first[t];
+        size_t k = start[t];
+        const size_t kend = start[t + 1];
+        while (k < kend && g < need && !dirty) {
+            while (k < kend && is_space((unsigned char)text[k]))
+                ++k;
+            if (k >= kend)
+                break;
+            size_t e = k;
+            while (e < len && !is_space((unsigned char)text[e]))
+                ++e;
+            const long long ent = g / fields;
+            const int f = (int)(g % fields);
+            const char *p = text + k;
+            if (f < 2) {
+                int v;
+                if (!scan_int(&p, text + e, &v) || p != text + e)
+                    dirty = 1;
+                else if (f == 0)
+                    ei[ent] = v;
+                else
+                    ej[ent] = v;
+            } else {
+                char *stop;
+                double v = strtod(p, &stop);
+                if (stop != text + e)
+                    dirty = 1;
+                else
+                    ev[ent] = v;
+            }
+            ++g;
+            k = e;
+        }
+    }
+    if (dirty)
+        return 0;
+    *complete = (int)whole;
+    return 1;
+}
+
 sparse_csr *io_load_csr(const char *path) {
     char *text = NULL;
     size_t len = 0;
@@ -188,33 +281,44 @@ sparse_csr *io_load_csr(const char *path) {
         goto done;
     }
 
-    /* single scan: parse, validate, count per row (file order kept) */
-    const char *p = text + mm.data_offset, *end = text + len;
-    long long stored = 0;
-    for (int e = 0; e < nz0; ++e) {
-        int i, j;
-        double v = 1.0;
-        if (!scan_int(&p, end, &i) || !scan_int(&p, end, &j) ||
-            (!pattern && !scan_double(&p, end, &v))) {
-            rc = -EIO; /* csr.c:71-79 */
-            goto done;
+    /* parse (file order kept).  Large clean files are tokenised in parallel;
+     * everything else goes through the sequential scanner. */
+    int parsed = 0; /* whole entries converted so far */
+    int fast = parse_entries_parallel(text, mm.data_offset, len, nz0, pattern,
+                                      ei, ej, ev, &parsed);
+    if (!fast) {
+        const char *p = text + mm.data_offset, *end = text + len;
+        for (parsed = 0; parsed < nz0; ++parsed) {
+            int i, j;
+            double v = 1.0;
+            if (!scan_int(&p, end, &i) || !scan_int(&p, end, &j) ||
+                (!pattern && !scan_double(&p, end, &v)))
+                break; /* -EIO below, unless an earlier entry is out of range */
+            ei[parsed] = i;
+            ej[parsed] = j;
+            if (!pattern)
+                ev[parsed] = v;
         }
-        --i;
-        --j;
+    }
+    /* validate and count per row, in entry order: the first bad entry
+     * decides the code, as in the reference's first pass (csr.c:68-95) */
+    long long stored = 0;
+    for (int e = 0; e < parsed; ++e) {
+        const int i = --ei[e], j = --ej[e];
         if (i < 0 || i >= M || j < 0 || j >= N) {
             rc = -ERANGE; /* csr.c:84-87 */
             goto done;
         }
-        ei[e] = i;
-        ej[e] = j;
-        if (!pattern)
-            ev[e] = v;
         fill[i]++;
         stored++;
         if (mirror && i != j) {
             fill[j]++;
             stored++;
         }
+    }
+    if (parsed < nz0) {
+        rc = -EIO; /* csr.c:71-79: short or unparsable entry */
+        goto done;
     }
     if (stored > INT_MAX) {
         rc = -EOVERFLOW;
@@ -256,6 +360,94 @@ done:
         csr_free(A);
         return ERR_PTR(rc);
     }
+    return A;
+}
+
+/* ------------------------------------------------------------------ */
+/* binary sidecar: the three CSR arrays behind a small header           */
+/* ------------------------------------------------------------------ */
+
+#define CSR_BIN_MAGIC 0x31525343564d5053ull /* "SPMVCSR1" */
+
+struct csr_bin_header {
+    uint64_t magic;
+    int32_t M, N, NZ, pad;
+    char name[MAX_NAME];
+};
+
+int csr_save_bin(const sparse_csr *A, const char *path) {
+    if (IS_ERR_OR_NULL(A) || !path)
+        return -EINVAL;
+    FILE *f = fopen(path, "wb");
+    if (!f)
+        return -errno;
+    struct csr_bin_header h;
+    memset(&h, 0, sizeof h);
+    h.magic = CSR_BIN_MAGIC;
+    h.M = A->M;
+    h.N = A->N;
+    h.NZ = A->NZ;
+    memcpy(h.name, A->name, MAX_NAME);
+    int ok = fwrite(&h, sizeof h, 1, f) == 1 &&
+             fwrite(A->IRP, sizeof(int), (size_t)A->M + 1, f) == (size_t)A->M + 1 &&
+             fwrite(A->JA, sizeof(int), (size_t)A->NZ, f) == (size_t)A->NZ &&
+             fwrite(A->AS, sizeof(double), (size_t)A->NZ, f) == (size_t)A->NZ;
+    if (fclose(f) != 0)
+        ok = 0;
+    return ok ? 0 : -EIO;
+}
+
+sparse_csr *csr_load_bin(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return ERR_PTR(-errno);
+    struct csr_bin_header h;
+    sparse_csr *A = NULL;
+    int rc = 0;
+    if (fread(&h, sizeof h, 1, f) != 1 || h.magic != CSR_BIN_MAGIC ||
+        h.M < 0 || h.N < 0 || h.NZ < 0) {
+        rc = -EINVAL;
+        goto out;
+    }
+    h.name[MAX_NAME - 1] = '\0';
+    A = csr_alloc(h.name, h.M, h.N, h.NZ);
+    if (IS_ERR(A)) {
+        rc = PTR_ERR(A);
+        A = NULL;
+        goto out;
+    }
+    if (fread(A->IRP, sizeof(int), (size_t)h.M + 1, f) != (size_t)h.M + 1 ||
+        fread(A->JA, sizeof(int), (size_t)h.NZ, f) != (size_t)h.NZ ||
+        fread(A->AS, sizeof(double), (size_t)h.NZ, f) != (size_t)h.NZ ||
+        A->IRP[0] != 0 || A->IRP[h.M] != h.NZ)
+        rc = -EIO;
+out:
+    fclose(f);
+    if (rc) {
+        csr_free(A);
+        return ERR_PTR(rc);
+    }
+    return A;
+}
+
+/* "<path>.bin" next to the text file: read it when it is at least as new as
+ * the .mtx, otherwise parse the text and (best effort) write the sidecar */
+sparse_csr *io_load_csr_cached(const char *path) {
+    char bin[MAX_PATH * 4];
+    struct stat st_txt, st_bin;
+    if (snprintf(bin, sizeof bin, "%s.bin", path) >= (int)sizeof bin)
+        return io_load_csr(path);
+    if (stat(path, &st_txt) == 0 && stat(bin, &st_bin) == 0 &&
+        st_bin.st_mtime >= st_txt.st_mtime) {
+        sparse_csr *A = csr_load_bin(bin);
+        if (!IS_ERR(A)) {
+            extract_matrix_name(path, A->name);
+            return A;
+        }
+    }
+    sparse_csr *A = io_load_csr(path);
+    if (!IS_ERR(A))
+        (void)csr_save_bin(A, bin);
     return A;
 }
 

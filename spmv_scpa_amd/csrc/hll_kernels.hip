@@ -110,7 +110,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return x * q + (x < r ? x : r) + k;
 }
 
-template <int U, bool REMAP>
+template <int U, bool REMAP, int ABL = 0> /* ABL 1: all gathers read x[0] */
 __global__ void k_hll_col_direct(int M, int b0, int b1,
                                  const int64_t *__restrict__ off,
                                  const int *__restrict__ ja,
@@ -145,7 +145,7 @@ __global__ void k_hll_col_direct(int M, int b0, int b1,
         double xv[U], av[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            xv[u] = x[cJ[u]];
+            xv[u] = (ABL & 1) ? x[cJ[u] & 1] : x[cJ[u]];
             av[u] = cA[u];
         }
         if (c + 1 < nfull) {
@@ -351,6 +351,27 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         break;
     }
     case 2:
+        if (variant & 32) { /* tuning: 4 columns per pipeline stage */
+            hipLaunchKernelGGL((k_hll_col_direct<4, true>),
+                               dim3((unsigned)((lanes + threads - 1) / threads)),
+                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+                               H->ja, H->as, x, y);
+            break;
+        }
+        if (variant & 64) { /* tuning: 16 columns per pipeline stage */
+            hipLaunchKernelGGL((k_hll_col_direct<16, true>),
+                               dim3((unsigned)((lanes + threads - 1) / threads)),
+                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+                               H->ja, H->as, x, y);
+            break;
+        }
+        if (variant & 16) {
+            hipLaunchKernelGGL((k_hll_col_direct<8, true, 1>),
+                               dim3((unsigned)((lanes + threads - 1) / threads)),
+                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+                               H->ja, H->as, x, y);
+            break;
+        }
         if (remap)
             hipLaunchKernelGGL((k_hll_col_direct<8, true>),
                                dim3((unsigned)((lanes + threads - 1) / threads)),

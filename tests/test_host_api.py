@@ -278,3 +278,85 @@ def test_driver_cli_cpu_path(tmp_path):
                         "8", "--window", "256", "-o", out, "-d", "--iters", "1"],
                        capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stderr
+
+
+def _write_big_mtx(path, M, N, nnz, sym=False, pattern=False, seed=3):
+    rng = np.random.default_rng(seed)
+    i = rng.integers(1, M + 1, nnz)
+    j = rng.integers(1, N + 1, nnz)
+    if sym:
+        i, j = np.maximum(i, j), np.minimum(i, j)
+    v = rng.standard_normal(nnz)
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s %s\n%% big\n%d %d %d\n"
+                % ("pattern" if pattern else "real",
+                   "symmetric" if sym else "general", M, N, nnz))
+        if pattern:
+            np.savetxt(f, np.c_[i, j], fmt="%d %d")
+        else:
+            for a, b, c in zip(i, j, v):
+                f.write("%d %d %s\n" % (a, b, repr(float(c))))
+
+
+@pytest.mark.parametrize("sym,pattern", [(False, False), (True, False),
+                                         (False, True)])
+def test_parallel_loader_equals_oracle(tmp_path, sym, pattern):
+    """>= 100k clean entries take the multi-threaded tokeniser; the result
+    must equal the oracle's two-pass fscanf restatement bit for bit."""
+    p = str(tmp_path / "big.mtx")
+    _write_big_mtx(p, 5000, 5000, 150_000, sym, pattern)
+    rc, M, N, NZ, IRP, JA, AS = O.load_mtx(p)
+    assert rc == 0
+    A = S.io_load_csr(p)
+    gI, gJ, gA = S.csr_arrays(A)
+    assert A.contents.NZ == NZ
+    assert np.array_equal(gI, IRP) and np.array_equal(gJ, JA)
+    assert np.array_equal(bits(gA), bits(AS))
+    # binary sidecar round trip + cached loader
+    S.csr_save_bin(A, p + ".bin")
+    B = S.csr_load_bin(p + ".bin")
+    bI, bJ, bA = S.csr_arrays(B)
+    assert np.array_equal(bI, IRP) and np.array_equal(bJ, JA)
+    assert np.array_equal(bits(bA), bits(AS))
+    Cc = S.io_load_csr_cached(p)
+    assert Cc.contents.name == b"big" and Cc.contents.NZ == NZ
+    with open(p + ".bin", "r+b") as f:  # corrupt the magic: falls back to text
+        f.write(b"XXXXXXXX")
+    os.utime(p + ".bin")
+    D = S.io_load_csr_cached(p)
+    assert D.contents.NZ == NZ
+    with pytest.raises(OSError):
+        S.csr_load_bin(str(tmp_path / "missing.bin"))
+    for h in (A, B, Cc, D):
+        S.csr_free(h)
+
+
+def test_parallel_loader_falls_back_on_unclean_tokens(tmp_path):
+    """Tokens fscanf would split ("7-3"), a short file and an out-of-range
+    entry late in a big file: same errno / arrays as the oracle."""
+    p = str(tmp_path / "odd.mtx")
+    _write_big_mtx(p, 4000, 4000, 120_000)
+    lines = open(p).read().splitlines()
+    for name, edit, want in (
+            ("split", lambda L: L[:60_000] + ["7-3 0.5"] + L[60_001:], None),
+            ("short", lambda L: L[:-5], -errno.EIO),
+            ("range", lambda L: L[:100_000] + ["4001 1 1.0"] + L[100_001:],
+             -errno.ERANGE),
+            ("garbage", lambda L: L[:90_000] + ["1 x 2.0"] + L[90_001:],
+             -errno.EIO)):
+        q = str(tmp_path / (name + ".mtx"))
+        open(q, "w").write("\n".join(edit(lines)) + "\n")
+        rc = O.load_mtx(q)[0]
+        if want is not None:
+            assert rc == want, name
+        if rc == 0:
+            A = S.io_load_csr(q)
+            _, _, _, _, IRP, JA, AS = O.load_mtx(q)
+            gI, gJ, gA = S.csr_arrays(A)
+            assert np.array_equal(gI, IRP) and np.array_equal(gJ, JA)
+            assert np.array_equal(bits(gA), bits(AS))
+            S.csr_free(A)
+        else:
+            with pytest.raises(OSError) as ei:
+                S.io_load_csr(q)
+            assert ei.value.errno == -rc, (name, ei.value.errno, rc)
