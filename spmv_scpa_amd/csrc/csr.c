@@ -124,6 +124,9 @@ static int read_whole_file(const char *path, char **buf, size_t *len) {
     if (!f)
         return -errno;
     size_t cap = 1 << 16, n = 0;
+    struct stat st; /* size the buffer once when the size is known */
+    if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0)
+        cap = (size_t)st.st_size + 1;
     char *b = malloc(cap + 1);
     if (!b) {
         fclose(f);
