@@ -50,9 +50,10 @@ def parse_args():
     ap.add_argument("--kernel", type=int, default=-1,
                     help="kernel id (hip_hll.h / hip_csr.h); -1 = default")
     ap.add_argument("--waves", type=int, default=0)
-    ap.add_argument("--chunks", type=int, default=1,
+    ap.add_argument("--chunks", type=int, default=0,
                     help="N>1: split each shard into row chunks and overlap "
-                         "the all-gather of chunk c with the kernel of c+1")
+                         "the all-gather of chunk c with the kernel of c+1 "
+                         "(0 = auto: 4 when N > 1, else 1)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise RCCL and run the y exchange even with "
                          "one rank (exercises the multi-GPU path on a "
@@ -206,7 +207,9 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    chunks = 1 if labels[kernel] == "tile_panels" else args.chunks
+    chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
+    if labels[kernel] == "tile_panels":
+        chunks = 1  # the blocked path runs whole shards only
     sharded = D.ShardedSpmv(mat, kernel, rank, world, Mloc, x, y,
                             waves_per_block=args.waves, chunks=chunks,
                             force_exchange=args.force_exchange)
@@ -290,7 +293,7 @@ def main():
             "stored_slots_per_gpu": slots,
             "partition": "contiguous row ranges, x replicated, in-place "
                          "all-gather(y) over RCCL" if world > 1 else "single GPU",
-            "chunks": chunks,
+            "chunks": chunks, "exchange": sharded.mode,
         },
         "roofline": {
             "bound": "hbm",

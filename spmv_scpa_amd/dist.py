@@ -10,6 +10,12 @@ iterative method).
 
 Exchange modes
   "allgather"  one in-place all_gather_into_tensor (ncclAllGather) per step.
+  "staged"     the shard is cut into k equal row chunks; chunk c of every
+               rank is written into a chunk-major staging buffer
+               stage[c][rank][:] and all-gathered in place (one
+               ncclAllGather per chunk, on RCCL's stream) while the kernel of
+               chunk c+1 runs; a final strided copy puts y back into row
+               order.  Only collectives, no point-to-point.
   "p2p"        the shard is cut into row chunks; as soon as the kernel of
                chunk c has finished, chunk c is sent to every peer with
                grouped isend/irecv (ncclSend/ncclRecv inside one group,
@@ -99,6 +105,35 @@ def wait_all(work):
         work.wait()
 
 
+class StagedExchange:
+    """Chunk-major staging for overlapped all-gathers (mode "staged")."""
+
+    def __init__(self, y, rank, world, rows_per_rank, chunks, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.y, self.rank, self.world = y, rank, world
+        self.rows, self.k = rows_per_rank, chunks
+        assert rows_per_rank % chunks == 0
+        self.ch = rows_per_rank // chunks
+        self.stage = torch.empty(chunks, world, self.ch, dtype=y.dtype,
+                                 device=y.device)
+
+    def out(self, c):
+        """where this rank's kernel writes chunk c"""
+        return self.stage[c, self.rank]
+
+    def gather(self, c):
+        return self.dist.all_gather_into_tensor(
+            self.stage[c].view(-1), self.stage[c, self.rank],
+            group=self.group, async_op=True)
+
+    def finish(self):
+        """stage[c][r][:] -> y[r*rows + c*ch : ...] (row order)"""
+        self.y.view(self.world, self.k, self.ch).copy_(
+            self.stage.transpose(0, 1))
+
+
 class ShardedSpmv:
     """One rank's part of y = A x over `world` GPUs.
 
@@ -119,17 +154,30 @@ class ShardedSpmv:
         self.row0 = rank * rows_per_rank
         self.bounds = chunk_bounds(rows_per_rank, chunks)
         if mode is None:
-            mode = "allgather" if len(self.bounds) <= 2 else "p2p"
-        self.ex = ShardExchange(y, rank, world, rows_per_rank, mode)
+            mode = "allgather" if len(self.bounds) <= 2 else "staged"
+        if mode == "staged":
+            k = len(self.bounds) - 1
+            ch = rows_per_rank // max(k, 1)
+            if (k < 2 or rows_per_rank % k or ch % HACK
+                    or self.bounds != [ch * i for i in range(k + 1)]):
+                mode, self.bounds = "allgather", [0, rows_per_rank]
+        self.mode = mode
+        self.staged = (StagedExchange(y, rank, world, rows_per_rank,
+                                      len(self.bounds) - 1)
+                       if mode == "staged" else None)
+        self.ex = ShardExchange(y, rank, world, rows_per_rank,
+                                "p2p" if mode == "p2p" else "allgather")
         self.compute = compute or self._launch
         self.is_hll = hasattr(mat, "num_blocks")
         self.force_exchange = force_exchange
 
-    # product compute: the HIP kernel on torch's current stream
-    def _launch(self, a, b):
+    # product compute: the HIP kernel on torch's current stream; rows [a, b)
+    # go to y (row order) or, when `out` is given, to out[0 : b-a]
+    def _launch(self, a, b, out=None):
         st = self.torch.cuda.current_stream().cuda_stream
         d_x = self.x.data_ptr()
-        d_y = self.y.data_ptr() + 8 * self.row0
+        d_y = (self.y.data_ptr() + 8 * self.row0 if out is None
+               else out.data_ptr() - 8 * a)
         if a == 0 and b == self.rows:
             self.mat.launch(self.kernel, d_x, d_y,
                             waves_per_block=self.waves, stream=st)
@@ -152,6 +200,17 @@ class ShardedSpmv:
             return
         pending = []
         nb = len(self.bounds) - 1
+        if self.staged is not None:
+            for c in range(nb):
+                self.compute(self.bounds[c], self.bounds[c + 1],
+                             self.staged.out(c))
+                if c == nb - 1 and events:
+                    events[1].record()
+                pending.append(self.staged.gather(c))
+            for w in pending:
+                wait_all(w)
+            self.staged.finish()
+            return
         for c in range(nb):
             a, b = self.bounds[c], self.bounds[c + 1]
             self.compute(a, b)

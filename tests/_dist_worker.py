@@ -32,12 +32,16 @@ def main():
     x = torch.from_numpy(O.synth_x(7, 0, N))
     y = torch.full((M,), float("nan"), dtype=torch.float64)
 
-    def compute(a, b):
+    def compute(a, b, out=None):
         sub = IRP[a:b + 1] - IRP[a]
         lo, hi = IRP[a], IRP[b]
-        y[row0 + a:row0 + b] = torch.from_numpy(
+        res = torch.from_numpy(
             O.csr_spmv(np.ascontiguousarray(sub), JA[lo:hi], AS[lo:hi],
                        x.numpy()))
+        if out is None:
+            y[row0 + a:row0 + b] = res
+        else:
+            out.copy_(res)
 
     sh = D.ShardedSpmv(None, 0, rank, world, rows_per_rank, x, y,
                        chunks=chunks, mode=mode, compute=compute)

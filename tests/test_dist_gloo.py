@@ -48,7 +48,10 @@ def run_world(world, mode, chunks, rows):
 @pytest.mark.parametrize("world,mode,chunks", [(2, "allgather", 1),
                                                (2, "p2p", 1),
                                                (2, "p2p", 4),
-                                               (3, "p2p", 3)])
+                                               (3, "p2p", 3),
+                                               (2, "staged", 4),
+                                               (3, "staged", 5),
+                                               (2, "staged", 3)])
 def test_sharded_spmv_gloo(world, mode, chunks):
     run_world(world, mode, chunks, rows=640)
 
