@@ -1,0 +1,54 @@
+/*
+ * spmv_mgpu.h -- single-process multi-GPU SpMV over the GPUs of one node:
+ * contiguous row ranges (boundaries multiples of HACK_SIZE), x replicated,
+ * every device computes its fragment of y, fragments exchanged with one
+ * grouped in-place ncclAllGather (RCCL over xGMI).  The reference has no
+ * multi-GPU path; this is what `spmv_scpa_amd -g N` runs.  (bench.py does
+ * the same with one process per GPU through torch.distributed.)
+ *
+ * All functions return 0 or a negative errno (-ENODEV: fewer GPUs than
+ * asked for).
+ */
+#ifndef SPMV_MGPU_H
+#define SPMV_MGPU_H
+
+#include <stdint.h>
+
+#include "csr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmv_mgpu spmv_mgpu;
+
+/* devices 0..ngpus-1, one RCCL communicator (ncclCommInitAll), one stream each */
+int spmv_mgpu_create(int ngpus, spmv_mgpu **out);
+void spmv_mgpu_destroy(spmv_mgpu *g);
+
+/* shard a host matrix by rows; as_hll != 0: col-major HLL shards (kernel 1/2) */
+int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll);
+/* weak scaling: every device generates rows_per_gpu (multiple of 32) rows of
+ * the (rows_per_gpu*ngpus)-square synthetic matrix (spmv_synth.h) */
+int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
+                       int64_t W, uint64_t seed, int as_hll);
+
+int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host); /* N doubles */
+int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed);       /* synth_x on device */
+
+/* warmup + iters steps of (local kernels, all-gather of y); ms_each[iters]
+ * = wall time per step, all devices synchronised on both sides.
+ * kernel < 0: default of the shard format. */
+int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
+                   double *ms_each);
+
+/* the gathered y as device `rank` holds it (M doubles, row order) */
+int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host);
+
+int spmv_mgpu_info(const spmv_mgpu *g, int *ngpus, int *rows_per_gpu,
+                   int64_t *nnz_total, int64_t *bytes_per_gpu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_MGPU_H */

@@ -744,3 +744,66 @@ def vec_synth(n, seed=7, first=0):
 def compute_gflops(ms, nnz):
     """2*nnz / (ms*1e6), 0 for ms <= 0 (reference utils.h:70-75)."""
     return (2.0 * nnz) / (ms * 1e6) if ms > 0.0 else 0.0
+
+
+# ---------------------------------------------------------------- multi-GPU (C)
+_sig("spmv_mgpu_create", C.c_int, C.c_int, C.POINTER(C.c_void_p))
+_sig("spmv_mgpu_destroy", None, C.c_void_p)
+_sig("spmv_mgpu_load_csr", C.c_int, C.c_void_p, _CSRp, C.c_int)
+_sig("spmv_mgpu_generate", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+     C.c_int64, C.c_uint64, C.c_int)
+_sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
+_sig("spmv_mgpu_fill_x", C.c_int, C.c_void_p, C.c_uint64)
+_sig("spmv_mgpu_spmv", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp)
+_sig("spmv_mgpu_get_y", C.c_int, C.c_void_p, C.c_int, _dp)
+_sig("spmv_mgpu_info", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64),
+     C.POINTER(C.c_int64))
+
+
+class MultiGpu:
+    """Single-process multi-GPU SpMV (spmv_mgpu.h): row shards + RCCL
+    all-gather of y, as the C driver's `-g N` runs it."""
+
+    h = None
+
+    def __init__(self, ngpus):
+        h = C.c_void_p()
+        _check(_lib.spmv_mgpu_create(ngpus, C.byref(h)), "spmv_mgpu_create")
+        self.h, self.n = h, ngpus
+
+    def load_csr(self, A, as_hll=False):
+        _check(_lib.spmv_mgpu_load_csr(self.h, A, int(as_hll)),
+               "spmv_mgpu_load_csr")
+        self.M = A.contents.M
+
+    def generate(self, kind, rows_per_gpu, K, W, seed=42, as_hll=True):
+        _check(_lib.spmv_mgpu_generate(self.h, kind, rows_per_gpu, K, W, seed,
+                                       int(as_hll)), "spmv_mgpu_generate")
+        self.M = rows_per_gpu * self.n
+
+    def set_x(self, x):
+        x, xp = _as_d(x)
+        _check(_lib.spmv_mgpu_set_x(self.h, xp), "spmv_mgpu_set_x")
+
+    def fill_x(self, seed=7):
+        _check(_lib.spmv_mgpu_fill_x(self.h, seed), "spmv_mgpu_fill_x")
+
+    def spmv(self, kernel=-1, warmup=1, iters=3):
+        ms = np.zeros(max(iters, 1))
+        _check(_lib.spmv_mgpu_spmv(self.h, kernel, warmup, iters,
+                                   ms.ctypes.data_as(_dp)), "spmv_mgpu_spmv")
+        return ms[:iters]
+
+    def get_y(self, rank=0):
+        y = np.zeros(self.M)
+        _check(_lib.spmv_mgpu_get_y(self.h, rank, y.ctypes.data_as(_dp)),
+               "spmv_mgpu_get_y")
+        return y
+
+    def destroy(self):
+        if self.h:
+            _lib.spmv_mgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.destroy()

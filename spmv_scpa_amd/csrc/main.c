@@ -26,15 +26,16 @@
 #include "hll.h"
 #include "logger.h"
 #include "spmv_engine.h"
+#include "spmv_mgpu.h"
 #include "spmv_synth.h"
 #include "utils.h"
 
 static struct {
     const char *matrix, *out_dir, *synthetic;
-    int rows, nnz_row, iters, cpu;
+    int rows, nnz_row, iters, cpu, gpus;
     long long window;
     bool debug;
-} opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 0, false};
+} opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, false};
 
 static sparse_csr *A;
 static sparse_hll *H_row, *H_col;
@@ -273,6 +274,59 @@ static void run_gpu(void) {
         die("resident GPU timing failed", rc);
 }
 
+/*
+ * -g N: the matrix is cut into N contiguous row ranges (multiples of 32
+ * rows), one per GPU; a step = every shard's kernel + an RCCL all-gather of
+ * the y fragments.  Rows go to roofline.csv with gpus = N.
+ */
+static void run_multi_gpu(void) {
+    spmv_mgpu *g = NULL;
+    int rc = spmv_mgpu_create(opt.gpus, &g);
+    if (rc)
+        die("multi-GPU setup (RCCL communicator)", rc);
+    double *ms = malloc((size_t)(opt.iters > 0 ? opt.iters : 1) * sizeof *ms);
+    for (int fmt = 0; fmt < 2 && !rc; ++fmt) { /* 0: CSR, 1: HLL */
+        if (fmt == 1) { /* fresh communicator and shards per format */
+            spmv_mgpu_destroy(g);
+            g = NULL;
+            rc = spmv_mgpu_create(opt.gpus, &g);
+            if (rc)
+                break;
+        }
+        rc = spmv_mgpu_load_csr(g, A, fmt);
+        if (!rc)
+            rc = spmv_mgpu_set_x(g, x.data);
+        if (!rc)
+            rc = spmv_mgpu_spmv(g, -1, 3, opt.iters > 0 ? opt.iters : 1, ms);
+        if (rc)
+            break;
+        if (opt.debug) { /* every device must hold the whole, correct y */
+            vec y = vec_create((size_t)A->M);
+            if (!y.data)
+                die("y allocation", -ENOMEM);
+            for (int r = 0; r < opt.gpus; ++r) {
+                rc = spmv_mgpu_get_y(g, r, y.data);
+                if (rc)
+                    break;
+                check(fmt ? "multi-GPU HLL" : "multi-GPU CSR", y);
+            }
+            vec_put(&y);
+        }
+        int64_t nz = 0, bytes = 0;
+        spmv_mgpu_info(g, NULL, NULL, &nz, &bytes);
+        double med = median_of(ms, opt.iters > 0 ? opt.iters : 1);
+        log_roofline(A->name, fmt ? "HLL" : "CSR", fmt ? 1 : 2, 8, opt.gpus,
+                     A->M, A->N, nz, nz, bytes * opt.gpus, med);
+        LOG_INFO("%d GPU(s) %s: %.4f ms per step (kernel + all-gather), "
+                 "%.1f GFLOP/s", opt.gpus, fmt ? "HLL" : "CSR", med,
+                 compute_gflops64(med, nz));
+    }
+    free(ms);
+    spmv_mgpu_destroy(g);
+    if (rc)
+        die("multi-GPU run failed", rc);
+}
+
 static int synth_kind(const char *s) {
     static const char *names[] = {"banded", "random", "ragged", "kkt"};
     for (int k = 0; k < 4; ++k)
@@ -290,12 +344,13 @@ int main(int argc, char **argv) {
         {"nnz-row", required_argument, NULL, 'K'},
         {"window", required_argument, NULL, 'W'},
         {"iters", required_argument, NULL, 'i'},
+        {"gpus", required_argument, NULL, 'g'},
         {"no-cpu", no_argument, NULL, 'C'},
         {"debug", no_argument, NULL, 'd'},
         {"help", no_argument, NULL, 'h'},
         {NULL, 0, NULL, 0}};
     int c;
-    while ((c = getopt_long(argc, argv, "m:o:s:i:dh", longopts, NULL)) != -1) {
+    while ((c = getopt_long(argc, argv, "m:o:s:i:g:dh", longopts, NULL)) != -1) {
         switch (c) {
         case 'm': opt.matrix = optarg; break;
         case 'o': opt.out_dir = optarg; break;
@@ -304,6 +359,7 @@ int main(int argc, char **argv) {
         case 'K': opt.nnz_row = atoi(optarg); break;
         case 'W': opt.window = atoll(optarg); break;
         case 'i': opt.iters = atoi(optarg); break;
+        case 'g': opt.gpus = atoi(optarg); break;
         case 'C': opt.cpu = 0; break;
         case 'd': opt.debug = true; break;
         case 'h':
@@ -355,9 +411,11 @@ int main(int argc, char **argv) {
         run_serial();
     if (opt.cpu)
         run_omp();
-    if (spmv_device_count() > 0)
+    if (spmv_device_count() > 0) {
         run_gpu();
-    else
+        if (opt.gpus >= 1 && (opt.gpus > 1 || getenv("SPMV_FORCE_MGPU")))
+            run_multi_gpu();
+    } else
         LOG_WARN("no GPU visible: GPU benchmarks skipped (no CPU fallback)");
 
     cleanup();

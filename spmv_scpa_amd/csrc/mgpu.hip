@@ -1,0 +1,291 @@
+/*
+ * mgpu.hip -- single-process multi-GPU SpMV for the C driver: row-range
+ * partition over the GPUs of one node + RCCL all-gather of the y fragments
+ * over xGMI (API: include/spmv_mgpu.h).  New; the reference is single-GPU.
+ *
+ * One host thread drives all devices: per device a stream, a shard handle
+ * (CSR or col-major HLL of the local rows with GLOBAL column indices), the
+ * full-length x and the full-length y.  A step launches every shard's kernel
+ * (asynchronous), then one grouped in-place ncclAllGather
+ * (sendbuff = y + rank*rows) so every device ends with the whole y.
+ * bench.py does the same with one process per GPU through torch.distributed;
+ * this is the path of `spmv_scpa_amd -g N`.
+ */
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <vector>
+
+#include "err.h"
+#include "hip_common.h"
+#include "spmv_mgpu.h"
+
+struct spmv_mgpu {
+    int n;
+    int rows_per_gpu; /* equal shards, multiple of 32 (last one padded) */
+    int M, N;         /* global shape */
+    int is_hll;
+    std::vector<int> dev;
+    std::vector<hipStream_t> stream;
+    std::vector<ncclComm_t> comm;
+    std::vector<spmv_csr_dev *> csr;
+    std::vector<spmv_hll_dev *> hll;
+    std::vector<double *> x, y;
+};
+
+static int nccl_errno(ncclResult_t r) {
+    return r == ncclSuccess ? 0 : (r == ncclSystemError ? -EIO : -EINVAL);
+}
+
+#define NCCL_TRY(call)                                                        \
+    do {                                                                      \
+        ncclResult_t r_ = (call);                                             \
+        if (r_ != ncclSuccess) {                                              \
+            rc = nccl_errno(r_);                                              \
+            goto fail;                                                        \
+        }                                                                     \
+    } while (0)
+
+extern "C" {
+
+void spmv_mgpu_destroy(spmv_mgpu *g) {
+    if (!g)
+        return;
+    for (int r = 0; r < g->n; ++r) {
+        (void)hipSetDevice(g->dev[r]);
+        if (g->csr[r])
+            spmv_csr_release(g->csr[r]);
+        if (g->hll[r])
+            spmv_hll_release(g->hll[r]);
+        (void)hipFree(g->x[r]);
+        (void)hipFree(g->y[r]);
+        if (g->comm[r])
+            ncclCommDestroy(g->comm[r]);
+        if (g->stream[r])
+            (void)hipStreamDestroy(g->stream[r]);
+    }
+    delete g;
+}
+
+int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
+    if (!out || ngpus < 1)
+        return -EINVAL;
+    *out = NULL;
+    if (spmv_device_count() < ngpus)
+        return -ENODEV;
+    int rc = 0;
+    spmv_mgpu *g = new spmv_mgpu();
+    g->n = ngpus;
+    g->rows_per_gpu = g->M = g->N = g->is_hll = 0;
+    g->dev.resize(ngpus);
+    g->stream.assign(ngpus, NULL);
+    g->comm.assign(ngpus, NULL);
+    g->csr.assign(ngpus, NULL);
+    g->hll.assign(ngpus, NULL);
+    g->x.assign(ngpus, NULL);
+    g->y.assign(ngpus, NULL);
+    for (int r = 0; r < ngpus; ++r)
+        g->dev[r] = r;
+    NCCL_TRY(ncclCommInitAll(g->comm.data(), ngpus, g->dev.data()));
+    for (int r = 0; r < ngpus; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipStreamCreate(&g->stream[r]));
+    }
+    *out = g;
+    return 0;
+fail:
+    spmv_mgpu_destroy(g);
+    return rc;
+}
+
+static int alloc_vectors(spmv_mgpu *g) {
+    int rc = 0;
+    const size_t ny = (size_t)g->rows_per_gpu * g->n; /* padded length */
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipMalloc((void **)&g->x[r],
+                          (size_t)(g->N > 0 ? g->N : 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&g->y[r], (ny ? ny : 1) * sizeof(double)));
+        HIP_TRY(hipMemset(g->y[r], 0, (ny ? ny : 1) * sizeof(double)));
+    }
+fail:
+    return rc;
+}
+
+/* shard a host matrix: contiguous row ranges, boundaries multiples of 32 */
+int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
+    if (!g || !A)
+        return -EINVAL;
+    int *starts = partition_rows_even(A->M, g->n, HACK_SIZE);
+    if (IS_ERR(starts))
+        return PTR_ERR(starts);
+    int rc = 0;
+    g->M = A->M;
+    g->N = A->N;
+    g->is_hll = as_hll != 0;
+    g->rows_per_gpu = g->n > 0 ? starts[1] - starts[0] : 0;
+    if (g->n == 1)
+        g->rows_per_gpu = A->M;
+    for (int r = 0; r < g->n && !rc; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        sparse_csr *S = csr_row_slice(A, starts[r], starts[r + 1]);
+        if (IS_ERR(S)) {
+            rc = PTR_ERR(S);
+            break;
+        }
+        rc = spmv_csr_upload(S, &g->csr[r]);
+        if (!rc && as_hll) {
+            rc = spmv_hll_from_csr(g->csr[r], 1, &g->hll[r]);
+            spmv_csr_release(g->csr[r]);
+            g->csr[r] = NULL;
+        }
+        csr_free(S);
+    }
+    if (!rc)
+        rc = alloc_vectors(g);
+fail:
+    free(starts);
+    return rc;
+}
+
+/* every device generates its own shard (spmv_synth.h), weak scaling */
+int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
+                       int64_t W, uint64_t seed, int as_hll) {
+    if (!g || rows_per_gpu < 0 || rows_per_gpu % HACK_SIZE)
+        return -EINVAL;
+    int rc = 0;
+    g->rows_per_gpu = rows_per_gpu;
+    g->M = g->N = rows_per_gpu * g->n;
+    g->is_hll = as_hll != 0;
+    for (int r = 0; r < g->n && !rc; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        rc = spmv_csr_generate(kind, rows_per_gpu, g->N, K, W,
+                               (int64_t)r * rows_per_gpu, seed, &g->csr[r]);
+        if (!rc && as_hll) {
+            rc = spmv_hll_from_csr(g->csr[r], 1, &g->hll[r]);
+            spmv_csr_release(g->csr[r]);
+            g->csr[r] = NULL;
+        }
+    }
+    if (!rc)
+        rc = alloc_vectors(g);
+fail:
+    return rc;
+}
+
+int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host) {
+    if (!g || !x_host)
+        return -EINVAL;
+    int rc = 0;
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipMemcpy(g->x[r], x_host, (size_t)g->N * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+fail:
+    return rc;
+}
+
+int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed) {
+    if (!g)
+        return -EINVAL;
+    int rc = 0;
+    for (int r = 0; r < g->n && !rc; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        rc = spmv_dev_fill_synth(g->x[r], g->N, seed, 0, g->stream[r]);
+    }
+fail:
+    return rc;
+}
+
+static double wall_ms_now(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
+
+/*
+ * `iters` steps of (local kernels + all-gather of y); ms_each[i] = wall time
+ * of step i with every device synchronised on both sides (max over devices
+ * by construction).  kernel < 0: 2 (CSR sub-wave) or 1 (HLL col-major).
+ */
+int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
+                   double *ms_each) {
+    if (!g || iters < 0 || warmup < 0 || (iters && !ms_each))
+        return -EINVAL;
+    int rc = 0;
+    if (kernel < 0)
+        kernel = g->is_hll ? 1 : 2;
+    for (int it = -warmup; it < iters && !rc; ++it) {
+        for (int r = 0; r < g->n; ++r) {
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            HIP_TRY(hipStreamSynchronize(g->stream[r]));
+        }
+        const double t0 = wall_ms_now();
+        for (int r = 0; r < g->n && !rc; ++r) {
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            double *yfrag = g->y[r] + (size_t)r * g->rows_per_gpu;
+            rc = g->is_hll
+                     ? spmv_hll_launch(g->hll[r], kernel, NULL, g->x[r], yfrag,
+                                       g->stream[r])
+                     : spmv_csr_launch(g->csr[r], kernel, NULL, g->x[r], yfrag,
+                                       g->stream[r]);
+        }
+        if (rc)
+            break;
+        if (g->n > 1) {
+            NCCL_TRY(ncclGroupStart());
+            for (int r = 0; r < g->n; ++r)
+                ncclAllGather(g->y[r] + (size_t)r * g->rows_per_gpu, g->y[r],
+                              (size_t)g->rows_per_gpu, ncclDouble, g->comm[r],
+                              g->stream[r]);
+            NCCL_TRY(ncclGroupEnd());
+        }
+        for (int r = 0; r < g->n; ++r) {
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            HIP_TRY(hipStreamSynchronize(g->stream[r]));
+        }
+        if (it >= 0)
+            ms_each[it] = wall_ms_now() - t0;
+    }
+fail:
+    return rc;
+}
+
+/* the gathered y as device `rank` holds it (M doubles) */
+int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host) {
+    if (!g || rank < 0 || rank >= g->n || !y_host)
+        return -EINVAL;
+    HIP_RET(hipSetDevice(g->dev[rank]));
+    HIP_RET(hipMemcpy(y_host, g->y[rank], (size_t)g->M * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int spmv_mgpu_info(const spmv_mgpu *g, int *ngpus, int *rows_per_gpu,
+                   int64_t *nnz_total, int64_t *bytes_per_gpu) {
+    if (!g)
+        return -EINVAL;
+    int64_t nz = 0, by = 0;
+    for (int r = 0; r < g->n; ++r) {
+        if (g->hll[r]) {
+            nz += g->hll[r]->NZ;
+            by = spmv_hll_algorithmic_bytes(g->hll[r]);
+        } else if (g->csr[r]) {
+            nz += g->csr[r]->NZ;
+            by = spmv_csr_algorithmic_bytes(g->csr[r]);
+        }
+    }
+    if (ngpus)
+        *ngpus = g->n;
+    if (rows_per_gpu)
+        *rows_per_gpu = g->rows_per_gpu;
+    if (nnz_total)
+        *nnz_total = nz;
+    if (bytes_per_gpu)
+        *bytes_per_gpu = by;
+    return 0;
+}
+
+} /* extern "C" */

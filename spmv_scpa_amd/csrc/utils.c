@@ -51,7 +51,7 @@ void log_prog_usage(const char *prog) {
             "      --rows <M> --nnz-row <K> --window <W>   synthetic shape\n"
             "  -o, --out <dir>         directory for serial.csv omp.csv cuda.csv\n"
             "  -d, --debug             validate every result against serial CSR\n"
-            "  -g, --gpus <n>          GPUs to row-partition over (default 1)\n"
+            "  -g, --gpus <n>          row-partition over n GPUs + RCCL all-gather(y)\n"
             "  -i, --iters <n>         timed GPU launches per kernel (default 20)\n"
             "      --no-cpu            skip the serial / OpenMP benchmarks\n"
             "  -h, --help              show this message\n",

@@ -1,0 +1,62 @@
+"""Single-process multi-GPU API (spmv_mgpu.h: row shards + grouped
+ncclAllGather).  On the 1-GPU box it runs with a world of one device; with
+more devices visible it uses all of them."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _golden as G
+import _oracle as O
+import spmv_scpa_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("as_hll", [False, True])
+def test_mgpu_host_matrix_matches_oracle(as_hll):
+    n = min(S.device_count(), 8)
+    M = N = 100_003  # not a multiple of 32 x n: last shard padded
+    IRP, JA, AS = O.synth_csr(S.SYNTH_RAGGED, M, N, 24, 5000, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("mg", M, N, IRP, JA, AS)
+    g = S.MultiGpu(n)
+    g.load_csr(A, as_hll)
+    g.set_x(x)
+    ms = g.spmv(iters=3)
+    assert len(ms) == 3 and np.all(ms > 0)
+    for r in range(n):
+        y = g.get_y(r)
+        assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
+    g.destroy()
+    S.csr_free(A)
+
+
+def test_mgpu_generated_shards():
+    n = min(S.device_count(), 8)
+    rows = 64_000
+    g = S.MultiGpu(n)
+    g.generate(S.SYNTH_RANDOM, rows, 32, 4096, 42, as_hll=True)
+    g.fill_x(7)
+    g.spmv(iters=2)
+    y = g.get_y(n - 1)
+    M = rows * n
+    for grow in (0, 31, rows - 1, M - 1):
+        want, sc = O.synth_row_dot(S.SYNTH_RANDOM, M, M, 32, 4096, 0, 42, 7, grow)
+        assert abs(y[grow] - want) <= 1e-12 * sc
+    g.destroy()
+    with pytest.raises(OSError):
+        S.MultiGpu(S.device_count() + 1)
+
+
+def test_driver_multi_gpu_flag(tmp_path):
+    drv = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
+    env = dict(os.environ, OMP_NUM_THREADS="4", SPMV_FORCE_MGPU="1")
+    r = subprocess.run([drv, "-m", G.mtx_path("sym70"), "-o", str(tmp_path),
+                        "-d", "--iters", "3", "--no-cpu", "-g", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "all-gather" in r.stdout
