@@ -458,28 +458,52 @@ __global__ void __launch_bounds__(NT)
     const int64_t b = cb[((int64_t)t * panels + step) * 2];
     const int64_t e = cb[((int64_t)t * panels + step) * 2 + 1];
     const int64_t row0 = (int64_t)t * tile_rows;
+    /* first batch of entries and the y slice are fetched together (they are
+     * independent); the x gathers follow the barrier: issued before it they
+     * delay the slice, whose loads return in order behind them (measured
+     * 2.97 ms vs 2.6 ms) */
+    int c[UN];
+    unsigned short rl[UN];
+    double v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int64_t k = b + tid + (int64_t)u * NT;
+        const bool ok = k < e;
+        c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
+        rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
+        v[u] = ok ? __builtin_nontemporal_load(tval + k) : 0.0;
+    }
     for (int i = tid; i < tile_rows; i += NT)
         ytile[i] = (!(ABL & 1) && row0 + i < M) ? y[row0 + i] : 0.0;
     __syncthreads();
-    for (int64_t k0 = b + tid; k0 < e; k0 += NT * UN) {
-        int c[UN];
-        unsigned short rl[UN];
-        double v[UN], xv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t k = k0 + (int64_t)u * NT;
-            const bool ok = k < e;
-            c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
-            rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
-            v[u] = ok ? __builtin_nontemporal_load(tval + k) : 0.0;
-        }
+    for (int64_t k0 = b + tid; k0 < e; k0 += (int64_t)NT * UN) {
+        double xv[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u)
             xv[u] = c[u] >= 0 ? ((ABL & 2) ? x[c[u] & 1023] : x[c[u]]) : 0.0;
+        double pr[UN];
+        unsigned short rr[UN];
+        bool on[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            pr[u] = v[u] * xv[u];
+            rr[u] = rl[u];
+            on[u] = c[u] >= 0;
+        }
+        if (k0 + (int64_t)NT * UN < e) { /* next batch behind the gathers */
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t k = k0 + (int64_t)NT * UN + (int64_t)u * NT;
+                const bool ok = k < e;
+                c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
+                rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
+                v[u] = ok ? __builtin_nontemporal_load(tval + k) : 0.0;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
-            if (c[u] >= 0)
-                unsafeAtomicAdd(&ytile[rl[u]], v[u] * xv[u]);
+            if (on[u])
+                unsafeAtomicAdd(&ytile[rr[u]], pr[u]);
     }
     __syncthreads();
     if (ABL & 1) {
