@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
                  double *__restrict__ y) {
     __shared__ double prod[STREAM_NNZ];
     __shared__ double part[STREAM_THREADS / WAVE];
+    __shared__ int rowptr[STREAM_THREADS + 1]; /* this range's slice of IRP */
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int rb = blk0 + blockIdx.x;
@@ -237,7 +238,13 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     }
 
     /* phase 1: coalesced stream of the workgroup's entries -> products;
-     * all STREAM_NNZ/STREAM_THREADS loads of a lane are issued together */
+     * all STREAM_NNZ/STREAM_THREADS loads of a lane are issued together.
+     * The row offsets of the range go to LDS alongside, so phase 2 has no
+     * dependent global load left. */
+    if (tid < row_b - row_a) /* at most STREAM_THREADS rows per range */
+        rowptr[tid] = irp[row_a + tid] - beg;
+    if (tid == 0)
+        rowptr[row_b - row_a] = cnt;
     {
         constexpr int E = STREAM_NNZ / STREAM_THREADS;
         int c[E];
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
         double acc = 0.0;
         const bool live = r < rows;
         if (live) {
-            const int a = irp[row_a + r] - beg, b = irp[row_a + r + 1] - beg;
+            const int a = rowptr[r], b = rowptr[r + 1];
             for (int k = a + sub; k < b; k += g)
                 acc += prod[k];
         }
