@@ -372,3 +372,16 @@ def test_autotune_picks_a_valid_kernel_and_stays_correct():
         dH.release()
         dA.release()
         S.csr_free(A)
+
+
+def test_int32_limits_are_reported_not_wrapped():
+    """The host structs count entries in int (reference csr.h:9-10): a shard
+    with more than INT_MAX entries must be refused (-EOVERFLOW), not wrapped
+    (the reference truncates silently, csr.c:153)."""
+    import errno
+    with pytest.raises(OSError) as ei:
+        S.CsrDevice.generate(S.SYNTH_RANDOM, 70_000_000, 70_000_000, 32, 1 << 20)
+    assert ei.value.errno == errno.EOVERFLOW
+    with pytest.raises(OSError) as ei:
+        S.csr_generate(S.SYNTH_BANDED, 70_000_000, 70_000_000, 32, 0)
+    assert ei.value.errno == errno.EOVERFLOW
