@@ -66,6 +66,77 @@ __global__ void k_spmvmix(const int *__restrict__ ja, const double *__restrict__
         *sink = acc;
 }
 
+/* HLL-shaped stream: a wave owns two consecutive 32x32 blocks (col-major):
+ * per step a half-wave reads 128 B of JA and 256 B of AS, 32 steps, U loads
+ * in flight.  PAIRS consecutive block pairs per wave. */
+template <int U, int PAIRS>
+__global__ void k_hllshape(const int *__restrict__ ja, const double *__restrict__ as,
+                           size_t nblocks, double *sink) {
+    size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    int lane = threadIdx.x & 63, half = lane >> 5, i = lane & 31;
+    double acc = 0;
+    for (int pr = 0; pr < PAIRS; ++pr) {
+        size_t b = (wave * PAIRS + pr) * 2 + half;
+        if (b >= nblocks) break;
+        const int *cj = ja + b * 1024 + i;
+        const double *ca = as + b * 1024 + i;
+        for (int j = 0; j < 32; j += U) {
+            int c[U]; double a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c[u] = __builtin_nontemporal_load(cj + (j + u) * 32);
+                a[u] = __builtin_nontemporal_load(ca + (j + u) * 32);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += a[u] * c[u];
+        }
+    }
+    if (acc == 1.2345e300) *sink = acc;
+}
+
+/* the same plus, one at a time, what the real kernel adds: F bit 0 = block
+ * offsets from an off[] array, bit 1 = y store, bit 2 = dependent x gather
+ * (x[c & 1023], L1 resident), bit 3 = two-stage software pipeline */
+template <int U, int F>
+__global__ void k_hllshape2(const int64_t *__restrict__ off, const int *__restrict__ ja,
+                            const double *__restrict__ as, const double *__restrict__ x,
+                            double *__restrict__ y, size_t nblocks, double *sink) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = t / 32;
+    int i = (int)(t % 32);
+    if (b >= nblocks) return;
+    size_t o = (F & 1) ? (size_t)off[b] : b * 1024;
+    const int *cj = ja + o + i;
+    const double *ca = as + o + i;
+    double acc = 0;
+    if (F & 8) {
+        int c[U]; double a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c[u] = __builtin_nontemporal_load(cj + u * 32); a[u] = __builtin_nontemporal_load(ca + u * 32); }
+        for (int j = 0; j < 32; j += U) {
+            double xv[U], av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xv[u] = (F & 4) ? x[c[u] & 1023] : (double)c[u]; av[u] = a[u]; }
+            if (j + U < 32) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { c[u] = __builtin_nontemporal_load(cj + (j + U + u) * 32); a[u] = __builtin_nontemporal_load(ca + (j + U + u) * 32); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += av[u] * xv[u];
+        }
+    } else {
+        for (int j = 0; j < 32; j += U) {
+            int c[U]; double a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { c[u] = __builtin_nontemporal_load(cj + (j + u) * 32); a[u] = __builtin_nontemporal_load(ca + (j + u) * 32); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += a[u] * ((F & 4) ? x[c[u] & 1023] : (double)c[u]);
+        }
+    }
+    if (F & 2) y[b * 32 + i] = acc;
+    else if (acc == 1.2345e300) *sink = acc;
+}
+
 __device__ __forceinline__ uint64_t mix(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -219,6 +290,35 @@ int main() {
             t = time_ms([&] { k_spmvmix<true><<<g, 256>>>(ja, as, n, dsink); });
             printf("  nt %8.1f\n", 12.0 * n / t * 1e-6);
         }
+    }
+    printf("== hll-shaped stream (no gather), 300M slots, nt loads GB/s\n");
+    {
+        size_t nblocks = 300000000 / 1024;
+        int *ja = (int *)buf; double *as = (double *)((char *)buf + ((size_t)3 << 29));
+        double bytes_h = 12.0 * nblocks * 1024;
+#define HS(U, PAIRS, THREADS) { size_t waves = (nblocks / 2 + PAIRS - 1) / PAIRS; \
+        unsigned g = (unsigned)((waves * 64 + THREADS - 1) / THREADS); \
+        double t = time_ms([&] { k_hllshape<U, PAIRS><<<g, THREADS>>>(ja, as, nblocks, dsink); }); \
+        printf("U=%2d pairs/wave=%d threads=%4d : %8.1f GB/s\n", U, PAIRS, THREADS, bytes_h / t * 1e-6); }
+        HS(4, 1, 256) HS(8, 1, 256) HS(8, 1, 512) HS(16, 1, 256) HS(32, 1, 256)
+        HS(8, 2, 256) HS(8, 4, 256) HS(8, 8, 256) HS(32, 4, 256)
+    }
+    printf("== hll-shaped stream + one feature at a time (U=8, 256 threads)\n");
+    {
+        size_t nblocks = 300000000 / 1024;
+        int *ja = (int *)buf; double *as = (double *)((char *)buf + ((size_t)3 << 29));
+        int64_t *off; CK(hipMalloc((void **)&off, (nblocks + 1) * 8));
+        { std::vector<int64_t> h(nblocks + 1); for (size_t k = 0; k <= nblocks; ++k) h[k] = (int64_t)k * 1024;
+          CK(hipMemcpy(off, h.data(), (nblocks + 1) * 8, hipMemcpyHostToDevice)); }
+        double *xx, *yy; CK(hipMalloc((void **)&xx, 8 * 1024 * 8)); CK(hipMemset(xx, 0, 8 * 1024 * 8));
+        CK(hipMalloc((void **)&yy, nblocks * 32 * 8));
+        CK(hipMemset(buf, 0, (size_t)3 << 29)); /* ja = 0: gathers stay in range */
+        double bytes_h = 12.0 * nblocks * 1024;
+        unsigned g = (unsigned)((nblocks * 32 + 255) / 256);
+#define HF(F) { double t = time_ms([&] { k_hllshape2<8, F><<<g, 256>>>(off, ja, as, xx, yy, nblocks, dsink); }); \
+        printf("features %2d (off=%d ystore=%d gather=%d pipelined=%d): %8.1f GB/s\n", F, F & 1, (F >> 1) & 1, (F >> 2) & 1, (F >> 3) & 1, bytes_h / t * 1e-6); }
+        HF(0) HF(1) HF(2) HF(3) HF(4) HF(7) HF(8) HF(12) HF(15)
+        CK(hipMemset(buf, 1, (size_t)3 << 29));
     }
     printf("== gather: 32 random fp64 gathers per lane, 10M lanes (320M gathers)\n");
     printf("   needed for config 3 at 60%% roofline: 384 Ggather/s\n");
