@@ -45,7 +45,7 @@ def parse_args():
                     help="column window W of the random family; 0 = N "
                          "(columns anywhere: the worst case)")
     ap.add_argument("--family", default="random",
-                    choices=["banded", "random", "ragged", "kkt"])
+                    choices=["banded", "random", "ragged", "kkt", "stencil"])
     ap.add_argument("--format", default="hll", choices=["hll", "csr"])
     ap.add_argument("--kernel", type=int, default=-1,
                     help="kernel id (hip_hll.h / hip_csr.h); -1 = default")
@@ -68,7 +68,8 @@ def cpu_baseline(family, K, W):
     built from /root/reference/src by oracle/build_ref.sh) on a bounded
     sample of the same workload; falls back to the oracle port."""
     rows = 2_000_000
-    kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3}[family]
+    kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3,
+            "stencil": 4}[family]
     host = os.cpu_count() or 1
     # the GPU box gives one GPU's share of the host (16 cores): time the
     # reference's ladder up to 32 threads and report the best
@@ -206,7 +207,8 @@ def main():
     Nglob = Mglob
     W = args.window if args.window > 0 else 2 * Nglob  # >= 2N: anywhere
     kind = {"banded": S.SYNTH_BANDED, "random": S.SYNTH_RANDOM,
-            "ragged": S.SYNTH_RAGGED, "kkt": S.SYNTH_KKT}[args.family]
+            "ragged": S.SYNTH_RAGGED, "kkt": S.SYNTH_KKT,
+            "stencil": S.SYNTH_STENCIL}[args.family]
     row0 = rank * Mloc
 
     # ---- build the shard in HBM (device-side generator + converter) ----

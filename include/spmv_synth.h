@@ -20,7 +20,13 @@
  *                 [K - K/4, K + K/4] (mean K): exercises HLL padding.
  *   SYNTH_KKT     irregular: most rows short (K/4..K/2), every 64th row a
  *                 long row of 8K entries, KKT-like arrow structure
- *                 (stand-in for nlpkkt160, config 4, which cannot be
+ *                 (row-length skew stress test).
+ *   SYNTH_STENCIL 3-D grid operator: row g = grid point (ix,iy,iz) of an
+ *                 nx x nx x nz grid (nx = W if W > 0, else cbrt(N)), coupled
+ *                 to its 27 neighbours (K > 7) or 7 neighbours (K <= 7)
+ *                 inside the grid: rows of 8..27 (4..7) entries, banded with
+ *                 three band groups -- the structure class of nlpkkt160 /
+ *                 FEM matrices (stand-in for config 4, which cannot be
  *                 downloaded here).
  * Values are uniform in [-1, 1); x is uniform in [0, 1).
  */
@@ -39,7 +45,8 @@ enum synth_kind {
     SYNTH_BANDED = 0,
     SYNTH_RANDOM = 1,
     SYNTH_RAGGED = 2,
-    SYNTH_KKT = 3
+    SYNTH_KKT = 3,
+    SYNTH_STENCIL = 4
 };
 
 typedef struct synth_spec {
@@ -73,9 +80,46 @@ SYNTH_FN double synth_x(uint64_t seed, int64_t idx) {
     return synth_u01(synth_hash2(seed, 0x78u, (uint64_t)idx));
 }
 
+/* grid edge of the stencil family: W if given, else floor(cbrt(N)) */
+SYNTH_FN int64_t synth_grid_nx(const synth_spec *s) {
+    if (s->W > 0)
+        return s->W;
+    int64_t n = 1;
+    while ((n + 1) * (n + 1) * (n + 1) <= (int64_t)s->N)
+        ++n;
+    return n;
+}
+
+/* neighbours of grid point g inside the grid and below N, ascending; returns
+ * the count, writes the columns when cols != 0 */
+SYNTH_FN int synth_stencil_cols(const synth_spec *s, int64_t g, int *cols) {
+    const int64_t nx = synth_grid_nx(s), nxy = nx * nx;
+    const int64_t ix = g % nx, iy = (g / nx) % nx, iz = g / nxy;
+    const int full = s->K > 7;
+    int n = 0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (!full && (dx != 0) + (dy != 0) + (dz != 0) > 1)
+                    continue;
+                const int64_t jx = ix + dx, jy = iy + dy, jz = iz + dz;
+                if (jx < 0 || jx >= nx || jy < 0 || jy >= nx || jz < 0)
+                    continue;
+                const int64_t c = jz * nxy + jy * nx + jx;
+                if (c >= (int64_t)s->N)
+                    continue;
+                if (cols)
+                    cols[n] = (int)c;
+                ++n;
+            }
+    return n;
+}
+
 /* number of entries of GLOBAL row g */
 SYNTH_FN int synth_row_len(const synth_spec *s, int64_t g) {
     switch (s->kind) {
+    case SYNTH_STENCIL:
+        return synth_stencil_cols(s, g, 0);
     case SYNTH_BANDED:
     case SYNTH_RANDOM:
         return s->K;
@@ -122,7 +166,9 @@ SYNTH_FN int synth_col_draw(const synth_spec *s, int64_t g, int t) {
  */
 SYNTH_FN void synth_fill_row(const synth_spec *s, int64_t g, int len,
                              int *cols, double *vals) {
-    if (s->kind == SYNTH_BANDED) {
+    if (s->kind == SYNTH_STENCIL) {
+        synth_stencil_cols(s, g, cols);
+    } else if (s->kind == SYNTH_BANDED) {
         int64_t st = g - s->K / 2;
         if (st > (int64_t)s->N - len)
             st = (int64_t)s->N - len;

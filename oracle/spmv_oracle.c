@@ -9,7 +9,7 @@
  * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
  * here bit-for-bit against outputs of the reference's own C code
  * (oracle/_ref/ref_strict, built from /root/reference/src by
- * oracle/build_ref.sh) stored under tests/golden/*.ref.txt.
+ * oracle/build_ref.sh) stored under tests/golden/ (the .ref.txt files).
  *
  * Plain C99 on flat arrays (ctypes-friendly).  Each function names the
  * reference lines it restates.  Strict IEEE: build without -ffast-math.

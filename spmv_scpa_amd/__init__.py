@@ -30,7 +30,7 @@ _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 
 MAX_NAME = 64
 HACK_SIZE = 32
-SYNTH_BANDED, SYNTH_RANDOM, SYNTH_RAGGED, SYNTH_KKT = 0, 1, 2, 3
+SYNTH_BANDED, SYNTH_RANDOM, SYNTH_RAGGED, SYNTH_KKT, SYNTH_STENCIL = 0, 1, 2, 3, 4
 NUM_CSR_KERNELS = 5
 NUM_HLL_KERNELS = 4
 #: extra kernel ids: the column-panel path (spmv_engine.h)

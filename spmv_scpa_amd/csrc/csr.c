@@ -460,7 +460,7 @@ sparse_csr *io_load_csr_cached(const char *path) {
 
 sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
                          int64_t row0, uint64_t seed) {
-    if (M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_KKT ||
+    if (M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_STENCIL ||
         (kind == SYNTH_BANDED && N < K))
         return ERR_PTR(-EINVAL);
     synth_spec s = {kind, M, N, K, W, row0, seed};
@@ -475,7 +475,8 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
     if (nz > INT_MAX)
         return ERR_PTR(-EOVERFLOW);
     static const char *names[] = {"synth_banded", "synth_random",
-                                  "synth_ragged", "synth_kkt"};
+                                  "synth_ragged", "synth_kkt",
+                                  "synth_stencil"};
     sparse_csr *A = csr_alloc(names[kind], M, N, (int)nz);
     if (IS_ERR(A))
         return A;

@@ -306,7 +306,7 @@ fail:
 int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
                       uint64_t seed, spmv_csr_dev **out) {
     if (!out || M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED ||
-        kind > SYNTH_KKT || (kind == SYNTH_BANDED && N < K))
+        kind > SYNTH_STENCIL || (kind == SYNTH_BANDED && N < K))
         return -EINVAL;
     *out = NULL;
     if (spmv_device_count() == 0)

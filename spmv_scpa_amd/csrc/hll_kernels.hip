@@ -164,7 +164,7 @@ __global__ void k_hll_col_direct(int M, int b0, int b1,
     for (int j = nfull * U; j < w; ++j)
         acc += ld_stream(ca + (size_t)j * rows) *
                x[ld_stream(cj + (size_t)j * rows)];
-    y[(int64_t)b * HACK + i] = acc;
+    __builtin_nontemporal_store(acc, y + (int64_t)b * HACK + i);
 }
 
 /* ------------------------------------------------------------------ */
@@ -270,7 +270,7 @@ __global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
         __builtin_amdgcn_wave_barrier();
     }
     if (half == 0 || hasB)
-        y[(int64_t)(bA + half) * HACK + i] = acc;
+        __builtin_nontemporal_store(acc, y + (int64_t)(bA + half) * HACK + i);
 }
 
 /* ------------------------------------------------------------------ */

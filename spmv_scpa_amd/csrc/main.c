@@ -328,8 +328,9 @@ static void run_multi_gpu(void) {
 }
 
 static int synth_kind(const char *s) {
-    static const char *names[] = {"banded", "random", "ragged", "kkt"};
-    for (int k = 0; k < 4; ++k)
+    static const char *names[] = {"banded", "random", "ragged", "kkt",
+                                  "stencil"};
+    for (int k = 0; k < 5; ++k)
         if (!strcmp(s, names[k]))
             return k;
     return -1;

@@ -302,13 +302,26 @@ def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
         dB.release()
     except OSError as e:
         out["error config2"] = str(e)
-    # config 4 stand-in: KKT-like irregular rows (nlpkkt160 itself cannot be
-    # downloaded here): 8.3M rows, short rows + one 128-entry row in 64
+    # config 4 stand-ins (nlpkkt160 itself cannot be downloaded here):
+    # (a) its structure class: 27-point operator on a 203^3 grid, 8.37M rows,
+    #     rows of 8..27 entries (ragged at the boundary), ~2.2e8 entries;
+    # (b) a row-length skew stress test: short rows + one 128-entry row in 64
     try:
+        n3 = 203 ** 3
+        dS = S.CsrDevice.generate(S.SYNTH_STENCIL, n3, n3, 27, 0, 0, 42)
+        for k in (1, 2, 4):
+            row("config4-like stencil27 203^3 csr_%s" % S.CSR_KERNEL_NAMES[k],
+                dS, med(dS.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        dSh = dS.to_hll(True)
+        for k in (1, 2):
+            row("config4-like stencil27 203^3 hll_%s" % S.HLL_KERNEL_NAMES[k],
+                dSh, med(dSh.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        dSh.release()
+        dS.release()
         dK = S.CsrDevice.generate(S.SYNTH_KKT, 8_345_600, Nglob, 16, 1 << 16,
                                   0, 42)
-        for k in (1, 2, 4):
-            row("config4-like kkt8.3M csr_%s" % S.CSR_KERNEL_NAMES[k], dK,
+        for k in (2, 4):
+            row("skewed-rows kkt8.3M csr_%s" % S.CSR_KERNEL_NAMES[k], dK,
                 med(dK.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
         dK.release()
     except OSError as e:

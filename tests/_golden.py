@@ -8,7 +8,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MTX_CASES = ["gen", "sym", "pat", "cage4_like", "tail40", "ragged100", "sym70",
              "skew", "herm", "patgen", "freeform"]
 SYNTH_CASES = ["synth_banded", "synth_random", "synth_random_wide",
-               "synth_ragged", "synth_kkt"]
+               "synth_ragged", "synth_kkt", "synth_stencil27",
+               "synth_stencil7"]
 
 _INT_KEYS = ("IRP", "JA", "shape", "hdr", "validate", "omp_nnz_threads",
              "error", "stride", "hll_bit_equal", "spec")

@@ -147,6 +147,8 @@ SYNTH = {
     "synth_random_wide": (1, 3000, 3000, 32, 6000, 42, 7, 3000),
     "synth_ragged": (2, 2077, 2500, 32, 256, 42, 7, 2077),
     "synth_kkt": (3, 3000, 3000, 16, 3000, 42, 7, 3000),
+    "synth_stencil27": (4, 3500, 3500, 27, 0, 42, 7, 3500),   # 15x15x16 grid, ragged top
+    "synth_stencil7": (4, 4096, 4096, 7, 16, 42, 7, 4096),
 }
 
 

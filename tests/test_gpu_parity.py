@@ -74,6 +74,8 @@ SYNTH_SMALL = [
     ("random_wide", S.SYNTH_RANDOM, 33_333, 32, 1 << 30),
     ("ragged", S.SYNTH_RAGGED, 20_011, 32, 4096),
     ("kkt", S.SYNTH_KKT, 30_000, 16, 30_000),
+    ("stencil27", S.SYNTH_STENCIL, 40_000, 27, 0),
+    ("stencil7", S.SYNTH_STENCIL, 33_000, 7, 30),
     ("one_row", S.SYNTH_RANDOM, 1, 32, 64),
     ("31_rows", S.SYNTH_RANDOM, 31, 5, 64),
     ("33_rows", S.SYNTH_RAGGED, 33, 8, 64),

@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--flush", type=int, default=0)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3}[a.family]
+    kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3,
+            "stencil": 4}[a.family]
     M = N = a.rows
     d_x = S.DevBuffer(N * 8)
     d_y = S.DevBuffer(M * 8)
@@ -42,7 +43,7 @@ def main():
     res = []
     ints = lambda s: [int(v) for v in s.split(",") if v != ""]
     for W in ints(a.windows):
-        Weff = W if W > 0 else 2 * N
+        Weff = W if (W > 0 or kind == 4) else 2 * N
         dA = S.CsrDevice.generate(kind, M, N, a.k, Weff, 0, 42)
         mats = {}
         for k in ints(a.hll_kernels):
