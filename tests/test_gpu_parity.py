@@ -281,8 +281,14 @@ def test_config3_random_hll_full_size_properties(W):
     want = np.array([O.synth_row_dot(S.SYNTH_RANDOM, M, N, K, W, 0, 42, 7,
                                      int(g)) for g in rows])
     ys = {}
+    dH.build_panels(0)  # the 2-D blocked path, bench.py's pick for W = N
+    info = dH.panels_info()
+    assert info["entries"] == M * K and info["tiles"] == (M + 1023) // 1024
+    assert info["steps"] == (info["panels"] if W >= N else info["steps"])
     for tag, fn in (("hll1", lambda: dH.launch(1, d_x.ptr, d_y.ptr)),
                     ("hll2", lambda: dH.launch(2, d_x.ptr, d_y.ptr)),
+                    ("hll4", lambda: dH.launch(S.HLL_KERNEL_PANELS, d_x.ptr,
+                                               d_y.ptr)),
                     ("csr2", lambda: dA.launch(2, d_x.ptr, d_y.ptr))):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         fn()
@@ -295,6 +301,7 @@ def test_config3_random_hll_full_size_properties(W):
         assert np.max(np.abs(got - want[:, 0]) / den) <= REL_TOL, tag
         ys[tag] = y
     assert np.max(np.abs(ys["hll1"] - ys["csr2"])) < 1e-11
+    assert np.max(np.abs(ys["hll1"] - ys["hll4"])) < 1e-11
     assert np.array_equal(ys["hll1"], ys["hll2"])  # same order of operations
     dH.release()
     dA.release()
