@@ -192,10 +192,11 @@ __global__ void k_flush(double *buf, size_t n) {
 /* row-block table of the CSR stream kernel (host, O(M))                */
 /* ------------------------------------------------------------------ */
 static void build_rowblk(const int *irp, int M, std::vector<int> &tab,
-                         int *max_len) {
+                         std::vector<unsigned char> &mode, int *max_len) {
     tab.clear();
+    mode.clear();
     tab.push_back(0);
-    int start = 0, longest = 0;
+    int start = 0, longest = 0, range_longest = 0;
     for (int r = 0; r < M; ++r) {
         int len = irp[r + 1] - irp[r];
         longest = std::max(longest, len);
@@ -203,17 +204,24 @@ static void build_rowblk(const int *irp, int M, std::vector<int> &tab,
         bool full = (have + len > STREAM_NNZ) || (r - start >= STREAM_THREADS);
         if (full && r > start) {
             tab.push_back(r); /* close [start, r) */
+            mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
             start = r;
+            range_longest = 0;
         }
+        range_longest = std::max(range_longest, len);
     }
-    if (M > start)
+    if (M > start) {
         tab.push_back(M);
+        mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
+    }
+    mode.push_back(0);
     *max_len = longest;
 }
 
 static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     int rc = 0;
     std::vector<int> tab;
+    std::vector<unsigned char> mode;
     std::vector<int> tmp;
     if (!host_irp) {
         tmp.resize((size_t)d->M + 1);
@@ -221,10 +229,13 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
                           hipMemcpyDeviceToHost));
         host_irp = tmp.data();
     }
-    build_rowblk(host_irp, d->M, tab, &d->max_row_len);
+    build_rowblk(host_irp, d->M, tab, mode, &d->max_row_len);
     d->n_rowblk = (int)tab.size() - 1;
     HIP_TRY(hipMalloc((void **)&d->rowblk, tab.size() * sizeof(int)));
     HIP_TRY(hipMemcpy(d->rowblk, tab.data(), tab.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
+    HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
                       hipMemcpyHostToDevice));
 fail:
     return rc;
@@ -252,6 +263,7 @@ void spmv_csr_release(spmv_csr_dev *d) {
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
+    (void)hipFree(d->rowblk_mode);
     panels_free(d->panels);
     free(d);
 }

@@ -52,6 +52,8 @@ static inline int hip_errno(hipError_t e) {
 /* nnz budget of one workgroup of the CSR stream kernel */
 #define STREAM_NNZ 2048
 #define STREAM_THREADS 256
+/* ranges whose longest row is at most this use the transposed form */
+#define STREAM_ROW_T 48
 
 struct spmv_panels; /* panels.hip */
 
@@ -65,6 +67,7 @@ struct spmv_csr_dev {
     /* stream kernel: workgroup k owns rows [rowblk[k], rowblk[k+1]) */
     int *rowblk;
     int n_rowblk;
+    unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
     int max_row_len;
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };
