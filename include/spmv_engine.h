@@ -97,6 +97,11 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          double *d_y, int row_begin, int row_end,
                          void *stream);
 int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols);
+/* schedule the NEXT build_panels calls prepare: 1 = "sweep" (one persistent
+ * launch, y tile resident in LDS; default), 0 = "steps" (one launch per
+ * non-empty panel step).  Environment SPMV_PANEL_SCHED=steps|sweep sets the
+ * initial value. */
+int spmv_set_panel_schedule(int sweep);
 /* geometry of the blocked copy: kernel launches per SpMV (steps), row
  * tiles, column panels, entries kept; -ENOENT when it is not built */
 int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,

@@ -201,6 +201,7 @@ _sig("spmv_csr_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
+_sig("spmv_set_panel_schedule", C.c_int, C.c_int)
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_hll_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_csr_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64))
@@ -283,6 +284,12 @@ def device_count():
 
 def set_device(d):
     _check(_lib.spmv_set_device(d), "spmv_set_device")
+
+
+def set_panel_schedule(sweep):
+    """schedule the next build_panels() calls prepare (spmv_engine.h)"""
+    _check(_lib.spmv_set_panel_schedule(int(bool(sweep))),
+           "spmv_set_panel_schedule")
 
 
 def device_info(d=0):

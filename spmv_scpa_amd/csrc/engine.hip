@@ -777,7 +777,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
                 bms = m;
                 best = SPMV_HLL_KERNEL_PANELS;
             } else {
-                panels_free(H->panels); /* give the 14 B/entry back */
+                panels_free(H->panels); /* give the 12 B/entry back */
                 H->panels = NULL;
             }
         } else if (rc != -ENOMEM && rc != -EOVERFLOW) {

@@ -10,28 +10,31 @@
  * anywhere spends 5.8 ms on its 320 M gathers whatever the kernel does.
  *
  * What: at upload the entries are bucketed by (row tile, column panel): a
- * tile is 1024 consecutive rows (its slice of y fits LDS, 8 KiB), a
- * panel is 2^18 columns (2 MiB of x).  Entries are stored tile-major and,
- * inside a tile, in panel order (col int32, row-in-tile uint16, value f64:
- * 14 B).  Products are added into the LDS tile with the hardware LDS fp64
- * atomic (ds_add_f64): no segmented reduction, no ordering inside a bucket.
+ * tile is a range of consecutive rows whose slice of y fits LDS, a panel is
+ * 2^18 columns (2 MiB of x).  Entries are stored tile-major and, inside a
+ * tile, in panel order, 12 B each: one 32-bit word (row-in-tile << shift |
+ * column-in-panel) and the fp64 value.  Products are added into the LDS tile
+ * with the hardware LDS fp64 atomic (ds_add_f64): no segmented reduction, no
+ * ordering inside a bucket.
  *
- * Default schedule: ONE LAUNCH PER STEP; in step s workgroup t adds the
- * s-th non-empty bucket of tile t into its y slice (coalesced read-modify-write through LDS; a
- * tile has one owner per launch, launches are stream-ordered, y is zeroed
- * first).  Every CU gathers from the same panel by construction.  Cost:
- * y is re-read and re-written once per panel that touches the tile.
- * Measured on config 3 with columns anywhere: 2.62 ms vs 5.81 ms for the
- * direct kernels (2.2x).  It LOSES on matrices with locality (most
- * (tile, panel) buckets empty -> few workgroups per launch), so it is
- * opt-in and bench.py picks it only when it measures faster.
+ * Schedule "steps" (tiles of 1024 rows): ONE LAUNCH PER STEP; in step s
+ * workgroup t adds the s-th non-empty bucket of tile t into its y slice
+ * (coalesced read-modify-write through LDS; a tile has one owner per launch,
+ * launches are stream-ordered, y is zeroed first).  Every CU gathers from the
+ * same panel by construction.  Cost: y is re-read and re-written once per
+ * panel that touches the tile (6.2 of the 11.6 GB per SpMV on config 3).
  *
- * Variant bit 3: one persistent launch, a workgroup keeps its tile in LDS
- * across all panels and writes y once (least traffic).  Workgroups drift
- * apart (no phase barrier), the L2 hit rate of the gathers falls to ~30 %
- * (rocprofv3 TCC_HIT/TCC_MISS) and it measures 4.3 ms; with all gathers
- * folded into one panel the same kernel runs 2.2 ms, which is what a
- * cheap-enough phase barrier could buy (next round).
+ * Schedule "sweep" (tiles of up to 8160 rows, 2 resident workgroups per CU):
+ * ONE persistent launch; a workgroup keeps its tile of y in LDS while it
+ * walks the panels in order and writes y once.  The workgroups of an XCD are
+ * kept within `lag` panels of each other by per-XCD phase counters (one
+ * agent-scope add per workgroup and phase, relaxed polls): the wait is only
+ * there for L2 locality -- it is BOUNDED, and falling through it costs
+ * speed, never correctness, so the kernel cannot hang on a chip that does
+ * not hold the whole grid.
+ *
+ * Both lose on matrices with locality (most buckets empty), so the path is
+ * opt-in and the autotuner keeps it only when it measures faster.
  *
  * Summation order inside a row depends on LDS atomic arrival order: results
  * are reproducible to rounding (tests hold them to 1e-12 of the row scale),
@@ -41,52 +44,70 @@
 
 #include "hip_common.h"
 
-#define TILE_ROWS_MAX 8192 /* 64 KiB of LDS per workgroup */
-#define TILE_THREADS 512
+#define TILE_ROWS_STEPS 1024 /* "steps" schedule: 8 KiB of LDS */
+#define TILE_ROWS_MAX 10208  /* "sweep" schedule: 2 x 79.75 KiB per CU */
+#define SWEEP_WG_PER_CU 2
+#define SWEEP_SPIN_MAX 4096  /* polls before a wait gives up (perf only) */
+#define CNT_STRIDE 32        /* one phase counter per 128-B line */
+#define SWEEP_TAIL 16384     /* zero slots behind the entries: >= 3 chunks */
 
 struct spmv_panels {
+    int N;           /* columns */
     int shift;       /* log2(columns per panel) */
     int panels;      /* column panels */
     int tile_rows;   /* rows per tile (multiple of 32) */
     int tiles;       /* row tiles */
+    int sweep;       /* built for the persistent schedule */
+    int grid;        /* sweep: workgroups of the launch */
     int64_t nnz;     /* entries kept */
-    int *col;        /* [nnz] absolute column */
-    unsigned short *rloc; /* [nnz] row inside its tile */
+    int64_t total;   /* slots of ENT/VAL in use (bucket padding included) */
+    unsigned *ent;   /* [nnz] row-in-tile << shift | column-in-panel */
     double *val;     /* [nnz] */
-    int64_t *tptr;   /* DEVICE [tiles+1] entry range of each tile */
-    int64_t *bptr;   /* DEVICE [tiles*panels+1] start of bucket (tile, panel) */
+    int64_t *bptr;   /* DEVICE [tiles*panels+1] start of bucket (tile, panel);
+                        multiples of 4 (steps) or 256 (sweep) slots */
+    int *blen;       /* DEVICE [tiles*panels] entries of the bucket (the slots
+                        up to the next start are padding, never read as data) */
     int64_t *cb;     /* DEVICE [tiles*panels*2] (begin,end) of the s-th NON-EMPTY
                         bucket of each tile, tile-major */
+    int *cpanel;     /* DEVICE [tiles*panels] panel of that bucket */
     int *nbk;        /* DEVICE [tiles] non-empty buckets per tile */
     int max_nbk;     /* launches needed = max over tiles */
+    int *phase_cnt;  /* DEVICE sweep: [8 XCDs][rounds*panels] arrival counters */
+    size_t phase_cnt_bytes;
 };
 
 void panels_free(spmv_panels *p) {
     if (!p)
         return;
-    (void)hipFree(p->col);
-    (void)hipFree(p->rloc);
+    (void)hipFree(p->ent);
     (void)hipFree(p->val);
-    (void)hipFree(p->tptr);
+    (void)hipFree(p->cpanel);
+    (void)hipFree(p->phase_cnt);
     (void)hipFree(p->bptr);
+    (void)hipFree(p->blen);
     (void)hipFree(p->cb);
     (void)hipFree(p->nbk);
     free(p);
 }
 
-/* ---- keys: (tile * panels + panel), all-ones = dropped slot ---- */
+/* ---- keys: (tile * panels + panel) << shift | column-in-panel: buckets in
+ * order and, inside a bucket, ascending columns, so the lanes of a gather
+ * instruction ask for neighbouring lines of x and entries that share a line
+ * share the request.  dropped slots: bucket id tiles*panels (sorts last) ---- */
 __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
                                 const int *__restrict__ irp,
-                                const int *__restrict__ ja, unsigned *key,
+                                const int *__restrict__ ja, uint64_t *key,
                                 unsigned *idx) {
     /* 8 lanes per row keep the writes reasonably coalesced */
     const int sub = threadIdx.x & 7;
     long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (row >= M)
         return;
-    const unsigned tk = (unsigned)(row / tile_rows) * (unsigned)panels;
+    const uint64_t tk = (uint64_t)(row / tile_rows) * (uint64_t)panels;
+    const unsigned low = (1u << shift) - 1u;
     for (int k = irp[row] + sub, e = irp[row + 1]; k < e; k += 8) {
-        key[k] = tk + (unsigned)(ja[k] >> shift);
+        const unsigned c = (unsigned)ja[k];
+        key[k] = ((tk + (c >> shift)) << shift) | (c & low);
         idx[k] = (unsigned)k;
     }
 }
@@ -94,7 +115,7 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
 __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
                                 int col_major, const int64_t *__restrict__ off,
                                 const int *__restrict__ ja,
-                                const double *__restrict__ as, unsigned *key,
+                                const double *__restrict__ as, uint64_t *key,
                                 unsigned *idx) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= M)
@@ -103,27 +124,56 @@ __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
     int rows = min(32, M - b * 32);
     int64_t o = off[b];
     int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
-    const unsigned tk = (unsigned)(row / tile_rows) * (unsigned)panels;
+    const uint64_t tk = (uint64_t)(row / tile_rows) * (uint64_t)panels;
+    const uint64_t dropped =
+        ((uint64_t)((M + tile_rows - 1) / tile_rows) * (uint64_t)panels) << shift;
+    const unsigned low = (1u << shift) - 1u;
     for (int j = 0; j < w; ++j) {
         int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
         /* pads carry the value 0.0 (hip_hll.h); a slot that is exactly zero
          * contributes nothing and is dropped */
-        key[t] = as[t] != 0.0 ? tk + (unsigned)(ja[t] >> shift) : ~0u;
+        const unsigned c = (unsigned)ja[t];
+        key[t] = as[t] != 0.0 ? ((tk + (c >> shift)) << shift) | (c & low)
+                              : dropped;
         idx[t] = (unsigned)t;
     }
 }
 
+/*
+ * Slot of entry r of a bucket in VAL.  "steps" layout: r.  "sweep" layout:
+ * inside every block of 256 entries (one wavefront's chunk; lane L owns
+ * entries 4L..4L+3, which it reads from ENT with one 16-byte load) the values
+ * are stored so that the lane's two 16-byte loads are at 2L and 128 + 2L --
+ * every load instruction of the wavefront then covers 1 KiB of whole cache
+ * lines, none of them twice (24 line requests per block instead of ~43: the
+ * CU's outstanding-miss slots are what the kernel runs out of).
+ */
+__device__ __forceinline__ int64_t sweep_val_slot(int64_t r, int permute) {
+    if (!permute)
+        return r;
+    const int i = (int)(r & 255), L = i >> 2, j = i & 3;
+    return (r & ~(int64_t)255) + (j < 2 ? 2 * L + j : 128 + 2 * L + (j - 2));
+}
+
 /* row of a source position: CSR needs a search in irp, HLL decodes the slot */
-__global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows,
+__global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows, int shift,
+                                  int permute,
                                   const unsigned *__restrict__ idx,
                                   const int *__restrict__ irp,
                                   const int *__restrict__ ja,
-                                  const double *__restrict__ as, int *tcol,
-                                  unsigned short *trow, double *tval) {
+                                  const double *__restrict__ as,
+                                  const uint64_t *__restrict__ skey,
+                                  const int64_t *__restrict__ raw,
+                                  const int64_t *__restrict__ bptr,
+                                  unsigned *tent, double *tval) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n)
         return;
     const unsigned t = idx[k];
+    const uint64_t bk = skey[k] >> shift; /* bucket */
+    const int64_t rk = k - raw[bk];       /* rank inside the bucket */
+    const int64_t dst = bptr[bk] + rk;
+    const int64_t vdst = bptr[bk] + sweep_val_slot(rk, permute);
     int lo = 0, hi = M; /* last row with irp[row] <= t */
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -132,22 +182,29 @@ __global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows,
         else
             hi = mid;
     }
-    tcol[k] = ja[t];
-    trow[k] = (unsigned short)(lo % tile_rows);
-    tval[k] = as[t];
+    tent[dst] = ((unsigned)(lo % tile_rows) << shift) |
+                ((unsigned)ja[t] & ((1u << shift) - 1u));
+    tval[vdst] = as[t];
 }
 
 __global__ void k_tile_gather_hll(int64_t n, int M, int nb, int tile_rows,
-                                  int col_major,
+                                  int shift, int permute, int col_major,
                                   const unsigned *__restrict__ idx,
                                   const int64_t *__restrict__ off,
                                   const int *__restrict__ ja,
-                                  const double *__restrict__ as, int *tcol,
-                                  unsigned short *trow, double *tval) {
+                                  const double *__restrict__ as,
+                                  const uint64_t *__restrict__ skey,
+                                  const int64_t *__restrict__ raw,
+                                  const int64_t *__restrict__ bptr,
+                                  unsigned *tent, double *tval) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n)
         return;
     const unsigned t = idx[k];
+    const uint64_t bk = skey[k] >> shift; /* bucket */
+    const int64_t rk = k - raw[bk];       /* rank inside the bucket */
+    const int64_t dst = bptr[bk] + rk;
+    const int64_t vdst = bptr[bk] + sweep_val_slot(rk, permute);
     int lo = 0, hi = nb; /* block holding slot t */
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -160,32 +217,14 @@ __global__ void k_tile_gather_hll(int64_t n, int M, int nb, int tile_rows,
     const unsigned rel = (unsigned)((int64_t)t - off[lo]);
     const unsigned w = (unsigned)(off[lo + 1] - off[lo]) / (unsigned)rows;
     const int i = col_major ? (int)(rel % (unsigned)rows) : (int)(rel / w);
-    tcol[k] = ja[t];
-    trow[k] = (unsigned short)((lo * 32 + i) % tile_rows);
-    tval[k] = as[t];
+    tent[dst] = ((unsigned)((lo * 32 + i) % tile_rows) << shift) |
+                ((unsigned)ja[t] & ((1u << shift) - 1u));
+    tval[vdst] = as[t];
 }
 
-/* first position whose key >= tile * panels, one thread per tile boundary */
-__global__ void k_tile_bounds(int tiles, int panels, int64_t n,
-                              const unsigned *__restrict__ key, int64_t *tptr) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > tiles)
-        return;
-    const uint64_t bound = (uint64_t)t * (uint64_t)panels;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((uint64_t)key[mid] < bound)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    tptr[t] = lo;
-}
-
-/* start of every (tile, panel) bucket: first position with key >= b */
-__global__ void k_bucket_bounds(int64_t buckets, int64_t n,
-                                const unsigned *__restrict__ key,
+/* start of every (tile, panel) bucket: first position with bucket id >= b */
+__global__ void k_bucket_bounds(int64_t buckets, int64_t n, int shift,
+                                const uint64_t *__restrict__ key,
                                 int64_t *bptr) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b > buckets)
@@ -193,7 +232,7 @@ __global__ void k_bucket_bounds(int64_t buckets, int64_t n,
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if ((uint64_t)key[mid] < (uint64_t)b)
+        if ((key[mid] >> shift) < (uint64_t)b)
             lo = mid + 1;
         else
             hi = mid;
@@ -201,20 +240,36 @@ __global__ void k_bucket_bounds(int64_t buckets, int64_t n,
     bptr[b] = lo;
 }
 
+/* bucket sizes, and the sizes rounded up to `pad` slots (input of the prefix
+ * sum that gives the padded starts); slot `buckets` closes the scan */
+__global__ void k_bucket_sizes(int64_t buckets, int64_t pad,
+                               const int64_t *__restrict__ raw, int *blen,
+                               int64_t *padded) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > buckets)
+        return;
+    const int64_t len = b < buckets ? raw[b + 1] - raw[b] : 0;
+    if (b < buckets)
+        blen[b] = (int)len;
+    padded[b] = (len + pad - 1) & ~(pad - 1);
+}
+
 /* compact every tile's non-empty buckets; one thread per tile */
 __global__ void k_compact_buckets(int tiles, int panels,
                                   const int64_t *__restrict__ bptr,
-                                  int64_t *cb, int *nbk) {
+                                  const int *__restrict__ blen, int64_t *cb,
+                                  int *cpanel, int *nbk) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles)
         return;
     int n = 0;
     for (int p = 0; p < panels; ++p) {
         int64_t b = bptr[(int64_t)t * panels + p];
-        int64_t e = bptr[(int64_t)t * panels + p + 1];
+        int64_t e = b + blen[(int64_t)t * panels + p];
         if (e > b) {
             cb[((int64_t)t * panels + n) * 2] = b;
             cb[((int64_t)t * panels + n) * 2 + 1] = e;
+            cpanel[(int64_t)t * panels + n] = p;
             ++n;
         }
     }
@@ -229,6 +284,36 @@ __global__ void k_max_int(int n, const int *__restrict__ v, int *out) {
     atomicMax(out, m);
 }
 
+static int g_panel_sweep = -1; /* -1: not decided (env or default) */
+
+static int panel_schedule(void) {
+    if (g_panel_sweep < 0) {
+        const char *ev = getenv("SPMV_PANEL_SCHED");
+        g_panel_sweep = (ev && !strcmp(ev, "steps")) ? 0 : 1;
+    }
+    return g_panel_sweep;
+}
+
+extern "C" int spmv_set_panel_schedule(int sweep) {
+    g_panel_sweep = sweep ? 1 : 0;
+    return 0;
+}
+
+static int sweep_grid(void) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return 512;
+    int per_cu = SWEEP_WG_PER_CU;
+    if (const char *ev = getenv("SPMV_SWEEP_WGS")) { /* tuning override */
+        int o = atoi(ev);
+        if (o >= 1 && o <= 8)
+            per_cu = o;
+    }
+    return prop.multiProcessorCount * per_cu;
+}
+
 static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
                         const int *irp_or_null, const int64_t *off_or_null,
                         int col_major, const int *ja, const double *as,
@@ -237,22 +322,40 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
+    const int sweep = panel_schedule();
+    /* tile height.  steps: 1024 rows measured best (2.62 ms on config 3;
+     * 3.3 ms at 8192): many small workgroups overlap their load / gather /
+     * store phases.  sweep: the fewest rounds of (grid x TILE_ROWS_MAX) rows
+     * that cover M, rows spread evenly over them. */
+    long long tr = TILE_ROWS_STEPS;
+    int grid = 0;
+    if (sweep) {
+        grid = sweep_grid();
+        const long long rounds =
+            ((long long)M + (long long)grid * TILE_ROWS_MAX - 1) /
+            ((long long)grid * TILE_ROWS_MAX);
+        const long long wg = (rounds > 0 ? rounds : 1) * grid;
+        tr = (((long long)M + wg - 1) / wg + 31) / 32 * 32;
+        if (tr < 32)
+            tr = 32;
+    }
+    if (const char *ev = getenv("SPMV_TILE_ROWS")) { /* tuning override */
+        long long o = atoll(ev);
+        if (o >= 32 && o <= TILE_ROWS_MAX)
+            tr = o / 32 * 32;
+    }
+    int rbits = 0;
+    while ((1ll << rbits) < tr)
+        ++rbits;
     int shift = 18; /* 2^18 columns = 2 MiB of x: half of an XCD's L2 */
     if (panel_cols > 0) {
         shift = 0;
         while ((1 << (shift + 1)) <= panel_cols && shift < 30)
             ++shift;
     }
+    if (shift > 32 - rbits) /* row-in-tile and column-in-panel share a word */
+        shift = 32 - rbits;
     const int panels = (int)((((int64_t)(N > 0 ? N : 1) - 1) >> shift) + 1);
-    /* tile height: 1024 rows (8 KiB of LDS) measured best for the default
-     * one-launch-per-panel schedule on config 3 (2.62 ms; 3.3 ms at 8192):
-     * many small workgroups overlap their load / gather / store phases */
-    long long tr = 1024;
-    if (const char *ev = getenv("SPMV_TILE_ROWS")) { /* tuning override */
-        long long o = atoll(ev);
-        if (o >= 32 && o <= TILE_ROWS_MAX)
-            tr = o / 32 * 32;
-    }
     const int tiles = (int)(((long long)M + tr - 1) / tr);
     if ((uint64_t)(tiles > 0 ? tiles : 1) * (uint64_t)panels >= 0xffffffffull)
         return -EOVERFLOW;
@@ -260,20 +363,25 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
     spmv_panels *P = (spmv_panels *)calloc(1, sizeof *P);
     if (!P)
         return -ENOMEM;
+    P->N = N;
     P->shift = shift;
     P->panels = panels;
     P->tile_rows = (int)tr;
     P->tiles = tiles;
-    unsigned *key[2] = {NULL, NULL};
+    P->sweep = sweep;
+    P->grid = sweep ? (grid < tiles ? grid : (tiles > 0 ? tiles : 1)) : 0;
+    uint64_t *key[2] = {NULL, NULL};
     unsigned *idx[2] = {NULL, NULL};
-    unsigned *skey = NULL, *sidx = NULL;
+    uint64_t *skey = NULL;
+    unsigned *sidx = NULL;
     void *tmp = NULL;
     size_t tmp_bytes = 0;
+    int64_t *raw = NULL, *padded = NULL; /* unpadded bucket starts, scan input */
     const size_t n = (size_t)(slots > 0 ? slots : 1);
     int64_t total = 0;
 
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMalloc((void **)&key[k], n * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void **)&key[k], n * sizeof(uint64_t)));
         HIP_TRY(hipMalloc((void **)&idx[k], n * sizeof(unsigned)));
     }
     skey = key[0];
@@ -290,16 +398,14 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
                                col_major, off_or_null, ja, as, key[0], idx[0]);
         HIP_TRY(hipGetLastError());
         {
-            hipcub::DoubleBuffer<unsigned> dk(key[0], key[1]);
+            hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
             hipcub::DoubleBuffer<unsigned> dv(idx[0], idx[1]);
-            /* CSR sources have no dropped slots: sort only the used bits */
-            int end_bit = 32;
-            if (irp_or_null) {
-                end_bit = 1;
-                while (end_bit < 32 &&
-                       (((uint64_t)tiles * (uint64_t)panels) >> end_bit))
-                    ++end_bit;
-            }
+            /* sort only the bits in use: bucket ids up to tiles*panels (the
+             * id of dropped slots) above `shift` column bits */
+            int end_bit = shift + 1;
+            while (end_bit < 64 &&
+                   (((uint64_t)tiles * (uint64_t)panels) >> (end_bit - shift)))
+                ++end_bit;
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
                 NULL, tmp_bytes, dk, dv, (int)slots, 0, end_bit, 0));
             HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
@@ -310,54 +416,85 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
             sidx = dv.Current();
         }
     }
-    HIP_TRY(hipMalloc((void **)&P->tptr, ((size_t)tiles + 1) * sizeof(int64_t)));
-    hipLaunchKernelGGL(k_tile_bounds, dim3((tiles + 256) / 256), dim3(256), 0,
-                       0, tiles, panels, slots, skey, P->tptr);
-    HIP_TRY(hipGetLastError());
     {
         const int64_t buckets = (int64_t)tiles * panels;
+        const unsigned gb = (unsigned)((buckets + 256) / 256);
+        HIP_TRY(hipMalloc((void **)&raw, ((size_t)buckets + 1) * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&padded,
+                          ((size_t)buckets + 1) * sizeof(int64_t)));
         HIP_TRY(hipMalloc((void **)&P->bptr,
                           ((size_t)buckets + 1) * sizeof(int64_t)));
-        hipLaunchKernelGGL(k_bucket_bounds,
-                           dim3((unsigned)((buckets + 256) / 256)), dim3(256),
-                           0, 0, buckets, slots, skey, P->bptr);
+        HIP_TRY(hipMalloc((void **)&P->blen, ((size_t)buckets + 1) * sizeof(int)));
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(gb), dim3(256), 0, 0, buckets,
+                           slots, shift, skey, raw);
+        hipLaunchKernelGGL(k_bucket_sizes, dim3(gb), dim3(256), 0, 0, buckets,
+                           (int64_t)(sweep ? 256 : 4), raw, P->blen, padded);
         HIP_TRY(hipGetLastError());
+        {
+            void *t2 = NULL;
+            size_t t2b = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t2, t2b, padded, P->bptr,
+                                                     (int)(buckets + 1), 0));
+            HIP_TRY(hipMalloc(&t2, t2b ? t2b : 16));
+            hipError_t e2 = hipcub::DeviceScan::ExclusiveSum(
+                t2, t2b, padded, P->bptr, (int)(buckets + 1), 0);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(t2);
+            HIP_TRY(e2);
+        }
         HIP_TRY(hipMalloc((void **)&P->cb,
                           ((size_t)buckets + 1) * 2 * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&P->cpanel,
+                          ((size_t)buckets + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void **)&P->nbk, ((size_t)tiles + 1) * sizeof(int)));
         HIP_TRY(hipMemset(P->nbk + tiles, 0, sizeof(int)));
         if (tiles > 0) {
             hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
-                               dim3(256), 0, 0, tiles, panels, P->bptr, P->cb,
-                               P->nbk);
+                               dim3(256), 0, 0, tiles, panels, P->bptr, P->blen,
+                               P->cb, P->cpanel, P->nbk);
             hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, 0, tiles,
                                P->nbk, P->nbk + tiles);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipMemcpy(&P->max_nbk, P->nbk + tiles, sizeof(int),
                           hipMemcpyDeviceToHost));
+        /* dropped slots sort behind the last bucket */
+        HIP_TRY(hipMemcpy(&P->nnz, raw + buckets, sizeof(int64_t),
+                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&total, P->bptr + buckets, sizeof total,
+                          hipMemcpyDeviceToHost));
     }
-    HIP_TRY(hipMemcpy(&total, P->tptr + tiles, sizeof total,
-                      hipMemcpyDeviceToHost));
-    P->nnz = total; /* dropped slots sort behind the last tile */
+    if (total + SWEEP_TAIL > (int64_t)INT32_MAX) {
+        rc = -EOVERFLOW; /* the kernels index slots with 32 bits */
+        goto fail;
+    }
+    P->total = total;
     {
-        const size_t m = (size_t)(P->nnz > 0 ? P->nnz : 1);
-        HIP_TRY(hipMalloc((void **)&P->col, m * sizeof(int)));
-        HIP_TRY(hipMalloc((void **)&P->rloc, m * sizeof(unsigned short)));
+        const size_t m = (size_t)total + SWEEP_TAIL; /* zeros behind the data */
+        HIP_TRY(hipMalloc((void **)&P->ent, m * sizeof(unsigned)));
         HIP_TRY(hipMalloc((void **)&P->val, m * sizeof(double)));
+        HIP_TRY(hipMemset(P->ent, 0, m * sizeof(unsigned)));
+        HIP_TRY(hipMemset(P->val, 0, m * sizeof(double)));
     }
     if (P->nnz > 0) {
         const unsigned g = (unsigned)((P->nnz + 255) / 256);
         if (irp_or_null)
             hipLaunchKernelGGL(k_tile_gather_csr, dim3(g), dim3(256), 0, 0,
-                               P->nnz, M, (int)tr, sidx, irp_or_null, ja, as,
-                               P->col, P->rloc, P->val);
+                               P->nnz, M, (int)tr, shift, sweep, sidx, irp_or_null,
+                               ja, as, skey, raw, P->bptr, P->ent, P->val);
         else
             hipLaunchKernelGGL(k_tile_gather_hll, dim3(g), dim3(256), 0, 0,
-                               P->nnz, M, nb, (int)tr, col_major, sidx,
-                               off_or_null, ja, as, P->col, P->rloc, P->val);
+                               P->nnz, M, nb, (int)tr, shift, sweep, col_major, sidx,
+                               off_or_null, ja, as, skey, raw, P->bptr, P->ent,
+                               P->val);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
+    }
+    if (sweep) {
+        const size_t rounds = ((size_t)tiles + P->grid - 1) / P->grid;
+        P->phase_cnt_bytes =
+            8 * (rounds ? rounds : 1) * (size_t)panels * CNT_STRIDE * sizeof(int);
+        HIP_TRY(hipMalloc((void **)&P->phase_cnt, P->phase_cnt_bytes));
     }
     *out = P;
     P = NULL;
@@ -367,80 +504,22 @@ fail:
         (void)hipFree(idx[k]);
     }
     (void)hipFree(tmp);
+    (void)hipFree(raw);
+    (void)hipFree(padded);
     panels_free(P);
     return rc;
 }
 
 /* ------------------------------------------------------------------ */
-/* the kernel: persistent workgroups, one row tile at a time             */
+/* schedule "steps": one launch per step                                 */
 /* ------------------------------------------------------------------ */
-#define TILE_UNROLL 8
-
-template <int ABL> /* ablation bits for timing experiments: 1 = no LDS add,
-                      2 = all gathers folded into one panel, 4 = no x gather */
-__global__ void __launch_bounds__(TILE_THREADS)
-    k_tiles_spmv(int M, int tile_rows, int tiles,
-                 const int64_t *__restrict__ tptr, const int *__restrict__ tcol,
-                 const unsigned short *__restrict__ trow,
-                 const double *__restrict__ tval, const double *__restrict__ x,
-                 double *__restrict__ y) {
-    extern __shared__ double ytile[];
-    const int tid = threadIdx.x;
-    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
-        for (int i = tid; i < tile_rows; i += TILE_THREADS)
-            ytile[i] = 0.0;
-        __syncthreads();
-        const int64_t b = tptr[t], e = tptr[t + 1];
-        for (int64_t k0 = b + tid; k0 < e; k0 += TILE_THREADS * TILE_UNROLL) {
-            int c[TILE_UNROLL];
-            unsigned short rl[TILE_UNROLL];
-            double v[TILE_UNROLL], xv[TILE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < TILE_UNROLL; ++u) {
-                const int64_t k = k0 + (int64_t)u * TILE_THREADS;
-                const bool ok = k < e;
-                c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
-                rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
-                v[u] = ok ? __builtin_nontemporal_load(tval + k) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < TILE_UNROLL; ++u)
-                xv[u] = c[u] >= 0 ? ((ABL & 4) ? 1.0
-                                     : (ABL & 2) ? x[c[u] & 0x3FFFF] /* one panel */
-                                                 : x[c[u]])
-                                  : 0.0;
-#pragma unroll
-            for (int u = 0; u < TILE_UNROLL; ++u) {
-                if (ABL & 1) {
-                    if (v[u] * xv[u] == 1.2345e300)
-                        ytile[rl[u]] = 1.0;
-                } else if (c[u] >= 0) {
-                    unsafeAtomicAdd(&ytile[rl[u]], v[u] * xv[u]);
-                }
-            }
-        }
-        __syncthreads();
-        const int64_t row0 = (int64_t)t * tile_rows;
-        for (int i = tid; i < tile_rows && row0 + i < M; i += TILE_THREADS)
-            y[row0 + i] = ytile[i];
-        __syncthreads();
-    }
-}
-
-/*
- * Variant with a hard phase boundary: one launch per column panel.  Every
- * workgroup adds its (tile, panel) bucket into the y slice of its tile
- * (through LDS, coalesced read-modify-write; the tile has a single owner per
- * launch and launches are stream-ordered).  All CUs gather from one panel by
- * construction, at the price of re-reading and re-writing y once per panel.
- */
-template <int NT, int ABL = 0, int UN = TILE_UNROLL> /* timing ablations: 1 no y traffic, 2 no gather */
+template <int NT, int UN>
 __global__ void __launch_bounds__(NT)
-    k_tiles_one_panel(int M, int tile_rows, int panels, int step,
+    k_tiles_one_panel(int M, int tile_rows, int panels, int shift, int step,
                       const int64_t *__restrict__ cb,
+                      const int *__restrict__ cpanel,
                       const int *__restrict__ nbk,
-                      const int *__restrict__ tcol,
-                      const unsigned short *__restrict__ trow,
+                      const unsigned *__restrict__ tent,
                       const double *__restrict__ tval,
                       const double *__restrict__ x, double *__restrict__ y) {
     extern __shared__ double ytile[];
@@ -457,47 +536,46 @@ __global__ void __launch_bounds__(NT)
         return; /* this tile has fewer non-empty buckets: y untouched */
     const int64_t b = cb[((int64_t)t * panels + step) * 2];
     const int64_t e = cb[((int64_t)t * panels + step) * 2 + 1];
+    const double *xp = x + ((int64_t)cpanel[(int64_t)t * panels + step] << shift);
+    const unsigned lowmask = (1u << shift) - 1u;
     const int64_t row0 = (int64_t)t * tile_rows;
     /* first batch of entries and the y slice are fetched together (they are
      * independent); the x gathers follow the barrier: issued before it they
      * delay the slice, whose loads return in order behind them (measured
      * 2.97 ms vs 2.6 ms) */
-    int c[UN];
-    unsigned short rl[UN];
+    unsigned en[UN];
     double v[UN];
+    bool ok[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int64_t k = b + tid + (int64_t)u * NT;
-        const bool ok = k < e;
-        c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
-        rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
-        v[u] = ok ? __builtin_nontemporal_load(tval + k) : 0.0;
+        ok[u] = k < e;
+        en[u] = ok[u] ? __builtin_nontemporal_load(tent + k) : 0u;
+        v[u] = ok[u] ? __builtin_nontemporal_load(tval + k) : 0.0;
     }
     for (int i = tid; i < tile_rows; i += NT)
-        ytile[i] = (!(ABL & 1) && row0 + i < M) ? y[row0 + i] : 0.0;
+        ytile[i] = row0 + i < M ? y[row0 + i] : 0.0;
     __syncthreads();
     for (int64_t k0 = b + tid; k0 < e; k0 += (int64_t)NT * UN) {
-        double xv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-            xv[u] = c[u] >= 0 ? ((ABL & 2) ? x[c[u] & 1023] : x[c[u]]) : 0.0;
         double pr[UN];
-        unsigned short rr[UN];
+        unsigned rr[UN];
         bool on[UN];
 #pragma unroll
+        for (int u = 0; u < UN; ++u)
+            pr[u] = ok[u] ? xp[en[u] & lowmask] : 0.0;
+#pragma unroll
         for (int u = 0; u < UN; ++u) {
-            pr[u] = v[u] * xv[u];
-            rr[u] = rl[u];
-            on[u] = c[u] >= 0;
+            pr[u] *= v[u];
+            rr[u] = en[u] >> shift;
+            on[u] = ok[u];
         }
         if (k0 + (int64_t)NT * UN < e) { /* next batch behind the gathers */
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int64_t k = k0 + (int64_t)NT * UN + (int64_t)u * NT;
-                const bool ok = k < e;
-                c[u] = ok ? __builtin_nontemporal_load(tcol + k) : -1;
-                rl[u] = ok ? __builtin_nontemporal_load(trow + k) : 0;
-                v[u] = ok ? __builtin_nontemporal_load(tval + k) : 0.0;
+                ok[u] = k < e;
+                en[u] = ok[u] ? __builtin_nontemporal_load(tent + k) : 0u;
+                v[u] = ok[u] ? __builtin_nontemporal_load(tval + k) : 0.0;
             }
         }
 #pragma unroll
@@ -506,13 +584,223 @@ __global__ void __launch_bounds__(NT)
                 unsafeAtomicAdd(&ytile[rr[u]], pr[u]);
     }
     __syncthreads();
-    if (ABL & 1) {
-        if (ytile[tid] == 1.2345e300)
-            y[row0] = 1.0;
-        return;
-    }
     for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
         y[row0 + i] = ytile[i];
+}
+
+/* ------------------------------------------------------------------ */
+/* schedule "sweep": one persistent launch                               */
+/* ------------------------------------------------------------------ */
+__device__ __forceinline__ void phase_arrive(int *cnt) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* bounded: a miss only costs L2 locality */
+__device__ __forceinline__ void phase_wait(const int *cnt, int want, int spin) {
+    for (int i = 0; i < spin; ++i) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
+            want)
+            return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+/*
+ * A lane owns Q groups of 4 consecutive entries per chunk: one 16-byte load
+ * of ENT and two of VAL per group (layout: sweep_val_slot).  Three
+ * chunk buffers rotate: while chunk c is gathered and added, the loads of
+ * c+1 are a whole iteration old and those of c+2 are issued behind c's
+ * gathers -- the CU's texture path serves requests in order, so a stream
+ * load queues behind every gather issued before it and needs that lead.
+ * Chunks follow each other across panel boundaries.
+ *
+ * Every vector-memory instruction of the loop body is UNCONDITIONAL (lanes
+ * past the end of a bucket read the slots that follow -- the arrays carry
+ * SWEEP_TAIL slots of slack -- and are masked afterwards; the phase poll is
+ * issued for every chunk and only looked at after a panel's last one): with
+ * loads under divergent or uniform branches the compiler can no longer
+ * count the in-order vmcnt queue and waits for everything, which
+ * serialises gathers and stream (measured 2.2 ms vs the sum of both).
+ * The poll for the NEXT panel's entry condition thus returns with the
+ * gathers and costs no drain; only a miss falls into the (bounded) spin.
+ */
+
+template <int Q> struct sweep_chunk {
+    u32x4 en[Q];
+    f64x2 va[Q], vb[Q];
+    int live[Q];      /* entries of the group that exist: <= 0 .. >= 4 */
+    int p;            /* wave-uniform: panel (>= panels: past the end) */
+    bool first, last; /* wave-uniform: first / last chunk of its bucket */
+};
+
+template <int NT, int Q, int ABL = 0> /* ABL: timing ablations, 1 = no LDS
+                                         add, 2 = gathers from one 8 KiB
+                                         window (L1 hits) */
+__global__ void __launch_bounds__(NT)
+    k_tiles_sweep(int M, int tile_rows, int tiles, int panels, int shift,
+                  int lag, int spin, unsigned total,
+                  const int64_t *__restrict__ bptr,
+                  const int *__restrict__ blen,
+                  const unsigned *__restrict__ tent,
+                  const double *__restrict__ tval,
+                  const double *__restrict__ x, double *__restrict__ y,
+                  int *phase_cnt) {
+    extern __shared__ double ytile[];
+    __shared__ int wave_done[8];
+    constexpr int WAVES = NT / WAVE;
+    constexpr unsigned CH = NT * Q * 4;
+    const int tid = threadIdx.x;
+    const int grid = gridDim.x;
+    /* workgroups are dealt to the XCDs round-robin */
+    const int xcd = blockIdx.x & 7;
+    const int n_x = grid / 8 + (xcd < (grid & 7) ? 1 : 0);
+    const int rounds = (tiles + grid - 1) / grid;
+    int *cnt = phase_cnt + (size_t)xcd * rounds * panels * CNT_STRIDE;
+    const unsigned lowmask = (ABL & 2) ? 1023u : (1u << shift) - 1u;
+    if (tid < 8)
+        wave_done[tid] = 0;
+
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * grid + blockIdx.x;
+        const int q0 = r * panels;
+        if (t >= tiles) { /* no tile this round: arrive at all its phases */
+            if (tid == 0)
+                for (int p = 0; p < panels; ++p)
+                    phase_arrive(cnt + (size_t)(q0 + p) * CNT_STRIDE);
+            continue;
+        }
+        for (int i = tid; i < tile_rows; i += NT)
+            ytile[i] = 0.0;
+        __syncthreads();
+
+        const int64_t *bp = bptr + (int64_t)t * panels;
+        const int *bl = blen + (int64_t)t * panels;
+        bool ready = !(lag > 0 && q0 >= lag); /* panel 0 of a later round */
+
+        /* position of the next chunk to load (wave-uniform) */
+        int fp = 0;
+        unsigned fk = (unsigned)bp[0], fe = fk + (unsigned)bl[0];
+        bool ffirst = true;
+
+        auto fill = [&](sweep_chunk<Q> &c) {
+            c.p = fp;
+            c.first = ffirst;
+            c.last = fk + CH >= fe;
+#pragma unroll
+            for (int g = 0; g < Q; ++g) {
+                /* the wavefront's block of 256 slots: ENT in entry order,
+                 * VAL permuted (sweep_val_slot) so that each of the three
+                 * loads reads 1 KiB of whole lines */
+                unsigned blk = fk + ((unsigned)g * NT + (tid & ~(WAVE - 1))) * 4u;
+                const unsigned lane = tid & (WAVE - 1);
+                c.live[g] = (int)(fe - (blk + lane * 4u));
+                if (ABL & 4) /* stream from a 192 KiB window: L2 hits */
+                    blk &= 0x3FFFu;
+                c.en[g] = __builtin_nontemporal_load(
+                    (const u32x4 *)(tent + blk + lane * 4u));
+                c.va[g] = __builtin_nontemporal_load(
+                    (const f64x2 *)(tval + blk + lane * 2u));
+                c.vb[g] = __builtin_nontemporal_load(
+                    (const f64x2 *)(tval + blk + 128u + lane * 2u));
+            }
+            /* advance */
+            if (fp < panels) {
+                if (!c.last) {
+                    fk += CH;
+                    ffirst = false;
+                } else {
+                    fp += 1;
+                    ffirst = true;
+                    if (fp < panels) {
+                        fk = (unsigned)bp[fp];
+                        fe = fk + (unsigned)bl[fp];
+                    } else { /* past the end: zeros of the tail */
+                        fk = total;
+                        fe = total;
+                    }
+                }
+            }
+        };
+
+        /* gather and add chunk `c`, loading the chunk after next into `f` */
+        auto step = [&](sweep_chunk<Q> &c, sweep_chunk<Q> &f) {
+            const int q = q0 + c.p;
+            if (c.first && !ready)
+                phase_wait(cnt + (size_t)(q - lag) * CNT_STRIDE, n_x, spin);
+            const double *xp = x + ((int64_t)c.p << shift);
+            double pr[Q][4], w[Q][4];
+            unsigned rr[Q][4];
+            int on[Q];
+#pragma unroll
+            for (int g = 0; g < Q; ++g) {
+                on[g] = c.live[g];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned col = u < on[g] ? (c.en[g][u] & lowmask) : 0u;
+                    pr[g][u] = xp[col];
+                    rr[g][u] = c.en[g][u] >> shift;
+                }
+                w[g][0] = c.va[g][0];
+                w[g][1] = c.va[g][1];
+                w[g][2] = c.vb[g][0];
+                w[g][3] = c.vb[g][1];
+            }
+            const bool last = c.last;
+            /* entry condition of the next panel; looked at only if `last` */
+            const int qn = (last && lag > 0 && q + 1 >= lag) ? q + 1 - lag : 0;
+            const int polled = __hip_atomic_load(cnt + (size_t)qn * CNT_STRIDE,
+                                                 __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            fill(f);
+#pragma unroll
+            for (int g = 0; g < Q; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double prod = pr[g][u] * w[g][u];
+                    if (ABL & 1) {
+                        if (u < on[g] && prod == 1.2345e300)
+                            ytile[rr[g][u]] = 1.0;
+                    } else if (u < on[g]) {
+                        unsafeAtomicAdd(&ytile[rr[g][u]], prod);
+                    }
+                }
+            if (last) {
+                ready = lag <= 0 || q + 1 < lag || polled >= n_x;
+                if ((tid & (WAVE - 1)) == 0) {
+                    /* the wave of the workgroup that finishes the panel last
+                     * arrives for all of them */
+                    const int old = atomicAdd(&wave_done[q & 7], 1);
+                    if (old == WAVES - 1) {
+                        wave_done[q & 7] = 0;
+                        phase_arrive(cnt + (size_t)q * CNT_STRIDE);
+                    }
+                }
+            }
+        };
+
+        sweep_chunk<Q> A, B, C;
+        fill(A);
+        fill(B);
+        for (;;) {
+            step(A, C);
+            if (B.p >= panels)
+                break;
+            step(B, A);
+            if (C.p >= panels)
+                break;
+            step(C, B);
+            if (A.p >= panels)
+                break;
+        }
+        __syncthreads();
+        const int64_t row0 = (int64_t)t * tile_rows;
+        for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
+            __builtin_nontemporal_store(ytile[i], y + row0 + i);
+        __syncthreads();
+    }
 }
 
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
@@ -521,70 +809,63 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         return -EINVAL;
     if (M == 0)
         return 0;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    HIP_RET(hipGetDevice(&dev));
-    HIP_RET(hipGetDeviceProperties(&prop, dev));
-    int grid = prop.multiProcessorCount * 2;
-    if (grid > P->tiles)
-        grid = P->tiles;
     const size_t lds = (size_t)P->tile_rows * sizeof(double);
-    if (!(variant & 8)) { /* default: one launch per panel */
-        HIP_RET(hipMemsetAsync(y, 0, (size_t)M * sizeof(double), s));
-        const bool small = (waves > 0 && waves < 8);
-        /* launch `step` handles the step-th NON-EMPTY bucket of every tile:
-         * a matrix whose rows reach over k panels needs k launches, all
-         * tiles busy in each of them */
-        const int abl = (variant >> 4) & 3;
-        const int un = (variant >> 8) & 15; /* tuning: unroll override */
-        for (int p = 0; p < P->max_nbk; ++p) {
-#define TP(NTHR, UNR)                                                          \
-    hipLaunchKernelGGL((k_tiles_one_panel<NTHR, 0, UNR>), dim3(P->tiles),     \
-                       dim3(NTHR), lds, s, M, P->tile_rows, P->panels, p,     \
-                       P->cb, P->nbk, P->col, P->rloc, P->val, x, y)
-            if (un == 1) { if (small) TP(256, 1); else TP(512, 1); continue; }
-            if (un == 2) { if (small) TP(256, 2); else TP(512, 2); continue; }
-            if (un == 4) { if (small) TP(256, 4); else TP(512, 4); continue; }
-#undef TP
-            if (abl == 1)
-                hipLaunchKernelGGL((k_tiles_one_panel<512, 1>), dim3(P->tiles),
-                                   dim3(512), lds, s, M, P->tile_rows,
-                                   P->panels, p, P->cb, P->nbk, P->col,
-                                   P->rloc, P->val, x, y);
-            else if (abl == 2)
-                hipLaunchKernelGGL((k_tiles_one_panel<512, 2>), dim3(P->tiles),
-                                   dim3(512), lds, s, M, P->tile_rows,
-                                   P->panels, p, P->cb, P->nbk, P->col,
-                                   P->rloc, P->val, x, y);
-            else if (abl == 3)
-                hipLaunchKernelGGL((k_tiles_one_panel<512, 3>), dim3(P->tiles),
-                                   dim3(512), lds, s, M, P->tile_rows,
-                                   P->panels, p, P->cb, P->nbk, P->col,
-                                   P->rloc, P->val, x, y);
-            else if (small)
-                hipLaunchKernelGGL((k_tiles_one_panel<256, 0, 4>),
-                                   dim3(P->tiles), dim3(256), lds, s, M,
-                                   P->tile_rows, P->panels, p, P->cb, P->nbk,
-                                   P->col, P->rloc, P->val, x, y);
-            else /* 512 lanes x 4 entries: 2.58 ms (x8: 2.65) on config 3 */
-                hipLaunchKernelGGL((k_tiles_one_panel<512, 0, 4>),
-                                   dim3(P->tiles), dim3(512), lds, s, M,
-                                   P->tile_rows, P->panels, p, P->cb, P->nbk,
-                                   P->col, P->rloc, P->val, x, y);
-        }
+    if (P->sweep) {
+        /* variant (tuning): bits 4-6 lag override (1..7), bit 7 no phase
+         * wait, bits 8-10 ablations, bit 11 one group of 4 per lane */
+        int lag = (variant >> 4) & 7;
+        if (lag == 0)
+            lag = 3;
+        if (variant & 128)
+            lag = 0;
+        HIP_RET(hipMemsetAsync(P->phase_cnt, 0, P->phase_cnt_bytes, s));
+#define SW(NTHR, QQ, A)                                                        \
+    do {                                                                       \
+        static bool big_lds_ok[64];                                            \
+        int dev_ = 0;                                                          \
+        HIP_RET(hipGetDevice(&dev_));                                          \
+        bool &big_lds_ok_ = big_lds_ok[dev_ & 63];                             \
+        if (!big_lds_ok_) { /* tiles above 64 KiB need the opt-in */           \
+            HIP_RET(hipFuncSetAttribute(                                       \
+                reinterpret_cast<const void *>(&k_tiles_sweep<NTHR, QQ, A>),   \
+                hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                TILE_ROWS_MAX * (int)sizeof(double)));                         \
+            big_lds_ok_ = true;                                                \
+        }                                                                      \
+        hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A>), dim3(P->grid),       \
+                           dim3(NTHR), lds, s, M, P->tile_rows, P->tiles,      \
+                           P->panels, P->shift, lag, SWEEP_SPIN_MAX,           \
+                           (unsigned)P->total, P->bptr, P->blen, P->ent,       \
+                           P->val, x, y, P->phase_cnt);                        \
+    } while (0)
+        const int abl = (variant >> 8) & 7;
+        const int two = !((variant >> 11) & 1); /* 2 groups of 4 per lane */
+        if (abl == 1) { SW(256, 1, 1); }
+        else if (abl == 2) { SW(256, 1, 2); }
+        else if (abl == 3) { SW(256, 1, 3); }
+        else if (abl == 4) { SW(256, 1, 4); }
+        else if (abl == 7) { SW(256, 1, 7); }
+        else if (waves > 0 && waves < 8) { if (two) SW(256, 2, 0); else SW(256, 1, 0); }
+        else { if (two) SW(512, 2, 0); else SW(512, 1, 0); }
+#undef SW
         return hip_errno(hipGetLastError());
     }
-#define TL(A) hipLaunchKernelGGL(k_tiles_spmv<A>, dim3(grid), dim3(TILE_THREADS), \
-                                 lds, s, M, P->tile_rows, P->tiles, P->tptr,     \
-                                 P->col, P->rloc, P->val, x, y)
-    switch ((variant >> 4) & 7) {
-    case 1: TL(1); break;
-    case 2: TL(2); break;
-    case 4: TL(4); break;
-    case 5: TL(5); break;
-    default: TL(0); break;
+    HIP_RET(hipMemsetAsync(y, 0, (size_t)M * sizeof(double), s));
+    /* launch `step` handles the step-th NON-EMPTY bucket of every tile: a
+     * matrix whose rows reach over k panels needs k launches, all tiles busy
+     * in each of them */
+    for (int p = 0; p < P->max_nbk; ++p) {
+        if (waves > 0 && waves < 8)
+            hipLaunchKernelGGL((k_tiles_one_panel<256, 4>), dim3(P->tiles),
+                               dim3(256), lds, s, M, P->tile_rows, P->panels,
+                               P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,
+                               P->val, x, y);
+        else /* 512 lanes x 4 entries: 2.58 ms (x8: 2.65) on config 3 */
+            hipLaunchKernelGGL((k_tiles_one_panel<512, 4>), dim3(P->tiles),
+                               dim3(512), lds, s, M, P->tile_rows, P->panels,
+                               P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,
+                               P->val, x, y);
     }
-#undef TL
     return hip_errno(hipGetLastError());
 }
 
@@ -600,5 +881,7 @@ int panels_from_hll(const spmv_hll_dev *H, int panel_cols, spmv_panels **out) {
 
 int64_t panels_nnz(const spmv_panels *P) { return P ? P->nnz : 0; }
 int panels_count(const spmv_panels *P) { return P ? P->panels : 0; }
-int panels_steps(const spmv_panels *P) { return P ? P->max_nbk : 0; }
+int panels_steps(const spmv_panels *P) {
+    return P ? (P->sweep ? 1 : P->max_nbk) : 0;
+}
 int panels_tiles(const spmv_panels *P) { return P ? P->tiles : 0; }

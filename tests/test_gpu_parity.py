@@ -283,8 +283,10 @@ def test_config3_random_hll_full_size_properties(W):
     ys = {}
     dH.build_panels(0)  # the 2-D blocked path, bench.py's pick for W = N
     info = dH.panels_info()
-    assert info["entries"] == M * K and info["tiles"] == (M + 1023) // 1024
-    assert info["steps"] == (info["panels"] if W >= N else info["steps"])
+    # default schedule: one persistent launch, 2 workgroups per CU, each
+    # owning one row tile per round (10M rows: 2 rounds of 512 tiles)
+    assert info["entries"] == M * K and info["steps"] == 1
+    assert 512 < info["tiles"] <= 1024 and info["panels"] == 39
     for tag, fn in (("hll1", lambda: dH.launch(1, d_x.ptr, d_y.ptr)),
                     ("hll2", lambda: dH.launch(2, d_x.ptr, d_y.ptr)),
                     ("hll4", lambda: dH.launch(S.HLL_KERNEL_PANELS, d_x.ptr,
@@ -315,14 +317,27 @@ PANEL_CASES = [
     ("kkt_long_rows", S.SYNTH_KKT, 9_000, 9_000, 16, 9000, 256),
     ("very_long_rows", S.SYNTH_RANDOM, 70, 4_000, 3000, 1 << 30, 1024),
     ("one_panel", S.SYNTH_RANDOM, 1_000, 1_000, 8, 100, 0),
+    ("more_tiles_than_groups", S.SYNTH_RANDOM, 40_000, 50_000, 8, 1 << 30, 4096),
+    ("empty_rows_banded", S.SYNTH_STENCIL, 27_000, 27_000, 7, 30, 128),
     ("tiny", S.SYNTH_RANDOM, 3, 64, 5, 64, 16),
 ]
 
 
+@pytest.fixture
+def default_panel_schedule():
+    yield
+    S.set_panel_schedule(True)
+
+
+@pytest.mark.parametrize("sweep", [True, False], ids=["sweep", "steps"])
 @pytest.mark.parametrize("tag,kind,M,N,K,W,pc", PANEL_CASES)
-def test_column_panel_path(tag, kind, M, N, K, W, pc):
+def test_column_panel_path(tag, kind, M, N, K, W, pc, sweep,
+                           default_panel_schedule):
     """Extra kernel (spmv_engine.h, panels.hip): entries bucketed by (row
-    tile, column panel), y tile accumulated in LDS with ds_add_f64."""
+    tile, column panel), y tile accumulated in LDS with ds_add_f64; both
+    schedules (one persistent launch with phase counters / one launch per
+    panel step)."""
+    S.set_panel_schedule(sweep)
     IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
     x = O.synth_x(7, 0, N)
     y_ref = O.csr_spmv(IRP, JA, AS, x)
@@ -333,13 +348,20 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc):
     with pytest.raises(OSError):  # not built yet
         dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
     dA.build_panels(pc)
-    for variant in (0, 8):  # per-panel launches / one persistent launch
+    info = dA.panels_info()
+    assert info["entries"] == int(IRP[-1])
+    assert (info["steps"] == 1) if sweep else (info["steps"] <= info["panels"])
+    # sweep tuning bits (panels.hip): 16 = workgroups at most one panel
+    # apart, 128 = no phase wait at all, 2048 = one group of 4 per lane
+    for variant, waves in (((0, 8), (0, 4), (16, 8), (128, 4), (2048, 8))
+                           if sweep else ((0, 8), (0, 4))):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         for _ in range(2):  # repeated launches must not accumulate
-            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant)
+            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant,
+                      waves_per_block=waves)
         S.stream_sync()
         assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
-                      (tag, "csr panels", variant))
+                      (tag, "csr panels", variant, waves))
     for cm in (True, False):
         H = S.csr_to_hll(A, cm)
         dH = S.HllDevice.upload(H, cm)
