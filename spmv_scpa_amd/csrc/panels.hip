@@ -846,7 +846,17 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         else if (abl == 4) { SW(256, 1, 4); }
         else if (abl == 7) { SW(256, 1, 7); }
         else if (waves > 0 && waves < 8) { if (two) SW(256, 2, 0); else SW(256, 1, 0); }
-        else { if (two) SW(512, 2, 0); else SW(512, 1, 0); }
+        else if (waves >= 8) { if (two) SW(512, 2, 0); else SW(512, 1, 0); }
+        else {
+            /* default: the chunk (threads x groups x 4 slots) that wastes
+             * few lanes on the average bucket; 512 x 2 measured best on
+             * config 3 (8000 entries per bucket) */
+            const double per_bucket =
+                (double)P->nnz / ((double)P->tiles * (double)P->panels);
+            if (per_bucket >= 6000.0) SW(512, 2, 0);
+            else if (per_bucket >= 3000.0) SW(512, 1, 0);
+            else SW(256, 1, 0);
+        }
 #undef SW
         return hip_errno(hipGetLastError());
     }

@@ -21,6 +21,9 @@ import spmv_scpa_amd as S  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--cols", type=int, default=0,
+                    help="columns (default = rows); > rows emulates one "
+                         "rank's shard of a multi-GPU problem")
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--family", default="random")
     ap.add_argument("--windows", default="2048,16384,1048576,0")
@@ -36,7 +39,8 @@ def main():
     a = ap.parse_args()
     kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3,
             "stencil": 4}[a.family]
-    M = N = a.rows
+    M = a.rows
+    N = a.cols or a.rows
     d_x = S.DevBuffer(N * 8)
     d_y = S.DevBuffer(M * 8)
     S.dev_fill_synth(d_x.ptr, N, 7)
