@@ -230,8 +230,9 @@ class ShardedSpmv:
 def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
     """Secondary numbers for the same JSON line (1 GPU only): the column-
     window sweep of the headline family (W = N is the worst case: every 8 B
-    gather of x pulls a 128 B line through the fabric), both HLL kernels and
-    the CSR sub-wave kernel, BASELINE config 2 (banded CSR, flushed) and the
+    gather of x pulls a 128 B line through the fabric), both HLL kernels, the
+    CSR sub-wave and stream kernels and the blocked path where the autotuner
+    picks it, BASELINE config 2 (banded CSR, flushed) and the
     KKT-like stand-in for config 4."""
     st = torch.cuda.current_stream().cuda_stream
     out = {}
@@ -266,8 +267,13 @@ def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
             for k in (1, 2):
                 row("%s hll_%s" % (wname, S.HLL_KERNEL_NAMES[k]), dH,
                     med(dH.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-            row("%s csr_subwave_row" % wname, dA,
-                med(dA.time(2, dx, dy, 2, 10, 0, args.waves, stream=st)))
+            for k in (2, 4):
+                row("%s csr_%s" % (wname, S.CSR_KERNEL_NAMES[k]), dA,
+                    med(dA.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+            best, _ = dH.autotune(dx, dy, True)
+            if best == S.HLL_KERNEL_PANELS:  # else: one of the rows above
+                row("%s hll_tile_panels (autotuned pick)" % wname, dH,
+                    med(dH.time(best, dx, dy, 2, 10, 0, args.waves, stream=st)))
             dH.release()
             dA.release()
         except OSError as e:  # e.g. out of memory on a smaller card
