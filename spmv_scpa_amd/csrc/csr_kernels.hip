@@ -224,6 +224,36 @@ __global__ void k_csr_block_row(int r0, int r1, const int *__restrict__ irp,
 #define TSKEW(k) ((k) + ((k) >> 5))
 #define STREAM_LDS (STREAM_NNZ + STREAM_NNZ / 32 + 1)
 
+template <int T>
+__device__ __forceinline__ void stream_rows(int tid, int rows, const int *rowptr,
+                                            const int *s_ja, const double *s_val,
+                                            const double *__restrict__ x,
+                                            double *__restrict__ y_range) {
+    const int r = tid / T, sub = tid % T;
+    double acc = 0.0;
+    if (r < rows) {
+        const int rz = rowptr[r + 1];
+        int k = rowptr[r] + sub;
+        for (; k + 3 * T < rz; k += 4 * T) {
+            const int c0 = s_ja[TSKEW(k)], c1 = s_ja[TSKEW(k + T)];
+            const int c2 = s_ja[TSKEW(k + 2 * T)], c3 = s_ja[TSKEW(k + 3 * T)];
+            const double v0 = s_val[TSKEW(k)], v1 = s_val[TSKEW(k + T)];
+            const double v2 = s_val[TSKEW(k + 2 * T)];
+            const double v3 = s_val[TSKEW(k + 3 * T)];
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            acc += v0 * x0;
+            acc += v1 * x1;
+            acc += v2 * x2;
+            acc += v3 * x3;
+        }
+        for (; k < rz; k += T)
+            acc += s_val[TSKEW(k)] * x[s_ja[TSKEW(k)]];
+    }
+    acc = group_sum<T>(acc); /* teams are aligned: idle lanes add 0 */
+    if (r < rows && sub == 0)
+        y_range[r] = acc;
+}
+
 __global__ void __launch_bounds__(STREAM_THREADS)
     k_csr_stream(const int *__restrict__ rowblk,
                  const unsigned char *__restrict__ mode,
@@ -287,25 +317,16 @@ __global__ void __launch_bounds__(STREAM_THREADS)
             }
         }
         __syncthreads();
-        if (tid < rows) {
-            const int ra = rowptr[tid], rz = rowptr[tid + 1];
-            double acc = 0.0;
-            int k = ra;
-            for (; k + 4 <= rz; k += 4) {
-                const int c0 = s_ja[TSKEW(k)], c1 = s_ja[TSKEW(k + 1)];
-                const int c2 = s_ja[TSKEW(k + 2)], c3 = s_ja[TSKEW(k + 3)];
-                const double v0 = s_val[TSKEW(k)], v1 = s_val[TSKEW(k + 1)];
-                const double v2 = s_val[TSKEW(k + 2)], v3 = s_val[TSKEW(k + 3)];
-                const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-                acc += v0 * x0;
-                acc += v1 * x1;
-                acc += v2 * x2;
-                acc += v3 * x3;
-            }
-            for (; k < rz; ++k)
-                acc += s_val[TSKEW(k)] * x[s_ja[TSKEW(k)]];
-            y[row_a + tid] = acc;
-        }
+        /* T lanes per row so that all 256 lanes work when the range has
+         * few rows (64 rows of 32 entries: T = 4); lane `sub` of a team takes
+         * entries sub, sub + T, ... -- neighbours in the row, usually the
+         * same line of x */
+        if (rows * 4 <= STREAM_THREADS)
+            stream_rows<4>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
+        else if (rows * 2 <= STREAM_THREADS)
+            stream_rows<2>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
+        else
+            stream_rows<1>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
         return;
     }
 
