@@ -45,7 +45,6 @@
 #include "hip_common.h"
 
 #define TILE_ROWS_STEPS 1024 /* "steps" schedule: 8 KiB of LDS */
-#define TILE_ROWS_MAX 10208  /* "sweep" schedule: 2 x 79.75 KiB per CU */
 #define SWEEP_WG_PER_CU 2
 #define SWEEP_SPIN_MAX 4096  /* polls before a wait gives up (perf only) */
 #define CNT_STRIDE 32        /* one phase counter per 128-B line */
@@ -59,6 +58,7 @@ struct spmv_panels {
     int tiles;       /* row tiles */
     int sweep;       /* built for the persistent schedule */
     int grid;        /* sweep: workgroups of the launch */
+    int wgs_per_cu;  /* sweep: workgroups sharing a CU's LDS */
     int64_t nnz;     /* entries kept */
     int64_t total;   /* slots of ENT/VAL in use (bucket padding included) */
     unsigned *ent;   /* [nnz] row-in-tile << shift | column-in-panel */
@@ -299,19 +299,45 @@ extern "C" int spmv_set_panel_schedule(int sweep) {
     return 0;
 }
 
-static int sweep_grid(void) {
+/* workgroups per CU of the sweep launch: 0 = choose per matrix */
+static int sweep_wgs_override(void) {
+    if (const char *ev = getenv("SPMV_SWEEP_WGS")) { /* tuning override */
+        int o = atoi(ev);
+        if (o >= 1 && o <= 8)
+            return o;
+    }
+    return 0;
+}
+
+/* rows of y one workgroup can hold when `per_cu` of them share a CU's LDS */
+static int sweep_tile_rows_max(int per_cu) {
+    return (int)((160 * 1024 - 64 * per_cu) / per_cu / 8 / 32 * 32);
+}
+
+static int device_cus(void) {
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipGetDeviceProperties(&prop, dev) != hipSuccess)
-        return 512;
-    int per_cu = SWEEP_WG_PER_CU;
-    if (const char *ev = getenv("SPMV_SWEEP_WGS")) { /* tuning override */
-        int o = atoi(ev);
-        if (o >= 1 && o <= 8)
-            per_cu = o;
-    }
-    return prop.multiProcessorCount * per_cu;
+        return 256;
+    return prop.multiProcessorCount;
+}
+
+/* tile height of the sweep schedule: the fewest rounds of (grid x tile_max)
+ * rows that cover M, rows spread evenly over them */
+static long long sweep_tile_rows(int M, int grid, int tile_max) {
+    const long long rounds = ((long long)M + (long long)grid * tile_max - 1) /
+                             ((long long)grid * tile_max);
+    const long long wg = (rounds > 0 ? rounds : 1) * grid;
+    long long tr = (((long long)M + wg - 1) / wg + 31) / 32 * 32;
+    return tr < 32 ? 32 : tr;
+}
+
+static int bits_for(long long n) { /* smallest b with 2^b >= n */
+    int b = 0;
+    while ((1ll << b) < n)
+        ++b;
+    return b;
 }
 
 static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
@@ -325,34 +351,45 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
     const int sweep = panel_schedule();
     /* tile height.  steps: 1024 rows measured best (2.62 ms on config 3;
      * 3.3 ms at 8192): many small workgroups overlap their load / gather /
-     * store phases.  sweep: the fewest rounds of (grid x TILE_ROWS_MAX) rows
-     * that cover M, rows spread evenly over them. */
+     * store phases.  sweep: sweep_tile_rows(). */
     long long tr = TILE_ROWS_STEPS;
-    int grid = 0;
+    int grid = 0, tile_max = TILE_ROWS_STEPS, per_cu = 0;
+    int want_shift = 18; /* 2^18 columns = 2 MiB of x: half of an XCD's L2 */
+    if (panel_cols > 0)
+        want_shift = bits_for((long long)panel_cols + 1) - 1; /* floor(log2) */
     if (sweep) {
-        grid = sweep_grid();
-        const long long rounds =
-            ((long long)M + (long long)grid * TILE_ROWS_MAX - 1) /
-            ((long long)grid * TILE_ROWS_MAX);
-        const long long wg = (rounds > 0 ? rounds : 1) * grid;
-        tr = (((long long)M + wg - 1) / wg + 31) / 32 * 32;
-        if (tr < 32)
-            tr = 32;
+        /* one 1024-lane workgroup per CU with a 160 KiB tile, or two of up
+         * to 512 lanes with 80 KiB tiles.  The tall tile halves the panel
+         * (row and column index share 32 bits) but puts twice the entries
+         * on a line of x, which the column-sorted buckets turn into fewer
+         * L2 requests: 1.61 vs 1.77 ms on config 3.  It needs buckets that
+         * fill its 4096-slot chunks, so it is taken only above 4000 entries
+         * per bucket (80 M columns, 1071 per bucket: 4.85 vs 3.35 ms). */
+        const int cus = device_cus();
+        per_cu = sweep_wgs_override();
+        if (per_cu == 0) {
+            const int tm = sweep_tile_rows_max(1);
+            const long long tr1 = sweep_tile_rows(M, cus, tm);
+            int sh = want_shift;
+            if (sh > 32 - bits_for(tr1))
+                sh = 32 - bits_for(tr1);
+            const double tiles1 = (double)(((long long)M + tr1 - 1) / tr1);
+            const double panels1 =
+                (double)((((int64_t)(N > 0 ? N : 1) - 1) >> sh) + 1);
+            per_cu = (double)slots / (tiles1 * panels1) >= 4000.0
+                         ? 1 : SWEEP_WG_PER_CU;
+        }
+        grid = cus * per_cu;
+        tile_max = sweep_tile_rows_max(per_cu);
+        tr = sweep_tile_rows(M, grid, tile_max);
     }
     if (const char *ev = getenv("SPMV_TILE_ROWS")) { /* tuning override */
         long long o = atoll(ev);
-        if (o >= 32 && o <= TILE_ROWS_MAX)
+        if (o >= 32 && o <= tile_max)
             tr = o / 32 * 32;
     }
-    int rbits = 0;
-    while ((1ll << rbits) < tr)
-        ++rbits;
-    int shift = 18; /* 2^18 columns = 2 MiB of x: half of an XCD's L2 */
-    if (panel_cols > 0) {
-        shift = 0;
-        while ((1 << (shift + 1)) <= panel_cols && shift < 30)
-            ++shift;
-    }
+    const int rbits = bits_for(tr);
+    int shift = want_shift;
     if (shift > 32 - rbits) /* row-in-tile and column-in-panel share a word */
         shift = 32 - rbits;
     const int panels = (int)((((int64_t)(N > 0 ? N : 1) - 1) >> shift) + 1);
@@ -370,6 +407,7 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
     P->tiles = tiles;
     P->sweep = sweep;
     P->grid = sweep ? (grid < tiles ? grid : (tiles > 0 ? tiles : 1)) : 0;
+    P->wgs_per_cu = per_cu;
     uint64_t *key[2] = {NULL, NULL};
     unsigned *idx[2] = {NULL, NULL};
     uint64_t *skey = NULL;
@@ -814,8 +852,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         /* variant (tuning): bits 4-6 lag override (1..7), bit 7 no phase
          * wait, bits 8-10 ablations, bit 11 one group of 4 per lane */
         int lag = (variant >> 4) & 7;
-        if (lag == 0)
-            lag = 3;
+        if (lag == 0) /* measured best: 3 for 2 MiB panels, 6 for 1 MiB */
+            lag = P->wgs_per_cu == 1 ? 6 : 3;
         if (variant & 128)
             lag = 0;
         HIP_RET(hipMemsetAsync(P->phase_cnt, 0, P->phase_cnt_bytes, s));
@@ -829,7 +867,7 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
             HIP_RET(hipFuncSetAttribute(                                       \
                 reinterpret_cast<const void *>(&k_tiles_sweep<NTHR, QQ, A>),   \
                 hipFuncAttributeMaxDynamicSharedMemorySize,                    \
-                TILE_ROWS_MAX * (int)sizeof(double)));                         \
+                160 * 1024 - 64));                                             \
             big_lds_ok_ = true;                                                \
         }                                                                      \
         hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A>), dim3(P->grid),       \
@@ -845,6 +883,7 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         else if (abl == 3) { SW(256, 1, 3); }
         else if (abl == 4) { SW(256, 1, 4); }
         else if (abl == 7) { SW(256, 1, 7); }
+        else if (P->wgs_per_cu == 1) { if (variant & 2048) SW(1024, 2, 0); else SW(1024, 1, 0); }
         else if (waves > 0 && waves < 8) { if (two) SW(256, 2, 0); else SW(256, 1, 0); }
         else if (waves >= 8) { if (two) SW(512, 2, 0); else SW(512, 1, 0); }
         else {
