@@ -54,6 +54,13 @@ def parse_args():
                     help="N>1: split each shard into row chunks and overlap "
                          "the all-gather of chunk c with the kernel of c+1 "
                          "(0 = auto: 4 when N > 1, else 1)")
+    ap.add_argument("--shards-per-gpu", type=int, default=1,
+                    help="logical shards of --rows-per-gpu rows held by each "
+                         "GPU (each its own int32-safe matrix)")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE config 5 as a FIXED problem: 8 logical "
+                         "shards of --rows-per-gpu rows (80M x 80M), 8/N per "
+                         "GPU; strong scaling over N = 1, 2, 4, 8")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise RCCL and run the y exchange even with "
                          "one rank (exercises the multi-GPU path on a "
@@ -202,7 +209,13 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    Mloc, K = args.rows_per_gpu, args.nnz_row
+    L = args.shards_per_gpu
+    if args.strong:
+        if 8 % world:
+            raise SystemExit("--strong needs 1, 2, 4 or 8 GPUs")
+        L = 8 // world
+    Mshard, K = args.rows_per_gpu, args.nnz_row
+    Mloc = Mshard * L  # rows of this rank
     Mglob = Mloc * world
     Nglob = Mglob
     W = args.window if args.window > 0 else 2 * Nglob  # >= 2N: anywhere
@@ -211,53 +224,63 @@ def main():
             "stencil": S.SYNTH_STENCIL}[args.family]
     row0 = rank * Mloc
 
-    # ---- build the shard in HBM (device-side generator + converter) ----
+    # ---- build the shard(s) in HBM (device-side generator + converter) ----
     t_setup = time.time()
-    dA = S.CsrDevice.generate(kind, Mloc, Nglob, K, W, row0, MATRIX_SEED)
     x = torch.empty(Nglob, dtype=torch.float64, device=dev)
     y = torch.zeros(Mglob, dtype=torch.float64, device=dev)
     S.dev_fill_synth(x.data_ptr(), Nglob, X_SEED, 0,
                      torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     tuned = None
+    mats, nnz_local, slots = [], 0, 0
+    for j in range(L):
+        dA = S.CsrDevice.generate(kind, Mshard, Nglob, K, W, row0 + j * Mshard,
+                                  MATRIX_SEED)
+        nnz_local += dA.NZ
+        if args.format == "hll":
+            col_major = True if args.kernel in (-1, 4) else \
+                S.HLL_KERNEL_COL_MAJOR[args.kernel]
+            m = dA.to_hll(col_major)
+            slots += m.slots
+            dA.release()
+        else:
+            m = dA
+            slots += dA.NZ
+        mats.append(m)
+    mat = mats[0]
     if args.format == "hll":
-        col_major = True if args.kernel in (-1, 4) else \
-            S.HLL_KERNEL_COL_MAJOR[args.kernel]
-        mat = dA.to_hll(col_major)
-        nnz_local, slots = dA.NZ, mat.slots
-        dA.release()
         labels, prefix = S.HLL_KERNEL_LABELS, "hll_"
     else:
-        mat = dA
-        nnz_local, slots = dA.NZ, dA.NZ
         labels, prefix = S.CSR_KERNEL_LABELS, "csr_"
     if args.kernel >= 0:
         kernel = args.kernel
-        if labels[kernel] == "tile_panels":
-            mat.build_panels(0)
     else:
-        # kernel chosen by measurement (spmv_*_autotune): the coalesced
-        # kernels and, if they run far below the stream rate, the 2-D
-        # blocked path.  Every rank must take the same decision.
+        # kernel chosen by measurement (spmv_*_autotune) on the first shard:
+        # the coalesced kernels and, if they run far below the stream rate,
+        # the 2-D blocked path.  Every rank must take the same decision.
         kernel, tuned = mat.autotune(x.data_ptr(), y.data_ptr() + 8 * row0)
         if world > 1:
             kk = torch.tensor([kernel], device=dev)
             dist.broadcast(kk, 0)
-            if int(kk.item()) != kernel:
-                kernel = int(kk.item())
-                if labels[kernel] == "tile_panels":
-                    mat.build_panels(0)
+            kernel = int(kk.item())
+    if labels[kernel] == "tile_panels":
+        for m in mats:
+            if m.panels_info() is None:
+                m.build_panels(0)
     kname = prefix + labels[kernel]
     pinfo = mat.panels_info() if labels[kernel] == "tile_panels" else None
-    launches_per_step = pinfo["steps"] if pinfo else 1
-    alg_bytes = mat.algorithmic_bytes  # per launch, per GPU
+    launches_per_step = (pinfo["steps"] if pinfo else 1) * L
+    # per step and GPU; one launch per logical shard
+    alg_bytes = sum(m.algorithmic_bytes for m in mats)
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
-    if labels[kernel] == "tile_panels":
-        chunks = 1  # the blocked path runs whole shards only
-    sharded = D.ShardedSpmv(mat, kernel, rank, world, Mloc, x, y,
+    if labels[kernel] == "tile_panels" or L > 1:
+        chunks = 1  # the blocked path runs whole shards only; with logical
+        #             shards the shard is the unit of overlap
+    sharded = D.ShardedSpmv(mats if L > 1 else mat, kernel, rank, world, Mloc,
+                            x, y,
                             waves_per_block=args.waves, chunks=chunks,
                             force_exchange=args.force_exchange)
 
@@ -318,6 +341,8 @@ def main():
                 % (args.family, args.format.upper(), Mloc, Nglob, Mglob, Nglob,
                    K, "N (anywhere)" if args.window <= 0 else str(W),
                    MATRIX_SEED))
+    if L > 1:
+        workload += ", %d logical shards of %d rows per GPU" % (L, Mshard)
     traffic = measured_traffic(workload, kname) if world == 1 else None
     out = {
         "metric": "fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), "
@@ -329,7 +354,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -339,7 +364,8 @@ def main():
             "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
             if tuned is not None else "fixed by --kernel",
             "kernel_launches_per_step": launches_per_step,
-            "rows_per_gpu": Mloc, "nnz_per_row": K, "nnz_global": nnz_global,
+            "rows_per_gpu": Mloc, "logical_shards_per_gpu": L,
+            "nnz_per_row": K, "nnz_global": nnz_global,
             "stored_slots_per_gpu": slots,
             "partition": "contiguous row ranges, x replicated, in-place "
                          "all-gather(y) over RCCL" if world > 1 else "single GPU",
@@ -367,7 +393,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.family, K, W)
-    if world == 1 and not args.no_extras:
+    if world == 1 and L == 1 and not args.no_extras:
         out["extras"] = D.extra_measurements(S, torch, mat, args, x, y, Mloc,
                                              Nglob, K, kind)
     print(json.dumps(out))

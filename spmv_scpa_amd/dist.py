@@ -137,7 +137,12 @@ class StagedExchange:
 class ShardedSpmv:
     """One rank's part of y = A x over `world` GPUs.
 
-    mat            CsrDevice or HllDevice holding rows [row0, row0+rows)
+    mat            CsrDevice or HllDevice holding rows [row0, row0+rows), or
+                   a list of L such handles of rows/L rows each ("logical
+                   shards": the fixed 80M-row problem of config 5 is 8 shards
+                   of 10M rows, 8/world per GPU, each int32-safe); a logical
+                   shard is then the unit of overlap -- shard c is all-gathered
+                   while shard c+1 computes -- and `chunks` is ignored
     x, y           full-length torch tensors on this rank's GPU
     chunks         > 1: overlap the exchange of chunk c with the kernel of c+1
     """
@@ -147,12 +152,24 @@ class ShardedSpmv:
                  force_exchange=False):
         import torch
         self.torch = torch
+        self.mats = list(mat) if isinstance(mat, (list, tuple)) else None
+        if self.mats is not None and len(self.mats) == 1:
+            mat, self.mats = self.mats[0], None
         self.mat, self.kernel = mat, kernel
         self.rank, self.world, self.rows = rank, world, rows_per_rank
         self.x, self.y = x, y
         self.waves = waves_per_block
         self.row0 = rank * rows_per_rank
-        self.bounds = chunk_bounds(rows_per_rank, chunks)
+        if self.mats is not None:
+            L = len(self.mats)
+            if rows_per_rank % L or (rows_per_rank // L) % HACK:
+                raise ValueError("logical shards must split the rank's rows "
+                                 "evenly at multiples of %d" % HACK)
+            self.shard_rows = rows_per_rank // L
+            self.bounds = [self.shard_rows * i for i in range(L + 1)]
+            mat = self.mats[0]
+        else:
+            self.bounds = chunk_bounds(rows_per_rank, chunks)
         if mode is None:
             mode = "allgather" if len(self.bounds) <= 2 else "staged"
         if mode == "staged":
@@ -178,7 +195,12 @@ class ShardedSpmv:
         d_x = self.x.data_ptr()
         d_y = (self.y.data_ptr() + 8 * self.row0 if out is None
                else out.data_ptr() - 8 * a)
-        if a == 0 and b == self.rows:
+        if self.mats is not None:  # one whole logical shard per call
+            assert a % self.shard_rows == 0 and b - a == self.shard_rows
+            self.mats[a // self.shard_rows].launch(
+                self.kernel, d_x, d_y + 8 * a, waves_per_block=self.waves,
+                stream=st)
+        elif a == 0 and b == self.rows:
             self.mat.launch(self.kernel, d_x, d_y,
                             waves_per_block=self.waves, stream=st)
         elif self.is_hll:
@@ -194,7 +216,11 @@ class ShardedSpmv:
         if events:
             events[0].record()
         if self.world == 1 and not self.force_exchange:
-            self.compute(0, self.rows)
+            for c in range(len(self.bounds) - 1) if self.mats else (None,):
+                if c is None:
+                    self.compute(0, self.rows)
+                else:
+                    self.compute(self.bounds[c], self.bounds[c + 1])
             if events:
                 events[1].record()
             return

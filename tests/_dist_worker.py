@@ -43,8 +43,17 @@ def main():
         else:
             out.copy_(res)
 
-    sh = D.ShardedSpmv(None, 0, rank, world, rows_per_rank, x, y,
-                       chunks=chunks, mode=mode, compute=compute)
+    if mode == "shards":
+        # `chunks` logical shards per rank (bench.py --strong): the shard is
+        # the unit of overlap, whatever `chunks` says
+        sh = D.ShardedSpmv([object()] * chunks, 0, rank, world, rows_per_rank,
+                           x, y, chunks=1, compute=compute)
+        assert sh.mode == ("staged" if chunks > 1 else "allgather")
+        assert sh.bounds == [rows_per_rank // chunks * i
+                             for i in range(chunks + 1)]
+    else:
+        sh = D.ShardedSpmv(None, 0, rank, world, rows_per_rank, x, y,
+                           chunks=chunks, mode=mode, compute=compute)
     for it in range(3):  # iterate: y of step k feeds nothing here, but the
         y.fill_(float("nan"))  # exchange must complete every time
         sh.step()

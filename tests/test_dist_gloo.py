@@ -51,7 +51,9 @@ def run_world(world, mode, chunks, rows):
                                                (3, "p2p", 3),
                                                (2, "staged", 4),
                                                (3, "staged", 5),
-                                               (2, "staged", 3)])
+                                               (2, "staged", 3),
+                                               (2, "shards", 4),
+                                               (2, "shards", 1)])
 def test_sharded_spmv_gloo(world, mode, chunks):
     run_world(world, mode, chunks, rows=640)
 

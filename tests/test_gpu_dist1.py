@@ -14,7 +14,13 @@ import spmv_scpa_amd as S
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("extra", [[], ["--chunks", "4"]])
+@pytest.mark.parametrize("extra", [
+    [], ["--chunks", "4"],
+    # logical shards (the fixed-problem form of config 5): 4 matrices per
+    # GPU, each all-gathered while the next one computes
+    ["--shards-per-gpu", "4"],
+    ["--shards-per-gpu", "2", "--kernel", "4", "--window", "0"],
+])
 def test_bench_through_torchrun_one_rank(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -30,3 +36,8 @@ def test_bench_through_torchrun_one_rank(extra):
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "GFLOP/s"
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["frac"] > 0
+    if "--shards-per-gpu" in extra:
+        L = int(extra[extra.index("--shards-per-gpu") + 1])
+        assert j["config"]["logical_shards_per_gpu"] == L
+        assert j["config"]["rows_per_gpu"] == 320000 * L
+        assert j["config"]["exchange"] == "staged"
