@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
     # GPU, each all-gathered while the next one computes
     ["--shards-per-gpu", "4"],
     ["--shards-per-gpu", "2", "--kernel", "4", "--window", "0"],
+    # the blocked path with an exchange splits the rank's rows in two by itself
+    ["--kernel", "4", "--window", "0", "--expect-shards", "2"],
 ])
 def test_bench_through_torchrun_one_rank(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -28,7 +30,12 @@ def test_bench_through_torchrun_one_rank(extra):
            "--master-port", "29577", os.path.join(S.ROOT, "bench.py"),
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu",
            "320000", "--window", "4096", "--kernel", "2", "--force-exchange",
-           "--no-cpu-baseline", "--no-extras"] + extra
+           "--no-cpu-baseline", "--no-extras"]
+    expect = None
+    if "--expect-shards" in extra:
+        i = extra.index("--expect-shards")
+        expect, extra = int(extra[i + 1]), extra[:i] + extra[i + 2:]
+    cmd += extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -40,4 +47,8 @@ def test_bench_through_torchrun_one_rank(extra):
         L = int(extra[extra.index("--shards-per-gpu") + 1])
         assert j["config"]["logical_shards_per_gpu"] == L
         assert j["config"]["rows_per_gpu"] == 320000 * L
+        assert j["config"]["exchange"] == "staged"
+    if expect:
+        assert j["config"]["logical_shards_per_gpu"] == expect
+        assert j["config"]["rows_per_gpu"] == 320000
         assert j["config"]["exchange"] == "staged"
