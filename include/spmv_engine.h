@@ -69,13 +69,17 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
 /*
  * Extra kernel id of both formats: the 2-D blocked path (no reference
  * counterpart, panels.hip).  The entries are additionally stored bucketed by
- * (row tile of 1024 rows, column panel of 2^18 columns = 2 MiB of x);
- * one launch per panel keeps the x gathers inside the XCD L2s while the
- * tile's slice of y accumulates in LDS.  Pays off only when rows reach far
- * beyond an L2 of x (2.2x on config 3 with columns anywhere; slower on
- * matrices with locality); costs 14 B per entry of extra HBM.  Build with
+ * (row tile, column panel of up to 2^18 columns = 2 MiB of x), 12 B each:
+ * a row tile's slice of y accumulates in LDS while the x gathers of a panel
+ * stay inside the XCD L2s.  Default schedule "sweep": one persistent launch,
+ * every workgroup keeps its tile in LDS across all panels, per-XCD phase
+ * counters (bounded waits) keep the workgroups on neighbouring panels.
+ * Pays off only when rows reach far beyond an L2 of x (3.6x on config 3 with
+ * columns anywhere; slower on matrices with locality -- use
+ * spmv_*_autotune); costs 12 B per entry of extra HBM.  Build with
  * spmv_*_build_panels() first (panel_cols = 0: default width), then launch
- * this id.  opts.variant bit 3 selects the single-launch persistent form.
+ * this id (whole matrix only).  opts.variant carries tuning bits
+ * (panels.hip), opts.waves_per_block < 8 selects 256-lane workgroups.
  */
 #define SPMV_CSR_KERNEL_PANELS 5
 #define SPMV_HLL_KERNEL_PANELS 4
