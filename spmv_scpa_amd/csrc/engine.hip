@@ -22,6 +22,70 @@
 int g_csr_waves = 8; /* 512-lane workgroups measured best on MI355X */
 int g_hll_waves = 8;
 
+/*
+ * The 2-D blocked path as a candidate.  `*bms` is the best direct kernel's
+ * time on entry.  Near the stream rate (within 1.4x of it at 7 TB/s) nothing
+ * is built.  Otherwise the "steps" schedule is built and timed: column-
+ * sorted buckets turn the gathers of a banded / skewed matrix into a few
+ * whole-line requests (random W = 2^14: 0.87 vs 1.19 ms; skewed rows 0.33 vs
+ * 0.51 ms).  When the direct kernels run beyond 2.5x the stream time the
+ * rows reach far outside an L2 and the "sweep" schedule is tried too (config
+ * 3: 1.63 ms vs 2.7 steps vs 5.8 direct).  The winner stays in `*slot`
+ * (12 B per entry); returns 1 when a blocked form won, 0 when not, < 0 on a
+ * device error.  Out of memory / index overflow just drops the candidate.
+ */
+template <class Build, class Time>
+static int tune_blocked(spmv_panels **slot, double stream_ms, double *bms,
+                        Build build, Time time_it) {
+    if (*bms <= 1.4 * stream_ms)
+        return 0;
+    spmv_panels *keep = NULL; /* best blocked copy so far */
+    const bool had = *slot != NULL;
+    const int n_sched = (*bms > 2.5 * stream_ms) ? 2 : 1;
+    for (int sched = 0; sched < n_sched; ++sched) {
+        spmv_panels *cand = NULL;
+        if (had && panels_is_sweep(*slot) == sched) {
+            cand = *slot; /* already built by the caller */
+        } else {
+            int rc = build(sched, &cand);
+            if (rc == -ENOMEM || rc == -EOVERFLOW)
+                continue;
+            if (rc)
+                return rc;
+        }
+        spmv_panels *prev = *slot;
+        *slot = cand;
+        double m = 0.0;
+        int rc = time_it(&m);
+        if (rc) {
+            if (cand != prev)
+                panels_free(cand);
+            *slot = prev;
+            return rc;
+        }
+        *slot = prev;
+        if (m < *bms) {
+            *bms = m;
+            if (keep && keep != prev)
+                panels_free(keep);
+            keep = cand;
+        } else if (cand != prev) {
+            panels_free(cand);
+        }
+    }
+    if (keep) {
+        if (*slot && *slot != keep)
+            panels_free(*slot);
+        *slot = keep;
+        return 1;
+    }
+    if (*slot && !had) {
+        panels_free(*slot);
+        *slot = NULL;
+    }
+    return 0;
+}
+
 extern "C" {
 
 const char *spmv_version(void) { return "spmv_scpa_amd 0.1 gfx950"; }
@@ -412,7 +476,7 @@ int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols) {
         return -EINVAL;
     panels_free(A->panels);
     A->panels = NULL;
-    return panels_from_csr(A, panel_cols, &A->panels);
+    return panels_from_csr(A, panel_cols, -1, &A->panels);
 }
 
 int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
@@ -420,7 +484,7 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
         return -EINVAL;
     panels_free(H->panels);
     H->panels = NULL;
-    return panels_from_hll(H, panel_cols, &H->panels);
+    return panels_from_hll(H, panel_cols, -1, &H->panels);
 }
 
 static int panels_info(const spmv_panels *P, int *steps, int *tiles,
@@ -761,28 +825,24 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
             best = cand[k];
         }
     }
-    /* the blocked path only pays when the gathers leave the L2: skip the
-     * build when the direct kernels already run near the stream rate */
-    const double stream_ms =
-        (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
-    if (allow_panels && bms > 2.5 * stream_ms) {
-        int rc = H->panels ? 0 : spmv_hll_build_panels(H, 0);
-        if (rc == 0) {
-            rc = spmv_hll_time(H, SPMV_HLL_KERNEL_PANELS, NULL, d_x, d_y, 1, 5,
-                               0, ms.data(), NULL);
-            if (rc)
-                return rc;
-            double m = median_of(ms);
-            if (m < bms) {
-                bms = m;
-                best = SPMV_HLL_KERNEL_PANELS;
-            } else {
-                panels_free(H->panels); /* give the 12 B/entry back */
-                H->panels = NULL;
-            }
-        } else if (rc != -ENOMEM && rc != -EOVERFLOW) {
+    if (allow_panels) {
+        const double stream_ms =
+            (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
+        int rc = tune_blocked(
+            &H->panels, stream_ms, &bms,
+            [&](int sched, spmv_panels **out) {
+                return panels_from_hll(H, 0, sched, out);
+            },
+            [&](double *m) {
+                int r = spmv_hll_time(H, SPMV_HLL_KERNEL_PANELS, NULL, d_x, d_y,
+                                      1, 5, 0, ms.data(), NULL);
+                *m = median_of(ms);
+                return r;
+            });
+        if (rc < 0)
             return rc;
-        }
+        if (rc > 0)
+            best = SPMV_HLL_KERNEL_PANELS;
     }
     *best_kernel = best;
     if (best_ms)
@@ -811,25 +871,23 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
             best = cand[k];
         }
     }
-    const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
-    if (allow_panels && bms > 2.5 * stream_ms) {
-        int rc = A->panels ? 0 : spmv_csr_build_panels(A, 0);
-        if (rc == 0) {
-            rc = spmv_csr_time(A, SPMV_CSR_KERNEL_PANELS, NULL, d_x, d_y, 1, 5,
-                               0, ms.data(), NULL);
-            if (rc)
-                return rc;
-            double m = median_of(ms);
-            if (m < bms) {
-                bms = m;
-                best = SPMV_CSR_KERNEL_PANELS;
-            } else {
-                panels_free(A->panels);
-                A->panels = NULL;
-            }
-        } else if (rc != -ENOMEM && rc != -EOVERFLOW) {
+    if (allow_panels) {
+        const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
+        int rc = tune_blocked(
+            &A->panels, stream_ms, &bms,
+            [&](int sched, spmv_panels **out) {
+                return panels_from_csr(A, 0, sched, out);
+            },
+            [&](double *m) {
+                int r = spmv_csr_time(A, SPMV_CSR_KERNEL_PANELS, NULL, d_x, d_y,
+                                      1, 5, 0, ms.data(), NULL);
+                *m = median_of(ms);
+                return r;
+            });
+        if (rc < 0)
             return rc;
-        }
+        if (rc > 0)
+            best = SPMV_CSR_KERNEL_PANELS;
     }
     *best_kernel = best;
     if (best_ms)

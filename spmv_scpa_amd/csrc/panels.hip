@@ -340,7 +340,8 @@ static int bits_for(long long n) { /* smallest b with 2^b >= n */
     return b;
 }
 
-static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
+static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
+                        int nb,
                         const int *irp_or_null, const int64_t *off_or_null,
                         int col_major, const int *ja, const double *as,
                         spmv_panels **out) {
@@ -348,7 +349,7 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int nb,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    const int sweep = panel_schedule();
+    const int sweep = sched < 0 ? panel_schedule() : (sched != 0);
     /* tile height.  steps: 1024 rows measured best (2.62 ms on config 3;
      * 3.3 ms at 8192): many small workgroups overlap their load / gather /
      * store phases.  sweep: sweep_tile_rows(). */
@@ -918,15 +919,21 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     return hip_errno(hipGetLastError());
 }
 
-int panels_from_csr(const spmv_csr_dev *A, int panel_cols, spmv_panels **out) {
-    return panels_build(A->M, A->N, A->NZ, panel_cols, 0, A->irp, NULL, 0,
-                        A->ja, A->as, out);
+/* sched: 0 = "steps", 1 = "sweep", < 0 = the process default
+ * (spmv_set_panel_schedule / SPMV_PANEL_SCHED) */
+int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
+                    spmv_panels **out) {
+    return panels_build(A->M, A->N, A->NZ, panel_cols, sched, 0, A->irp, NULL,
+                        0, A->ja, A->as, out);
 }
 
-int panels_from_hll(const spmv_hll_dev *H, int panel_cols, spmv_panels **out) {
-    return panels_build(H->M, H->N, H->slots, panel_cols, H->nb, NULL, H->off,
-                        H->col_major, H->ja, H->as, out);
+int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
+                    spmv_panels **out) {
+    return panels_build(H->M, H->N, H->slots, panel_cols, sched, H->nb, NULL,
+                        H->off, H->col_major, H->ja, H->as, out);
 }
+
+int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }
 
 int64_t panels_nnz(const spmv_panels *P) { return P ? P->nnz : 0; }
 int panels_count(const spmv_panels *P) { return P ? P->panels : 0; }
