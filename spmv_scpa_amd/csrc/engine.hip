@@ -24,64 +24,73 @@ int g_hll_waves = 8;
 
 /*
  * The 2-D blocked path as a candidate.  `*bms` is the best direct kernel's
- * time on entry.  Near the stream rate (within 1.4x of it at 7 TB/s) nothing
- * is built.  Otherwise the "steps" schedule is built and timed: column-
- * sorted buckets turn the gathers of a banded / skewed matrix into a few
- * whole-line requests (random W = 2^14: 0.87 vs 1.19 ms; skewed rows 0.33 vs
- * 0.51 ms).  When the direct kernels run beyond 2.5x the stream time the
- * rows reach far outside an L2 and the "sweep" schedule is tried too (config
- * 3: 1.63 ms vs 2.7 steps vs 5.8 direct).  The winner stays in `*slot`
- * (12 B per entry); returns 1 when a blocked form won, 0 when not, < 0 on a
- * device error.  Out of memory / index overflow just drops the candidate.
+ * time on entry.  Near the stream rate (within 1.3x of it at 7 TB/s) nothing
+ * is built.  Otherwise the "steps" schedule is built and timed with tiles of
+ * 8192 rows, then 16384 or 2048 rows depending on which way it improves:
+ * column-sorted buckets turn the gathers of a banded / skewed matrix into a
+ * few whole-line requests (random W = 2^14: 0.68 vs 1.19 ms direct; W = 2^17:
+ * 0.84 vs 1.58; W = 2^20: 1.18 vs 2.9; skewed rows 0.21 vs 0.51).  When the
+ * direct kernels run beyond 2.5x the stream time the rows reach far outside
+ * an L2 and the "sweep" schedule is tried too (config 3: 1.62 ms vs 3.2
+ * steps vs 5.8 direct).  The winner stays in `*slot` (12 B per entry);
+ * returns 1 when a blocked form won, 0 when not, < 0 on a device error.  Out
+ * of memory / index overflow just drops the candidate.
  */
 template <class Build, class Time>
 static int tune_blocked(spmv_panels **slot, double stream_ms, double *bms,
                         Build build, Time time_it) {
-    if (*bms <= 1.4 * stream_ms)
+    if (*bms <= 1.3 * stream_ms)
         return 0;
-    spmv_panels *keep = NULL; /* best blocked copy so far */
-    const bool had = *slot != NULL;
-    const int n_sched = (*bms > 2.5 * stream_ms) ? 2 : 1;
-    for (int sched = 0; sched < n_sched; ++sched) {
+    spmv_panels *const original = *slot; /* caller-built copy, if any */
+    spmv_panels *keep = NULL;            /* best blocked copy so far */
+    int err = 0;
+    /* build + time one candidate; keeps it when it beats everything so far;
+     * returns its time (or a huge one when it could not be built) */
+    auto try_one = [&](int sched, int tile_rows) -> double {
         spmv_panels *cand = NULL;
-        if (had && panels_is_sweep(*slot) == sched) {
-            cand = *slot; /* already built by the caller */
-        } else {
-            int rc = build(sched, &cand);
-            if (rc == -ENOMEM || rc == -EOVERFLOW)
-                continue;
-            if (rc)
-                return rc;
+        int rc = build(sched, tile_rows, &cand);
+        if (rc == -ENOMEM || rc == -EOVERFLOW)
+            return 1e300;
+        if (rc) {
+            err = rc;
+            return 1e300;
         }
-        spmv_panels *prev = *slot;
         *slot = cand;
         double m = 0.0;
-        int rc = time_it(&m);
+        rc = time_it(&m);
+        *slot = original;
         if (rc) {
-            if (cand != prev)
-                panels_free(cand);
-            *slot = prev;
-            return rc;
+            err = rc;
+            panels_free(cand);
+            return 1e300;
         }
-        *slot = prev;
         if (m < *bms) {
             *bms = m;
-            if (keep && keep != prev)
-                panels_free(keep);
+            panels_free(keep);
             keep = cand;
-        } else if (cand != prev) {
+        } else {
             panels_free(cand);
         }
+        return m;
+    };
+    const bool far = *bms > 2.5 * stream_ms;
+    const double t8 = try_one(0, 8192);
+    if (!err) {
+        const double t16 = try_one(0, 16384);
+        if (!err && t16 >= t8)
+            (void)try_one(0, 2048);
+    }
+    if (!err && far)
+        (void)try_one(1, 0);
+    if (err) {
+        panels_free(keep);
+        *slot = original;
+        return err;
     }
     if (keep) {
-        if (*slot && *slot != keep)
-            panels_free(*slot);
+        panels_free(original);
         *slot = keep;
         return 1;
-    }
-    if (*slot && !had) {
-        panels_free(*slot);
-        *slot = NULL;
     }
     return 0;
 }
@@ -476,7 +485,7 @@ int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols) {
         return -EINVAL;
     panels_free(A->panels);
     A->panels = NULL;
-    return panels_from_csr(A, panel_cols, -1, &A->panels);
+    return panels_from_csr(A, panel_cols, -1, 0, &A->panels);
 }
 
 int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
@@ -484,7 +493,7 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
         return -EINVAL;
     panels_free(H->panels);
     H->panels = NULL;
-    return panels_from_hll(H, panel_cols, -1, &H->panels);
+    return panels_from_hll(H, panel_cols, -1, 0, &H->panels);
 }
 
 static int panels_info(const spmv_panels *P, int *steps, int *tiles,
@@ -830,8 +839,8 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
             (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
         int rc = tune_blocked(
             &H->panels, stream_ms, &bms,
-            [&](int sched, spmv_panels **out) {
-                return panels_from_hll(H, 0, sched, out);
+            [&](int sched, int tile_rows, spmv_panels **out) {
+                return panels_from_hll(H, 0, sched, tile_rows, out);
             },
             [&](double *m) {
                 int r = spmv_hll_time(H, SPMV_HLL_KERNEL_PANELS, NULL, d_x, d_y,
@@ -875,8 +884,8 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
         const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
         int rc = tune_blocked(
             &A->panels, stream_ms, &bms,
-            [&](int sched, spmv_panels **out) {
-                return panels_from_csr(A, 0, sched, out);
+            [&](int sched, int tile_rows, spmv_panels **out) {
+                return panels_from_csr(A, 0, sched, tile_rows, out);
             },
             [&](double *m) {
                 int r = spmv_csr_time(A, SPMV_CSR_KERNEL_PANELS, NULL, d_x, d_y,

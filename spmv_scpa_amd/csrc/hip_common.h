@@ -107,9 +107,9 @@ int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s);
 
 /* column-panel path (panels.hip) */
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
-                    spmv_panels **out);
+                    int tile_rows, spmv_panels **out);
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
-                    spmv_panels **out);
+                    int tile_rows, spmv_panels **out);
 int panels_is_sweep(const spmv_panels *P);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s);

@@ -20,9 +20,12 @@
  * Schedule "steps" (tiles of 1024 rows): ONE LAUNCH PER STEP; in step s
  * workgroup t adds the s-th non-empty bucket of tile t into its y slice
  * (coalesced read-modify-write through LDS; a tile has one owner per launch,
- * launches are stream-ordered, y is zeroed first).  Every CU gathers from the
- * same panel by construction.  Cost: y is re-read and re-written once per
- * panel that touches the tile (6.2 of the 11.6 GB per SpMV on config 3).
+ * launches are stream-ordered, step 0 starts from zero).  Every CU gathers
+ * from the same or a neighbouring panel by construction.  Cost: y is re-read
+ * and re-written once per further panel that touches the tile (6.2 of the
+ * 11.6 GB per SpMV on config 3) -- nothing for a matrix whose tiles stay
+ * inside one panel, which is where this schedule wins: with the buckets
+ * column-sorted a banded or skewed matrix turns into a pure stream.
  *
  * Schedule "sweep" (tiles of up to 8160 rows, 2 resident workgroups per CU):
  * ONE persistent launch; a workgroup keeps its tile of y in LDS while it
@@ -33,8 +36,9 @@
  * speed, never correctness, so the kernel cannot hang on a chip that does
  * not hold the whole grid.
  *
- * Both lose on matrices with locality (most buckets empty), so the path is
- * opt-in and the autotuner keeps it only when it measures faster.
+ * The path is opt-in (12 B per entry of extra HBM) and the autotuner keeps
+ * it, in the schedule that measures faster, only when it beats the direct
+ * kernels.
  *
  * Summation order inside a row depends on LDS atomic arrival order: results
  * are reproducible to rounding (tests hold them to 1e-12 of the row scale),
@@ -44,7 +48,7 @@
 
 #include "hip_common.h"
 
-#define TILE_ROWS_STEPS 1024 /* "steps" schedule: 8 KiB of LDS */
+#define TILE_ROWS_STEPS 4096 /* "steps" schedule default: 32 KiB of LDS */
 #define SWEEP_WG_PER_CU 2
 #define SWEEP_SPIN_MAX 4096  /* polls before a wait gives up (perf only) */
 #define CNT_STRIDE 32        /* one phase counter per 128-B line */
@@ -64,7 +68,7 @@ struct spmv_panels {
     unsigned *ent;   /* [nnz] row-in-tile << shift | column-in-panel */
     double *val;     /* [nnz] */
     int64_t *bptr;   /* DEVICE [tiles*panels+1] start of bucket (tile, panel);
-                        multiples of 4 (steps) or 256 (sweep) slots */
+                        multiples of 256 slots (one wavefront's block) */
     int *blen;       /* DEVICE [tiles*panels] entries of the bucket (the slots
                         up to the next start are padding, never read as data) */
     int64_t *cb;     /* DEVICE [tiles*panels*2] (begin,end) of the s-th NON-EMPTY
@@ -140,24 +144,32 @@ __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
 }
 
 /*
- * Slot of entry r of a bucket in VAL.  "steps" layout: r.  "sweep" layout:
- * inside every block of 256 entries (one wavefront's chunk; lane L owns
- * entries 4L..4L+3, which it reads from ENT with one 16-byte load) the values
- * are stored so that the lane's two 16-byte loads are at 2L and 128 + 2L --
- * every load instruction of the wavefront then covers 1 KiB of whole cache
- * lines, none of them twice (24 line requests per block instead of ~43: the
- * CU's outstanding-miss slots are what the kernel runs out of).
+ * Slots of entry r of a bucket in ENT and VAL.  Buckets are cut into blocks
+ * of 256 entries, one wavefront's chunk.  Lane L of the wavefront owns
+ * entries L, 64 + L, 128 + L, 192 + L of the block: its u-th gather then
+ * goes out together with those of entries 64u .. 64u + 63 -- CONSECUTIVE
+ * entries of the column-sorted bucket, so lanes that want the same line of
+ * x share one request (with 4 consecutive entries per lane instead, an
+ * instruction spans 256 entries and shares nothing: 4x the L2 requests on a
+ * band of 2^17 columns).  The block is stored so that the lane still gets
+ * its four entries with one 16-byte load of ENT (slot 4L + u) and two of
+ * VAL (2L + u for u < 2, 128 + 2L + u - 2 above): every load instruction of
+ * the wavefront covers 1 KiB of whole cache lines, none of them twice (24
+ * line requests per block instead of ~43 -- the CU's outstanding-miss slots
+ * are what the kernels run out of).
  */
-__device__ __forceinline__ int64_t sweep_val_slot(int64_t r, int permute) {
-    if (!permute)
-        return r;
-    const int i = (int)(r & 255), L = i >> 2, j = i & 3;
-    return (r & ~(int64_t)255) + (j < 2 ? 2 * L + j : 128 + 2 * L + (j - 2));
+__device__ __forceinline__ int64_t block_ent_slot(int64_t r) {
+    const int i = (int)(r & 255), u = i >> 6, L = i & 63;
+    return (r & ~(int64_t)255) + 4 * L + u;
+}
+
+__device__ __forceinline__ int64_t block_val_slot(int64_t r) {
+    const int i = (int)(r & 255), u = i >> 6, L = i & 63;
+    return (r & ~(int64_t)255) + (u < 2 ? 2 * L + u : 128 + 2 * L + (u - 2));
 }
 
 /* row of a source position: CSR needs a search in irp, HLL decodes the slot */
 __global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows, int shift,
-                                  int permute,
                                   const unsigned *__restrict__ idx,
                                   const int *__restrict__ irp,
                                   const int *__restrict__ ja,
@@ -172,8 +184,8 @@ __global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows, int shift,
     const unsigned t = idx[k];
     const uint64_t bk = skey[k] >> shift; /* bucket */
     const int64_t rk = k - raw[bk];       /* rank inside the bucket */
-    const int64_t dst = bptr[bk] + rk;
-    const int64_t vdst = bptr[bk] + sweep_val_slot(rk, permute);
+    const int64_t dst = bptr[bk] + block_ent_slot(rk);
+    const int64_t vdst = bptr[bk] + block_val_slot(rk);
     int lo = 0, hi = M; /* last row with irp[row] <= t */
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -188,7 +200,7 @@ __global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows, int shift,
 }
 
 __global__ void k_tile_gather_hll(int64_t n, int M, int nb, int tile_rows,
-                                  int shift, int permute, int col_major,
+                                  int shift, int col_major,
                                   const unsigned *__restrict__ idx,
                                   const int64_t *__restrict__ off,
                                   const int *__restrict__ ja,
@@ -203,8 +215,8 @@ __global__ void k_tile_gather_hll(int64_t n, int M, int nb, int tile_rows,
     const unsigned t = idx[k];
     const uint64_t bk = skey[k] >> shift; /* bucket */
     const int64_t rk = k - raw[bk];       /* rank inside the bucket */
-    const int64_t dst = bptr[bk] + rk;
-    const int64_t vdst = bptr[bk] + sweep_val_slot(rk, permute);
+    const int64_t dst = bptr[bk] + block_ent_slot(rk);
+    const int64_t vdst = bptr[bk] + block_val_slot(rk);
     int lo = 0, hi = nb; /* block holding slot t */
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -341,7 +353,7 @@ static int bits_for(long long n) { /* smallest b with 2^b >= n */
 }
 
 static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
-                        int nb,
+                        int tile_rows, int nb,
                         const int *irp_or_null, const int64_t *off_or_null,
                         int col_major, const int *ja, const double *as,
                         spmv_panels **out) {
@@ -350,11 +362,14 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
     const int sweep = sched < 0 ? panel_schedule() : (sched != 0);
-    /* tile height.  steps: 1024 rows measured best (2.62 ms on config 3;
-     * 3.3 ms at 8192): many small workgroups overlap their load / gather /
-     * store phases.  sweep: sweep_tile_rows(). */
+    /* tile height.  steps: the taller the tile, the more entries of a bucket
+     * share a line of x (fewer L2 requests) but the fewer workgroups there
+     * are and the more LDS each holds; best measured per matrix: 2048 rows
+     * for a band of 2^14 columns (0.68 ms), 8192 for 2^17 (0.84), 16384 for
+     * 2^20 (1.18) and for skewed rows (0.21) -- spmv_*_autotune tries these.
+     * sweep: sweep_tile_rows(). */
     long long tr = TILE_ROWS_STEPS;
-    int grid = 0, tile_max = TILE_ROWS_STEPS, per_cu = 0;
+    int grid = 0, tile_max = 16384 /* steps: 128 KiB of LDS */, per_cu = 0;
     int want_shift = 18; /* 2^18 columns = 2 MiB of x: half of an XCD's L2 */
     if (panel_cols > 0)
         want_shift = bits_for((long long)panel_cols + 1) - 1; /* floor(log2) */
@@ -384,6 +399,8 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
         tile_max = sweep_tile_rows_max(per_cu);
         tr = sweep_tile_rows(M, grid, tile_max);
     }
+    if (!sweep && tile_rows >= 32 && tile_rows <= tile_max)
+        tr = tile_rows / 32 * 32;
     if (const char *ev = getenv("SPMV_TILE_ROWS")) { /* tuning override */
         long long o = atoll(ev);
         if (o >= 32 && o <= tile_max)
@@ -467,7 +484,7 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
         hipLaunchKernelGGL(k_bucket_bounds, dim3(gb), dim3(256), 0, 0, buckets,
                            slots, shift, skey, raw);
         hipLaunchKernelGGL(k_bucket_sizes, dim3(gb), dim3(256), 0, 0, buckets,
-                           (int64_t)(sweep ? 256 : 4), raw, P->blen, padded);
+                           (int64_t)256, raw, P->blen, padded);
         HIP_TRY(hipGetLastError());
         {
             void *t2 = NULL;
@@ -519,11 +536,11 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
         const unsigned g = (unsigned)((P->nnz + 255) / 256);
         if (irp_or_null)
             hipLaunchKernelGGL(k_tile_gather_csr, dim3(g), dim3(256), 0, 0,
-                               P->nnz, M, (int)tr, shift, sweep, sidx, irp_or_null,
+                               P->nnz, M, (int)tr, shift, sidx, irp_or_null,
                                ja, as, skey, raw, P->bptr, P->ent, P->val);
         else
             hipLaunchKernelGGL(k_tile_gather_hll, dim3(g), dim3(256), 0, 0,
-                               P->nnz, M, nb, (int)tr, shift, sweep, col_major, sidx,
+                               P->nnz, M, nb, (int)tr, shift, col_major, sidx,
                                off_or_null, ja, as, skey, raw, P->bptr, P->ent,
                                P->val);
         HIP_TRY(hipGetLastError());
@@ -550,84 +567,6 @@ fail:
 }
 
 /* ------------------------------------------------------------------ */
-/* schedule "steps": one launch per step                                 */
-/* ------------------------------------------------------------------ */
-template <int NT, int UN>
-__global__ void __launch_bounds__(NT)
-    k_tiles_one_panel(int M, int tile_rows, int panels, int shift, int step,
-                      const int64_t *__restrict__ cb,
-                      const int *__restrict__ cpanel,
-                      const int *__restrict__ nbk,
-                      const unsigned *__restrict__ tent,
-                      const double *__restrict__ tval,
-                      const double *__restrict__ x, double *__restrict__ y) {
-    extern __shared__ double ytile[];
-    const int tid = threadIdx.x;
-    /* XCD-contiguous tile ranges: the tiles an XCD runs at one time are
-     * neighbours, so their step-th panels coincide or are adjacent */
-    int t;
-    {
-        const int nx = 8, nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk / nx, r = nblk % nx, xx = bid % nx, kk = bid / nx;
-        t = xx * q + (xx < r ? xx : r) + kk;
-    }
-    if (step >= nbk[t])
-        return; /* this tile has fewer non-empty buckets: y untouched */
-    const int64_t b = cb[((int64_t)t * panels + step) * 2];
-    const int64_t e = cb[((int64_t)t * panels + step) * 2 + 1];
-    const double *xp = x + ((int64_t)cpanel[(int64_t)t * panels + step] << shift);
-    const unsigned lowmask = (1u << shift) - 1u;
-    const int64_t row0 = (int64_t)t * tile_rows;
-    /* first batch of entries and the y slice are fetched together (they are
-     * independent); the x gathers follow the barrier: issued before it they
-     * delay the slice, whose loads return in order behind them (measured
-     * 2.97 ms vs 2.6 ms) */
-    unsigned en[UN];
-    double v[UN];
-    bool ok[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-        const int64_t k = b + tid + (int64_t)u * NT;
-        ok[u] = k < e;
-        en[u] = ok[u] ? __builtin_nontemporal_load(tent + k) : 0u;
-        v[u] = ok[u] ? __builtin_nontemporal_load(tval + k) : 0.0;
-    }
-    for (int i = tid; i < tile_rows; i += NT)
-        ytile[i] = row0 + i < M ? y[row0 + i] : 0.0;
-    __syncthreads();
-    for (int64_t k0 = b + tid; k0 < e; k0 += (int64_t)NT * UN) {
-        double pr[UN];
-        unsigned rr[UN];
-        bool on[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-            pr[u] = ok[u] ? xp[en[u] & lowmask] : 0.0;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            pr[u] *= v[u];
-            rr[u] = en[u] >> shift;
-            on[u] = ok[u];
-        }
-        if (k0 + (int64_t)NT * UN < e) { /* next batch behind the gathers */
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int64_t k = k0 + (int64_t)NT * UN + (int64_t)u * NT;
-                ok[u] = k < e;
-                en[u] = ok[u] ? __builtin_nontemporal_load(tent + k) : 0u;
-                v[u] = ok[u] ? __builtin_nontemporal_load(tval + k) : 0.0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-            if (on[u])
-                unsafeAtomicAdd(&ytile[rr[u]], pr[u]);
-    }
-    __syncthreads();
-    for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
-        y[row0 + i] = ytile[i];
-}
-
-/* ------------------------------------------------------------------ */
 /* schedule "sweep": one persistent launch                               */
 /* ------------------------------------------------------------------ */
 __device__ __forceinline__ void phase_arrive(int *cnt) {
@@ -649,7 +588,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 /*
  * A lane owns Q groups of 4 consecutive entries per chunk: one 16-byte load
- * of ENT and two of VAL per group (layout: sweep_val_slot).  Three
+ * of ENT and two of VAL per group (layout: block_ent_slot).  Three
  * chunk buffers rotate: while chunk c is gathered and added, the loads of
  * c+1 are a whole iteration old and those of c+2 are issued behind c's
  * gathers -- the CU's texture path serves requests in order, so a stream
@@ -670,7 +609,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int Q> struct sweep_chunk {
     u32x4 en[Q];
     f64x2 va[Q], vb[Q];
-    int live[Q];      /* entries of the group that exist: <= 0 .. >= 4 */
+    int live[Q];      /* entry u of the lane exists iff live > 64 u */
     int p;            /* wave-uniform: panel (>= panels: past the end) */
     bool first, last; /* wave-uniform: first / last chunk of its bucket */
 };
@@ -731,11 +670,11 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
             for (int g = 0; g < Q; ++g) {
                 /* the wavefront's block of 256 slots: ENT in entry order,
-                 * VAL permuted (sweep_val_slot) so that each of the three
+                 * VAL permuted (block_val_slot) so that each of the three
                  * loads reads 1 KiB of whole lines */
                 unsigned blk = fk + ((unsigned)g * NT + (tid & ~(WAVE - 1))) * 4u;
                 const unsigned lane = tid & (WAVE - 1);
-                c.live[g] = (int)(fe - (blk + lane * 4u));
+                c.live[g] = (int)(fe - blk) - (int)lane; /* > 64u: entry u */
                 if (ABL & 4) /* stream from a 192 KiB window: L2 hits */
                     blk &= 0x3FFFu;
                 c.en[g] = __builtin_nontemporal_load(
@@ -778,7 +717,7 @@ __global__ void __launch_bounds__(NT)
                 on[g] = c.live[g];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const unsigned col = u < on[g] ? (c.en[g][u] & lowmask) : 0u;
+                    const unsigned col = 64 * u < on[g] ? (c.en[g][u] & lowmask) : 0u;
                     pr[g][u] = xp[col];
                     rr[g][u] = c.en[g][u] >> shift;
                 }
@@ -800,9 +739,9 @@ __global__ void __launch_bounds__(NT)
                 for (int u = 0; u < 4; ++u) {
                     const double prod = pr[g][u] * w[g][u];
                     if (ABL & 1) {
-                        if (u < on[g] && prod == 1.2345e300)
+                        if (64 * u < on[g] && prod == 1.2345e300)
                             ytile[rr[g][u]] = 1.0;
-                    } else if (u < on[g]) {
+                    } else if (64 * u < on[g]) {
                         unsafeAtomicAdd(&ytile[rr[g][u]], prod);
                     }
                 }
@@ -840,6 +779,118 @@ __global__ void __launch_bounds__(NT)
             __builtin_nontemporal_store(ytile[i], y + row0 + i);
         __syncthreads();
     }
+}
+
+/* ------------------------------------------------------------------ */
+/* schedule "steps": one launch per step                                 */
+/* ------------------------------------------------------------------ */
+/*
+ * In step s workgroup t adds the s-th non-empty bucket of tile t into the
+ * tile's slice of y (through LDS; a tile has one owner per launch and the
+ * launches are stream-ordered).  Step 0 starts every slice from zero -- also
+ * for tiles without entries -- so y needs no memset and is only re-read by
+ * tiles that reach a second panel.  Same entry layout and load discipline as
+ * the sweep kernel: blocks of 256 slots per wavefront, 16-byte loads over
+ * whole lines, every vector load unconditional, the loads of chunk c+1 behind
+ * the gathers of chunk c.
+ */
+template <int NT, int Q>
+__global__ void __launch_bounds__(NT)
+    k_tiles_step(int M, int tile_rows, int panels, int shift, int step,
+                 const int64_t *__restrict__ cb, const int *__restrict__ cpanel,
+                 const int *__restrict__ nbk, const unsigned *__restrict__ tent,
+                 const double *__restrict__ tval, const double *__restrict__ x,
+                 double *__restrict__ y) {
+    extern __shared__ double ytile[];
+    constexpr unsigned CH = NT * Q * 4;
+    const int tid = threadIdx.x;
+    /* XCD-contiguous tile ranges: the tiles an XCD runs at one time are
+     * neighbours, so their step-th panels coincide or are adjacent */
+    int t;
+    {
+        const int nx = 8, nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk / nx, r = nblk % nx, xx = bid % nx, kk = bid / nx;
+        t = xx * q + (xx < r ? xx : r) + kk;
+    }
+    const int64_t row0 = (int64_t)t * tile_rows;
+    if (step >= nbk[t]) {
+        if (step == 0) /* a tile without entries: its rows are zero */
+            for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
+                y[row0 + i] = 0.0;
+        return;
+    }
+    const unsigned b = (unsigned)cb[((int64_t)t * panels + step) * 2];
+    const unsigned e = (unsigned)cb[((int64_t)t * panels + step) * 2 + 1];
+    const double *xp = x + ((int64_t)cpanel[(int64_t)t * panels + step] << shift);
+    const unsigned lowmask = (1u << shift) - 1u;
+    const unsigned lane = tid & (WAVE - 1);
+    const unsigned wbase = (tid & ~(WAVE - 1)) * 4u;
+
+    auto fill = [&](sweep_chunk<Q> &c, unsigned k0) {
+#pragma unroll
+        for (int g = 0; g < Q; ++g) {
+            const unsigned blk = k0 + (unsigned)g * NT * 4u + wbase;
+            c.live[g] = (int)(e - blk) - (int)lane; /* > 64u: entry u */
+            c.en[g] = __builtin_nontemporal_load(
+                (const u32x4 *)(tent + blk + lane * 4u));
+            c.va[g] = __builtin_nontemporal_load(
+                (const f64x2 *)(tval + blk + lane * 2u));
+            c.vb[g] = __builtin_nontemporal_load(
+                (const f64x2 *)(tval + blk + 128u + lane * 2u));
+        }
+    };
+    auto consume = [&](sweep_chunk<Q> &c, sweep_chunk<Q> &f, unsigned knext) {
+        double pr[Q][4], w[Q][4];
+        unsigned rr[Q][4];
+        int on[Q];
+#pragma unroll
+        for (int g = 0; g < Q; ++g) {
+            on[g] = c.live[g];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned col = 64 * u < on[g] ? (c.en[g][u] & lowmask) : 0u;
+                pr[g][u] = xp[col];
+                rr[g][u] = c.en[g][u] >> shift;
+            }
+            w[g][0] = c.va[g][0];
+            w[g][1] = c.va[g][1];
+            w[g][2] = c.vb[g][0];
+            w[g][3] = c.vb[g][1];
+        }
+        fill(f, knext); /* past the bucket: slack slots, masked by `live` */
+#pragma unroll
+        for (int g = 0; g < Q; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (64 * u < on[g])
+                    unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
+    };
+
+    sweep_chunk<Q> A, B;
+    fill(A, b);
+    /* the first entries and the y slice are fetched together; the x gathers
+     * follow the barrier (issued before it they delay the slice, whose loads
+     * return in order behind them) */
+    if (step == 0)
+        for (int i = tid; i < tile_rows; i += NT)
+            ytile[i] = 0.0;
+    else
+        for (int i = tid; i < tile_rows; i += NT)
+            ytile[i] = row0 + i < M ? y[row0 + i] : 0.0;
+    __syncthreads();
+    for (unsigned k0 = b;;) {
+        consume(A, B, k0 + CH);
+        k0 += CH;
+        if (k0 >= e)
+            break;
+        consume(B, A, k0 + CH);
+        k0 += CH;
+        if (k0 >= e)
+            break;
+    }
+    __syncthreads();
+    for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
+        y[row0 + i] = ytile[i];
 }
 
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
@@ -900,37 +951,53 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
 #undef SW
         return hip_errno(hipGetLastError());
     }
-    HIP_RET(hipMemsetAsync(y, 0, (size_t)M * sizeof(double), s));
     /* launch `step` handles the step-th NON-EMPTY bucket of every tile: a
      * matrix whose rows reach over k panels needs k launches, all tiles busy
-     * in each of them */
-    for (int p = 0; p < P->max_nbk; ++p) {
-        if (waves > 0 && waves < 8)
-            hipLaunchKernelGGL((k_tiles_one_panel<256, 4>), dim3(P->tiles),
-                               dim3(256), lds, s, M, P->tile_rows, P->panels,
-                               P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,
-                               P->val, x, y);
-        else /* 512 lanes x 4 entries: 2.58 ms (x8: 2.65) on config 3 */
-            hipLaunchKernelGGL((k_tiles_one_panel<512, 4>), dim3(P->tiles),
-                               dim3(512), lds, s, M, P->tile_rows, P->panels,
-                               P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,
-                               P->val, x, y);
+     * in each of them; step 0 also zeroes the rows of empty tiles */
+    const int steps = P->max_nbk > 0 ? P->max_nbk : 1;
+    const double per_bucket =
+        (double)P->nnz / ((double)P->tiles * (double)steps);
+    for (int p = 0; p < steps; ++p) {
+#define ST(NTHR, QQ)                                                           \
+    do {                                                                       \
+        static bool big_lds_ok[64];                                            \
+        int dev_ = 0;                                                          \
+        HIP_RET(hipGetDevice(&dev_));                                          \
+        bool &big_lds_ok_ = big_lds_ok[dev_ & 63];                             \
+        if (!big_lds_ok_) { /* tiles above 64 KiB need the opt-in */           \
+            HIP_RET(hipFuncSetAttribute(                                       \
+                reinterpret_cast<const void *>(&k_tiles_step<NTHR, QQ>),       \
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+            big_lds_ok_ = true;                                                \
+        }                                                                      \
+        hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>), dim3(P->tiles),          \
+                           dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
+                           P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,      \
+                           P->val, x, y);                                      \
+    } while (0)
+        if (waves > 0 && waves < 8) ST(256, 1);
+        else if (waves > 8) ST(1024, 1);
+        else if (waves == 8) ST(512, 1);
+        else if (per_bucket >= 3000.0) ST(512, 1);
+        else ST(256, 1);
+#undef ST
     }
     return hip_errno(hipGetLastError());
 }
 
 /* sched: 0 = "steps", 1 = "sweep", < 0 = the process default
- * (spmv_set_panel_schedule / SPMV_PANEL_SCHED) */
+ * (spmv_set_panel_schedule / SPMV_PANEL_SCHED); tile_rows: rows per tile of
+ * the steps schedule (0 = default, up to 16384) */
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
-                    spmv_panels **out) {
-    return panels_build(A->M, A->N, A->NZ, panel_cols, sched, 0, A->irp, NULL,
-                        0, A->ja, A->as, out);
+                    int tile_rows, spmv_panels **out) {
+    return panels_build(A->M, A->N, A->NZ, panel_cols, sched, tile_rows, 0,
+                        A->irp, NULL, 0, A->ja, A->as, out);
 }
 
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
-                    spmv_panels **out) {
-    return panels_build(H->M, H->N, H->slots, panel_cols, sched, H->nb, NULL,
-                        H->off, H->col_major, H->ja, H->as, out);
+                    int tile_rows, spmv_panels **out) {
+    return panels_build(H->M, H->N, H->slots, panel_cols, sched, tile_rows,
+                        H->nb, NULL, H->off, H->col_major, H->ja, H->as, out);
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }

@@ -348,6 +348,10 @@ def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
         for k in (1, 2):
             row("config4-like stencil27 203^3 hll_%s" % S.HLL_KERNEL_NAMES[k],
                 dSh, med(dSh.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        best, _ = dS.autotune(dx, dy, True)
+        if best == S.CSR_KERNEL_PANELS:
+            row("config4-like stencil27 203^3 csr_tile_panels (autotuned pick)",
+                dS, med(dS.time(best, dx, dy, 2, 10, 0, args.waves, stream=st)))
         dSh.release()
         dS.release()
         dK = S.CsrDevice.generate(S.SYNTH_KKT, 8_345_600, Nglob, 16, 1 << 16,
@@ -355,6 +359,10 @@ def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
         for k in (2, 4):
             row("skewed-rows kkt8.3M csr_%s" % S.CSR_KERNEL_NAMES[k], dK,
                 med(dK.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
+        best, _ = dK.autotune(dx, dy, True)
+        if best == S.CSR_KERNEL_PANELS:
+            row("skewed-rows kkt8.3M csr_tile_panels (autotuned pick)", dK,
+                med(dK.time(best, dx, dy, 2, 10, 0, args.waves, stream=st)))
         dK.release()
     except OSError as e:
         out["error config4"] = str(e)
