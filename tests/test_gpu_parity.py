@@ -378,6 +378,36 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sweep,
     S.csr_free(A)
 
 
+@pytest.mark.parametrize("tile_rows", [32, 2048, 16384])
+def test_steps_schedule_tile_heights(tile_rows, default_panel_schedule,
+                                     monkeypatch):
+    """The steps schedule at the tile heights the autotuner tries (16 KiB and
+    128 KiB of LDS) and at the smallest one; a matrix with empty rows, rows
+    longer than a chunk and more than one panel per tile."""
+    M, N, K, W = 50_000, 60_000, 16, 20_000
+    IRP, JA, AS = O.synth_csr(S.SYNTH_KKT, M, N, K, W, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("tiles", M, N, IRP, JA, AS)
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+    dA = S.CsrDevice.upload(A)
+    S.set_panel_schedule(False)
+    monkeypatch.setenv("SPMV_TILE_ROWS", str(tile_rows))
+    dA.build_panels(8192)  # 8 panels: several steps per tile
+    monkeypatch.delenv("SPMV_TILE_ROWS")
+    info = dA.panels_info()
+    assert info["tiles"] == -(-M // tile_rows) and info["steps"] > 1
+    for waves in (0, 4, 8, 16):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, waves_per_block=waves)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                      ("steps", tile_rows, waves))
+    dA.release()
+    S.csr_free(A)
+
+
 def test_autotune_picks_a_valid_kernel_and_stays_correct():
     """spmv_*_autotune: measured choice between the coalesced kernels and the
     2-D blocked path; whatever it picks must still match the oracle."""
