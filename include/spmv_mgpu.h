@@ -42,6 +42,10 @@ int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed);       /* synth_x on device */
 int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
                    double *ms_each);
 
+/* measured kernel choice for the loaded shards (spmv_*_autotune per device,
+ * device 0's pick for all); pass *kernel to spmv_mgpu_spmv() */
+int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel);
+
 /* the gathered y as device `rank` holds it (M doubles, row order) */
 int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host);
 

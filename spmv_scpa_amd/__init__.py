@@ -762,6 +762,7 @@ _sig("spmv_mgpu_generate", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
 _sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
 _sig("spmv_mgpu_fill_x", C.c_int, C.c_void_p, C.c_uint64)
 _sig("spmv_mgpu_spmv", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp)
+_sig("spmv_mgpu_autotune", C.c_int, C.c_void_p, _ip)
 _sig("spmv_mgpu_get_y", C.c_int, C.c_void_p, C.c_int, _dp)
 _sig("spmv_mgpu_info", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64),
      C.POINTER(C.c_int64))
@@ -794,6 +795,13 @@ class MultiGpu:
 
     def fill_x(self, seed=7):
         _check(_lib.spmv_mgpu_fill_x(self.h, seed), "spmv_mgpu_fill_x")
+
+    def autotune(self):
+        """-> kernel id measured fastest for the loaded shards"""
+        k = C.c_int()
+        _check(_lib.spmv_mgpu_autotune(self.h, C.byref(k)),
+               "spmv_mgpu_autotune")
+        return k.value
 
     def spmv(self, kernel=-1, warmup=1, iters=3):
         ms = np.zeros(max(iters, 1))

@@ -296,8 +296,11 @@ static void run_multi_gpu(void) {
         rc = spmv_mgpu_load_csr(g, A, fmt);
         if (!rc)
             rc = spmv_mgpu_set_x(g, x.data);
+        int kernel = -1;
         if (!rc)
-            rc = spmv_mgpu_spmv(g, -1, 3, opt.iters > 0 ? opt.iters : 1, ms);
+            rc = spmv_mgpu_autotune(g, &kernel);
+        if (!rc)
+            rc = spmv_mgpu_spmv(g, kernel, 3, opt.iters > 0 ? opt.iters : 1, ms);
         if (rc)
             break;
         if (opt.debug) { /* every device must hold the whole, correct y */

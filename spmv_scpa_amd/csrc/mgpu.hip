@@ -199,6 +199,42 @@ fail:
     return rc;
 }
 
+/*
+ * Measured kernel choice for the shards (spmv_*_autotune on every device;
+ * device 0's pick is used by all so that the ranks stay in step; a device
+ * that did not keep a blocked copy builds one when the pick needs it).
+ */
+int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
+    if (!g || !kernel)
+        return -EINVAL;
+    int rc = 0, pick = -1;
+    const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
+    for (int r = 0; r < g->n && !rc; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        double *yfrag = g->y[r] + (size_t)r * g->rows_per_gpu;
+        int k = -1;
+        rc = g->is_hll
+                 ? spmv_hll_autotune(g->hll[r], g->x[r], yfrag, 1, &k, NULL)
+                 : spmv_csr_autotune(g->csr[r], g->x[r], yfrag, 1, &k, NULL);
+        if (r == 0)
+            pick = k;
+    }
+    for (int r = 1; r < g->n && !rc && pick == blocked; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        int steps = 0;
+        int have = g->is_hll
+                       ? spmv_hll_panels_info(g->hll[r], &steps, NULL, NULL, NULL)
+                       : spmv_csr_panels_info(g->csr[r], &steps, NULL, NULL, NULL);
+        if (have == -ENOENT)
+            rc = g->is_hll ? spmv_hll_build_panels(g->hll[r], 0)
+                           : spmv_csr_build_panels(g->csr[r], 0);
+    }
+    if (!rc)
+        *kernel = pick;
+fail:
+    return rc;
+}
+
 static double wall_ms_now(void) {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);

@@ -31,6 +31,13 @@ def test_mgpu_host_matrix_matches_oracle(as_hll):
     for r in range(n):
         y = g.get_y(r)
         assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
+    # measured kernel choice (may be the blocked path), same answer
+    k = g.autotune()
+    assert k in ((1, 2, S.HLL_KERNEL_PANELS) if as_hll
+                 else (1, 2, 4, S.CSR_KERNEL_PANELS))
+    g.spmv(kernel=k, iters=2)
+    y = g.get_y(n - 1)
+    assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
     g.destroy()
     S.csr_free(A)
 
