@@ -275,15 +275,23 @@ def main():
         # two logical shards so that the all-gather of the first half runs
         # under the kernel of the second (kernel time is unchanged: 2 x
         # 1.70 ms vs 3.35 ms for 10M rows x 80M columns)
+        model = mat if mat.panels_info() is not None else None
         for m in mats:
-            m.release()
+            if m is not model:
+                m.release()
         L, Mshard = 2, Mshard // 2
         mats, nnz_local, slots = build_shards(L, Mshard)
         mat = mats[0]
+        if model is not None:  # the tuned schedule and tile height
+            for m in mats:
+                m.build_panels_like(model)
+            model.release()
     if labels[kernel] == "tile_panels":
-        for m in mats:
+        if mat.panels_info() is None:
+            mat.build_panels(0)
+        for m in mats[1:]:  # the tuned shard's schedule and tile height
             if m.panels_info() is None:
-                m.build_panels(0)
+                m.build_panels_like(mat)
     kname = prefix + labels[kernel]
     pinfo = mat.panels_info() if labels[kernel] == "tile_panels" else None
     launches_per_step = (pinfo["steps"] if pinfo else 1) * L

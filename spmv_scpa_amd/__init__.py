@@ -203,6 +203,8 @@ _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_csr_build_panels_like", C.c_int, C.c_void_p, C.c_void_p)
+_sig("spmv_hll_build_panels_like", C.c_int, C.c_void_p, C.c_void_p)
 _sig("spmv_hll_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_csr_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64))
 _sig("spmv_csr_algorithmic_bytes", C.c_int64, C.c_void_p)
@@ -614,6 +616,10 @@ class CsrDevice:
         _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
                "spmv_csr_build_panels")
 
+    def build_panels_like(self, model):
+        _check(_lib.spmv_csr_build_panels_like(self.h, model.h),
+               "spmv_csr_build_panels_like")
+
     def panels_info(self):
         """-> dict(steps, tiles, panels, entries) or None when not built"""
         a, b, c, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
@@ -675,6 +681,10 @@ class HllDevice:
     def build_panels(self, panel_cols=0):
         _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
                "spmv_hll_build_panels")
+
+    def build_panels_like(self, model):
+        _check(_lib.spmv_hll_build_panels_like(self.h, model.h),
+               "spmv_hll_build_panels_like")
 
     def panels_info(self):
         """-> dict(steps, tiles, panels, entries) or None when not built"""

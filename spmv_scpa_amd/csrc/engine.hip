@@ -496,6 +496,26 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
     return panels_from_hll(H, panel_cols, -1, 0, &H->panels);
 }
 
+/* same schedule and tile height as `model`'s blocked copy (shards of one
+ * matrix: tune one, build the others alike) */
+int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
+    if (!A || !model || !model->panels)
+        return -EINVAL;
+    panels_free(A->panels);
+    A->panels = NULL;
+    return panels_from_csr(A, 0, panels_is_sweep(model->panels),
+                           panels_tile_rows(model->panels), &A->panels);
+}
+
+int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
+    if (!H || !model || !model->panels)
+        return -EINVAL;
+    panels_free(H->panels);
+    H->panels = NULL;
+    return panels_from_hll(H, 0, panels_is_sweep(model->panels),
+                           panels_tile_rows(model->panels), &H->panels);
+}
+
 static int panels_info(const spmv_panels *P, int *steps, int *tiles,
                        int *panels, int64_t *entries) {
     if (!P)

@@ -111,6 +111,7 @@ int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out);
 int panels_is_sweep(const spmv_panels *P);
+int panels_tile_rows(const spmv_panels *P);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s);
 void panels_free(spmv_panels *p);

@@ -1001,6 +1001,7 @@ int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }
+int panels_tile_rows(const spmv_panels *P) { return P ? P->tile_rows : 0; }
 
 int64_t panels_nnz(const spmv_panels *P) { return P ? P->nnz : 0; }
 int panels_count(const spmv_panels *P) { return P ? P->panels : 0; }

@@ -408,6 +408,39 @@ def test_steps_schedule_tile_heights(tile_rows, default_panel_schedule,
     S.csr_free(A)
 
 
+def test_build_panels_like_copies_schedule_and_tile_height(
+        default_panel_schedule, monkeypatch):
+    """Shards of one matrix: tune (here: build) one, build the others with
+    the same schedule and tile height (bench.py --strong, N > 1)."""
+    M, N, W = 30_000, 600_000, 1 << 30  # 3 panels of 2^18 columns
+    A0 = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 16, W, 0, 42)
+    A1 = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 16, W, M, 42)
+    with pytest.raises(OSError):
+        A1.build_panels_like(A0)  # the model has no blocked copy yet
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    for sweep, rows in ((False, 2048), (True, 0)):
+        S.set_panel_schedule(sweep)
+        if rows:
+            monkeypatch.setenv("SPMV_TILE_ROWS", str(rows))
+        A0.build_panels(0)
+        monkeypatch.delenv("SPMV_TILE_ROWS", raising=False)
+        S.set_panel_schedule(not sweep)  # the copy must not follow the default
+        A1.build_panels_like(A0)
+        i0, i1 = A0.panels_info(), A1.panels_info()
+        assert (i0["tiles"], i0["panels"]) == (i1["tiles"], i1["panels"])
+        assert (i1["steps"] == 1) == sweep
+        A1.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        y = d_y.to_numpy(np.float64, M)
+        for r in (0, 1, M // 2, M - 1):
+            want, sc = O.synth_row_dot(S.SYNTH_RANDOM, 2 * M, N, 16, W, 0, 42,
+                                       7, M + r)
+            assert abs(y[r] - want) <= 1e-12 * sc
+    A0.release()
+    A1.release()
+
+
 def test_autotune_picks_a_valid_kernel_and_stays_correct():
     """spmv_*_autotune: measured choice between the coalesced kernels and the
     2-D blocked path; whatever it picks must still match the oracle."""
