@@ -975,7 +975,11 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                            P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,      \
                            P->val, x, y);                                      \
     } while (0)
-        if (waves > 0 && waves < 8) ST(256, 1);
+        if (variant & 2048) { /* tuning: two groups of 4 per lane */
+            if (waves > 0 && waves < 8) ST(256, 2);
+            else ST(512, 2);
+        }
+        else if (waves > 0 && waves < 8) ST(256, 1);
         else if (waves > 8) ST(1024, 1);
         else if (waves == 8) ST(512, 1);
         else if (per_bucket >= 3000.0) ST(512, 1);
