@@ -310,6 +310,39 @@ def test_config3_random_hll_full_size_properties(W):
     dA.release()
 
 
+def test_config5_one_shard_of_the_8_gpu_problem():
+    """BASELINE config 5 on one GPU: rank 3's shard of the 80M x 80M matrix
+    (10M local rows starting at global row 30M, GLOBAL column indices up to
+    8e7, x of 640 MB).  The direct kernel and the autotuned pick (the blocked
+    path here) against rows recomputed from the workload definition."""
+    M, N, K, W = 10_000_000, 80_000_000, 32, 1 << 30
+    row0 = 3 * M
+    dA = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, K, W, row0, 42)
+    dH = dA.to_hll(True)
+    dA.release()
+    assert dH.slots == M * K
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    rng = np.random.default_rng(11)
+    rows = np.unique(np.concatenate([[0, 31, 32, M - 1],
+                                     rng.integers(0, M, 4_000)]))
+    want = np.array([O.synth_row_dot(S.SYNTH_RANDOM, 8 * M, N, K, W, 0, 42, 7,
+                                     row0 + int(g)) for g in rows])
+    best, ms = dH.autotune(d_x.ptr, d_y.ptr)
+    assert best == S.HLL_KERNEL_PANELS  # 6 ms direct vs ~3.4 ms blocked
+    ys = {}
+    for tag, k in (("direct", 2), ("autotuned", best)):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        dH.launch(k, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        y = d_y.to_numpy(np.float64, M)
+        assert np.all(np.isfinite(y)), tag
+        assert np.max(np.abs(y[rows] - want[:, 0]) / want[:, 1]) <= TIGHT, tag
+        ys[tag] = y
+    assert np.max(np.abs(ys["direct"] - ys["autotuned"])) < 1e-11
+    dH.release()
+
+
 PANEL_CASES = [
     # tag, kind, M, N, K, W, panel_cols
     ("wide_small_panels", S.SYNTH_RANDOM, 20_000, 20_000, 32, 1 << 30, 512),
