@@ -314,6 +314,11 @@ def main():
     torch.cuda.synchronize()
     rng = np.random.default_rng(1234 + rank)
     rows = np.concatenate([[0, Mloc - 1], rng.integers(0, Mloc, 256)])
+    if world > 1:  # and rows every OTHER rank computed: the exchange
+        others = [r for r in range(world) if r != rank]
+        rows = np.concatenate(
+            [rows] + [np.array([0, Mloc // 2, Mloc - 1]) + (r - rank) * Mloc
+                      for r in others])
     got = y[row0 + torch.as_tensor(rows, device=dev)].cpu().numpy()
     checked = 0
     for g, r in zip(got, rows):
