@@ -102,10 +102,13 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          void *stream);
 int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols);
 /* schedule the NEXT build_panels calls prepare: 1 = "sweep" (one persistent
- * launch, y tile resident in LDS; default), 0 = "steps" (one launch per
- * non-empty panel step).  Environment SPMV_PANEL_SCHED=steps|sweep sets the
- * initial value. */
-int spmv_set_panel_schedule(int sweep);
+ * launch over all panels with phase counters; for rows that reach far beyond
+ * an L2 of x; default), 2 = "chain" (one launch, a workgroup walks its
+ * tile's non-empty buckets; for banded / clustered / skewed matrices),
+ * 0 = "steps" (same layout as chain, one launch per non-empty panel step).
+ * -EINVAL otherwise.  Environment SPMV_PANEL_SCHED=steps|sweep|chain sets
+ * the initial value.  spmv_*_autotune tries them all. */
+int spmv_set_panel_schedule(int sched);
 /* geometry of the blocked copy: kernel launches per SpMV (steps), row
  * tiles, column panels, entries kept; -ENOENT when it is not built */
 int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,

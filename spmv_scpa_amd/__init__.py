@@ -288,10 +288,14 @@ def set_device(d):
     _check(_lib.spmv_set_device(d), "spmv_set_device")
 
 
-def set_panel_schedule(sweep):
-    """schedule the next build_panels() calls prepare (spmv_engine.h)"""
-    _check(_lib.spmv_set_panel_schedule(int(bool(sweep))),
-           "spmv_set_panel_schedule")
+PANEL_SCHED = {"steps": 0, "sweep": 1, "chain": 2}
+
+
+def set_panel_schedule(sched):
+    """schedule the next build_panels() calls prepare (spmv_engine.h):
+    "steps" / "sweep" / "chain", or 0 / 1 / 2 (True = sweep, False = steps)"""
+    code = PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched)
+    _check(_lib.spmv_set_panel_schedule(code), "spmv_set_panel_schedule")
 
 
 def device_info(d=0):

@@ -24,64 +24,68 @@ int g_hll_waves = 8;
 
 /*
  * The 2-D blocked path as a candidate.  `*bms` is the best direct kernel's
- * time on entry.  Near the stream rate (within 1.3x of it at 7 TB/s) nothing
- * is built.  Otherwise the "steps" schedule is built and timed with tiles of
- * 8192 rows, then 16384 or 2048 rows depending on which way it improves:
- * column-sorted buckets turn the gathers of a banded / skewed matrix into a
- * few whole-line requests (random W = 2^14: 0.68 vs 1.19 ms direct; W = 2^17:
- * 0.84 vs 1.58; W = 2^20: 1.18 vs 2.9; skewed rows 0.21 vs 0.51).  When the
- * direct kernels run beyond 2.5x the stream time the rows reach far outside
- * an L2 and the "sweep" schedule is tried too (config 3: 1.62 ms vs 3.2
- * steps vs 5.8 direct).  The winner stays in `*slot` (12 B per entry);
- * returns 1 when a blocked form won, 0 when not, < 0 on a device error.  Out
- * of memory / index overflow just drops the candidate.
+ * time on entry.  Near the stream rate (within 1.2x of it at 7 TB/s) nothing
+ * is built.  Otherwise the steps layout is built with tiles of 8192 and of
+ * 16384 rows and timed both as one chain launch and as one launch per step:
+ * column-sorted buckets turn the gathers of a banded / clustered / skewed
+ * matrix into a few whole-line requests (chain, random W = 2^14: 0.63 vs
+ * 1.19 ms direct; W = 2^17: 0.68 vs 1.58; W = 2^20: 0.89 vs 2.9; skewed rows
+ * 0.165 vs 0.51; 27-point stencil 0.44 vs 0.52).  When the direct kernels
+ * run beyond 2.5x the stream time the rows reach far outside an L2 and the
+ * sweep schedule is tried too (config 3: 1.6 ms vs 1.9 chain vs 5.8 direct).
+ * The winner stays in `*slot` (12 B per entry); returns 1 when a blocked
+ * form won, 0 when not, < 0 on a device error.  Out of memory / index
+ * overflow just drops the candidate.
  */
 template <class Build, class Time>
 static int tune_blocked(spmv_panels **slot, double stream_ms, double *bms,
                         Build build, Time time_it) {
-    if (*bms <= 1.3 * stream_ms)
+    if (*bms <= 1.2 * stream_ms)
         return 0;
     spmv_panels *const original = *slot; /* caller-built copy, if any */
     spmv_panels *keep = NULL;            /* best blocked copy so far */
     int err = 0;
-    /* build + time one candidate; keeps it when it beats everything so far;
-     * returns its time (or a huge one when it could not be built) */
-    auto try_one = [&](int sched, int tile_rows) -> double {
+    /* build + time one candidate (steps layout: in both launch modes); keeps
+     * it when it beats everything so far */
+    auto try_one = [&](int sched, int tile_rows) {
         spmv_panels *cand = NULL;
         int rc = build(sched, tile_rows, &cand);
         if (rc == -ENOMEM || rc == -EOVERFLOW)
-            return 1e300;
+            return;
         if (rc) {
             err = rc;
-            return 1e300;
+            return;
         }
         *slot = cand;
-        double m = 0.0;
-        rc = time_it(&m);
-        *slot = original;
-        if (rc) {
-            err = rc;
-            panels_free(cand);
-            return 1e300;
+        double best_m = 1e300;
+        int best_chain = 0;
+        for (int chain = (sched == 0 ? 1 : 0); chain >= 0 && !err; --chain) {
+            panels_set_chain(cand, chain);
+            double m = 0.0;
+            rc = time_it(&m);
+            if (rc)
+                err = rc;
+            else if (m < best_m) {
+                best_m = m;
+                best_chain = chain;
+            }
         }
-        if (m < *bms) {
-            *bms = m;
+        panels_set_chain(cand, best_chain);
+        *slot = original;
+        if (!err && best_m < *bms) {
+            *bms = best_m;
             panels_free(keep);
             keep = cand;
         } else {
             panels_free(cand);
         }
-        return m;
     };
     const bool far = *bms > 2.5 * stream_ms;
-    const double t8 = try_one(0, 8192);
-    if (!err) {
-        const double t16 = try_one(0, 16384);
-        if (!err && t16 >= t8)
-            (void)try_one(0, 2048);
-    }
+    try_one(0, 8192);
+    if (!err)
+        try_one(0, 16384);
     if (!err && far)
-        (void)try_one(1, 0);
+        try_one(1, 0);
     if (err) {
         panels_free(keep);
         *slot = original;
@@ -503,8 +507,10 @@ int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
         return -EINVAL;
     panels_free(A->panels);
     A->panels = NULL;
-    return panels_from_csr(A, 0, panels_is_sweep(model->panels),
-                           panels_tile_rows(model->panels), &A->panels);
+    const int sched = panels_is_sweep(model->panels)   ? 1
+                      : panels_is_chain(model->panels) ? 2 : 0;
+    return panels_from_csr(A, 0, sched, panels_tile_rows(model->panels),
+                           &A->panels);
 }
 
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
@@ -512,8 +518,10 @@ int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
         return -EINVAL;
     panels_free(H->panels);
     H->panels = NULL;
-    return panels_from_hll(H, 0, panels_is_sweep(model->panels),
-                           panels_tile_rows(model->panels), &H->panels);
+    const int sched = panels_is_sweep(model->panels)   ? 1
+                      : panels_is_chain(model->panels) ? 2 : 0;
+    return panels_from_hll(H, 0, sched, panels_tile_rows(model->panels),
+                           &H->panels);
 }
 
 static int panels_info(const spmv_panels *P, int *steps, int *tiles,

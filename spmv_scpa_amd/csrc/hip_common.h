@@ -112,6 +112,8 @@ int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out);
 int panels_is_sweep(const spmv_panels *P);
 int panels_tile_rows(const spmv_panels *P);
+int panels_is_chain(const spmv_panels *P);
+void panels_set_chain(spmv_panels *P, int chain);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s);
 void panels_free(spmv_panels *p);

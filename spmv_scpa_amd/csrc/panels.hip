@@ -36,6 +36,12 @@
  * speed, never correctness, so the kernel cannot hang on a chip that does
  * not hold the whole grid.
  *
+ * Schedule "chain" (same layout as steps): ONE launch, workgroup t walks
+ * all non-empty buckets of tile t with its slice of y in LDS and writes it
+ * once; no phase control -- neighbouring tiles stay on neighbouring panels
+ * by themselves when a tile has only a handful of buckets.  The fastest form
+ * for banded / clustered / skewed matrices (k_tiles_chain).
+ *
  * The path is opt-in (12 B per entry of extra HBM) and the autotuner keeps
  * it, in the schedule that measures faster, only when it beats the direct
  * kernels.
@@ -61,6 +67,7 @@ struct spmv_panels {
     int tile_rows;   /* rows per tile (multiple of 32) */
     int tiles;       /* row tiles */
     int sweep;       /* built for the persistent schedule */
+    int chain;       /* steps layout, launched as one chain launch */
     int grid;        /* sweep: workgroups of the launch */
     int wgs_per_cu;  /* sweep: workgroups sharing a CU's LDS */
     int64_t nnz;     /* entries kept */
@@ -296,18 +303,22 @@ __global__ void k_max_int(int n, const int *__restrict__ v, int *out) {
     atomicMax(out, m);
 }
 
-static int g_panel_sweep = -1; /* -1: not decided (env or default) */
+/* 0 steps, 1 sweep, 2 chain; -1: not decided (env or default) */
+static int g_panel_sched = -1;
 
 static int panel_schedule(void) {
-    if (g_panel_sweep < 0) {
+    if (g_panel_sched < 0) {
         const char *ev = getenv("SPMV_PANEL_SCHED");
-        g_panel_sweep = (ev && !strcmp(ev, "steps")) ? 0 : 1;
+        g_panel_sched = (ev && !strcmp(ev, "steps")) ? 0
+                        : (ev && !strcmp(ev, "chain")) ? 2 : 1;
     }
-    return g_panel_sweep;
+    return g_panel_sched;
 }
 
-extern "C" int spmv_set_panel_schedule(int sweep) {
-    g_panel_sweep = sweep ? 1 : 0;
+extern "C" int spmv_set_panel_schedule(int sched) {
+    if (sched < 0 || sched > 2)
+        return -EINVAL;
+    g_panel_sched = sched;
     return 0;
 }
 
@@ -361,7 +372,9 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    const int sweep = sched < 0 ? panel_schedule() : (sched != 0);
+    if (sched < 0)
+        sched = panel_schedule();
+    const int sweep = sched == 1;
     /* tile height.  steps: the taller the tile, the more entries of a bucket
      * share a line of x (fewer L2 requests) but the fewer workgroups there
      * are and the more LDS each holds; best measured per matrix: 2048 rows
@@ -424,6 +437,7 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
     P->tile_rows = (int)tr;
     P->tiles = tiles;
     P->sweep = sweep;
+    P->chain = sched == 2;
     P->grid = sweep ? (grid < tiles ? grid : (tiles > 0 ? tiles : 1)) : 0;
     P->wgs_per_cu = per_cu;
     uint64_t *key[2] = {NULL, NULL};
@@ -893,6 +907,122 @@ __global__ void __launch_bounds__(NT)
         y[row0 + i] = ytile[i];
 }
 
+/* ------------------------------------------------------------------ */
+/* schedule "chain": the steps layout in ONE launch                      */
+/* ------------------------------------------------------------------ */
+/*
+ * Workgroup t walks ALL non-empty buckets of tile t in panel order with the
+ * tile's slice of y in LDS and writes it once: no read-modify-write of y, no
+ * launch boundaries, loads running ahead across bucket boundaries.  There is
+ * no phase control: neighbouring tiles (XCD-contiguous ranges) start
+ * together and do the same amount of work per bucket, so on a banded /
+ * clustered matrix, where a tile has a handful of buckets, they stay on
+ * neighbouring panels by themselves.  On a matrix without locality (dozens
+ * of buckets per tile) they drift apart -- that is what the sweep schedule's
+ * phase counters are for.
+ */
+template <int NT, int Q>
+__global__ void __launch_bounds__(NT)
+    k_tiles_chain(int M, int tile_rows, int panels, int shift, unsigned total,
+                  const int64_t *__restrict__ cb, const int *__restrict__ cpanel,
+                  const int *__restrict__ nbk, const unsigned *__restrict__ tent,
+                  const double *__restrict__ tval, const double *__restrict__ x,
+                  double *__restrict__ y) {
+    extern __shared__ double ytile[];
+    constexpr unsigned CH = NT * Q * 4;
+    const int tid = threadIdx.x;
+    int t;
+    {
+        const int nx = 8, nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk / nx, r = nblk % nx, xx = bid % nx, kk = bid / nx;
+        t = xx * q + (xx < r ? xx : r) + kk;
+    }
+    const int64_t row0 = (int64_t)t * tile_rows;
+    const int nb = nbk[t];
+    const int64_t *tcb = cb + (int64_t)t * panels * 2;
+    const int *tpan = cpanel + (int64_t)t * panels;
+    const unsigned lowmask = (1u << shift) - 1u;
+    const unsigned lane = tid & (WAVE - 1);
+    const unsigned wbase = (tid & ~(WAVE - 1)) * 4u;
+
+    /* position of the next chunk to load (wave-uniform) */
+    int fs = 0, fpan = nb > 0 ? tpan[0] : 0;
+    unsigned fk = nb > 0 ? (unsigned)tcb[0] : total;
+    unsigned fe = nb > 0 ? (unsigned)tcb[1] : total;
+
+    auto fill = [&](sweep_chunk<Q> &c) {
+        c.p = fs < nb ? fpan : -1;
+#pragma unroll
+        for (int g = 0; g < Q; ++g) {
+            const unsigned blk = fk + (unsigned)g * NT * 4u + wbase;
+            c.live[g] = (int)(fe - blk) - (int)lane;
+            c.en[g] = __builtin_nontemporal_load(
+                (const u32x4 *)(tent + blk + lane * 4u));
+            c.va[g] = __builtin_nontemporal_load(
+                (const f64x2 *)(tval + blk + lane * 2u));
+            c.vb[g] = __builtin_nontemporal_load(
+                (const f64x2 *)(tval + blk + 128u + lane * 2u));
+        }
+        if (fs < nb) {
+            fk += CH;
+            if (fk >= fe) {
+                fs += 1;
+                if (fs < nb) {
+                    fk = (unsigned)tcb[2 * fs];
+                    fe = (unsigned)tcb[2 * fs + 1];
+                    fpan = tpan[fs];
+                } else { /* past the end: zeros of the tail */
+                    fk = fe = total;
+                }
+            }
+        }
+    };
+    auto consume = [&](sweep_chunk<Q> &c, sweep_chunk<Q> &f) {
+        const double *xp = x + ((int64_t)c.p << shift);
+        double pr[Q][4], w[Q][4];
+        unsigned rr[Q][4];
+        int on[Q];
+#pragma unroll
+        for (int g = 0; g < Q; ++g) {
+            on[g] = c.live[g];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned col = 64 * u < on[g] ? (c.en[g][u] & lowmask) : 0u;
+                pr[g][u] = xp[col];
+                rr[g][u] = c.en[g][u] >> shift;
+            }
+            w[g][0] = c.va[g][0];
+            w[g][1] = c.va[g][1];
+            w[g][2] = c.vb[g][0];
+            w[g][3] = c.vb[g][1];
+        }
+        fill(f);
+#pragma unroll
+        for (int g = 0; g < Q; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (64 * u < on[g])
+                    unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
+    };
+
+    sweep_chunk<Q> A, B;
+    fill(A);
+    for (int i = tid; i < tile_rows; i += NT)
+        ytile[i] = 0.0;
+    __syncthreads();
+    for (;;) {
+        if (A.p < 0)
+            break;
+        consume(A, B);
+        if (B.p < 0)
+            break;
+        consume(B, A);
+    }
+    __syncthreads();
+    for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
+        y[row0 + i] = ytile[i];
+}
+
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s) {
     if (!P)
@@ -951,6 +1081,34 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
 #undef SW
         return hip_errno(hipGetLastError());
     }
+    if (P->chain != !!(variant & 1)) { /* variant bit 0 flips the stored mode */
+        const double per_bucket_c =
+            (double)P->nnz / ((double)P->tiles *
+                              (double)(P->max_nbk > 0 ? P->max_nbk : 1));
+#define CHN(NTHR, QQ)                                                          \
+    do {                                                                       \
+        static bool big_lds_ok[64];                                            \
+        int dev_ = 0;                                                          \
+        HIP_RET(hipGetDevice(&dev_));                                          \
+        bool &big_lds_ok_ = big_lds_ok[dev_ & 63];                             \
+        if (!big_lds_ok_) { /* tiles above 64 KiB need the opt-in */           \
+            HIP_RET(hipFuncSetAttribute(                                       \
+                reinterpret_cast<const void *>(&k_tiles_chain<NTHR, QQ>),      \
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+            big_lds_ok_ = true;                                                \
+        }                                                                      \
+        hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>), dim3(P->tiles),         \
+                           dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
+                           P->shift, (unsigned)P->total, P->cb, P->cpanel,     \
+                           P->nbk, P->ent, P->val, x, y);                      \
+    } while (0)
+        if (waves > 0 && waves < 8) CHN(256, 1);
+        else if (waves > 8) CHN(1024, 1);
+        else if (waves == 8 || per_bucket_c >= 3000.0) CHN(512, 1);
+        else CHN(256, 1);
+#undef CHN
+        return hip_errno(hipGetLastError());
+    }
     /* launch `step` handles the step-th NON-EMPTY bucket of every tile: a
      * matrix whose rows reach over k panels needs k launches, all tiles busy
      * in each of them; step 0 also zeroes the rows of empty tiles */
@@ -989,9 +1147,10 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     return hip_errno(hipGetLastError());
 }
 
-/* sched: 0 = "steps", 1 = "sweep", < 0 = the process default
- * (spmv_set_panel_schedule / SPMV_PANEL_SCHED); tile_rows: rows per tile of
- * the steps schedule (0 = default, up to 16384) */
+/* sched: 0 = "steps", 1 = "sweep", 2 = "chain" (the steps layout, launched
+ * as one chain launch), < 0 = the process default (spmv_set_panel_schedule /
+ * SPMV_PANEL_SCHED); tile_rows: rows per tile of the steps layout (0 =
+ * default, up to 16384) */
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
     return panels_build(A->M, A->N, A->NZ, panel_cols, sched, tile_rows, 0,
@@ -1005,11 +1164,16 @@ int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }
+int panels_is_chain(const spmv_panels *P) { return P ? P->chain : 0; }
+void panels_set_chain(spmv_panels *P, int chain) {
+    if (P && !P->sweep)
+        P->chain = chain != 0;
+}
 int panels_tile_rows(const spmv_panels *P) { return P ? P->tile_rows : 0; }
 
 int64_t panels_nnz(const spmv_panels *P) { return P ? P->nnz : 0; }
 int panels_count(const spmv_panels *P) { return P ? P->panels : 0; }
 int panels_steps(const spmv_panels *P) {
-    return P ? (P->sweep ? 1 : P->max_nbk) : 0;
+    return P ? (P->sweep || P->chain ? 1 : P->max_nbk) : 0;
 }
 int panels_tiles(const spmv_panels *P) { return P ? P->tiles : 0; }

@@ -360,18 +360,19 @@ PANEL_CASES = [
 @pytest.fixture
 def default_panel_schedule():
     yield
-    S.set_panel_schedule(True)
+    S.set_panel_schedule("sweep")
 
 
-@pytest.mark.parametrize("sweep", [True, False], ids=["sweep", "steps"])
+@pytest.mark.parametrize("sched", ["sweep", "steps", "chain"])
 @pytest.mark.parametrize("tag,kind,M,N,K,W,pc", PANEL_CASES)
-def test_column_panel_path(tag, kind, M, N, K, W, pc, sweep,
+def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
                            default_panel_schedule):
     """Extra kernel (spmv_engine.h, panels.hip): entries bucketed by (row
-    tile, column panel), y tile accumulated in LDS with ds_add_f64; both
-    schedules (one persistent launch with phase counters / one launch per
-    panel step)."""
-    S.set_panel_schedule(sweep)
+    tile, column panel), y tile accumulated in LDS with ds_add_f64; all
+    schedules (one persistent launch over all panels with phase counters /
+    one launch per panel step / one launch chaining a tile's buckets)."""
+    S.set_panel_schedule(sched)
+    sweep = sched == "sweep"
     IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
     x = O.synth_x(7, 0, N)
     y_ref = O.csr_spmv(IRP, JA, AS, x)
@@ -384,11 +385,14 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sweep,
     dA.build_panels(pc)
     info = dA.panels_info()
     assert info["entries"] == int(IRP[-1])
-    assert (info["steps"] == 1) if sweep else (info["steps"] <= info["panels"])
+    assert ((info["steps"] == 1) if sched != "steps"
+            else (info["steps"] <= info["panels"]))
     # sweep tuning bits (panels.hip): 16 = workgroups at most one panel
-    # apart, 128 = no phase wait at all, 2048 = one group of 4 per lane
+    # apart, 128 = no phase wait at all, 2048 = one group of 4 per lane;
+    # steps layout: bit 0 flips between step launches and the chain launch
     for variant, waves in (((0, 8), (0, 4), (16, 8), (128, 4), (2048, 8))
-                           if sweep else ((0, 8), (0, 4))):
+                           if sweep else
+                           ((0, 8), (0, 4), (1, 0), (1, 16), (2048, 8))):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         for _ in range(2):  # repeated launches must not accumulate
             dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant,
@@ -425,18 +429,20 @@ def test_steps_schedule_tile_heights(tile_rows, default_panel_schedule,
     A = S.csr_from_arrays("tiles", M, N, IRP, JA, AS)
     d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
     dA = S.CsrDevice.upload(A)
-    S.set_panel_schedule(False)
+    S.set_panel_schedule("steps")
     monkeypatch.setenv("SPMV_TILE_ROWS", str(tile_rows))
     dA.build_panels(8192)  # 8 panels: several steps per tile
     monkeypatch.delenv("SPMV_TILE_ROWS")
     info = dA.panels_info()
     assert info["tiles"] == -(-M // tile_rows) and info["steps"] > 1
-    for waves in (0, 4, 8, 16):
-        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
-        dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, waves_per_block=waves)
-        S.stream_sync()
-        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
-                      ("steps", tile_rows, waves))
+    for variant in (0, 1):  # step launches / one chain launch
+        for waves in (0, 4, 8, 16):
+            S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr,
+                      waves_per_block=waves, variant=variant)
+            S.stream_sync()
+            assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                          ("steps", tile_rows, waves, variant))
     dA.release()
     S.csr_free(A)
 
@@ -452,17 +458,18 @@ def test_build_panels_like_copies_schedule_and_tile_height(
         A1.build_panels_like(A0)  # the model has no blocked copy yet
     d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
     S.dev_fill_synth(d_x.ptr, N, 7)
-    for sweep, rows in ((False, 2048), (True, 0)):
-        S.set_panel_schedule(sweep)
+    for sched, rows in (("steps", 2048), ("sweep", 0), ("chain", 4096)):
+        S.set_panel_schedule(sched)
         if rows:
             monkeypatch.setenv("SPMV_TILE_ROWS", str(rows))
         A0.build_panels(0)
         monkeypatch.delenv("SPMV_TILE_ROWS", raising=False)
-        S.set_panel_schedule(not sweep)  # the copy must not follow the default
+        # the copy must not follow the default
+        S.set_panel_schedule("steps" if sched != "steps" else "sweep")
         A1.build_panels_like(A0)
         i0, i1 = A0.panels_info(), A1.panels_info()
         assert (i0["tiles"], i0["panels"]) == (i1["tiles"], i1["panels"])
-        assert (i1["steps"] == 1) == sweep
+        assert i1["steps"] == (3 if sched == "steps" else 1)
         A1.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
         S.stream_sync()
         y = d_y.to_numpy(np.float64, M)
