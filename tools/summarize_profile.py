@@ -46,7 +46,7 @@ def last_dispatch(path):
 
 # bench.py kernel label -> device function(s) that run it
 KERNEL_FUNCS = {
-    "tile_panels": ("k_tiles_sweep", "k_tiles_step"),
+    "tile_panels": ("k_tiles_sweep", "k_tiles_step", "k_tiles_chain"),
     "hll_threads_row_major": ("k_hll_row_major",),
     "hll_threads_col_major": ("k_hll_col_lds",),
     "hll_wave_block": ("k_hll_col_direct",),
