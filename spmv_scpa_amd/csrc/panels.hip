@@ -1023,6 +1023,20 @@ __global__ void __launch_bounds__(NT)
         y[row0 + i] = ytile[i];
 }
 
+/* tiles above 64 KiB of LDS need the opt-in, once per kernel and device */
+template <auto Kernel> static int allow_big_lds(void) {
+    static bool done[64];
+    int dev = 0;
+    HIP_RET(hipGetDevice(&dev));
+    if (!done[dev & 63]) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 64));
+        done[dev & 63] = true;
+    }
+    return 0;
+}
+
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s) {
     if (!P)
@@ -1041,17 +1055,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         HIP_RET(hipMemsetAsync(P->phase_cnt, 0, P->phase_cnt_bytes, s));
 #define SW(NTHR, QQ, A)                                                        \
     do {                                                                       \
-        static bool big_lds_ok[64];                                            \
-        int dev_ = 0;                                                          \
-        HIP_RET(hipGetDevice(&dev_));                                          \
-        bool &big_lds_ok_ = big_lds_ok[dev_ & 63];                             \
-        if (!big_lds_ok_) { /* tiles above 64 KiB need the opt-in */           \
-            HIP_RET(hipFuncSetAttribute(                                       \
-                reinterpret_cast<const void *>(&k_tiles_sweep<NTHR, QQ, A>),   \
-                hipFuncAttributeMaxDynamicSharedMemorySize,                    \
-                160 * 1024 - 64));                                             \
-            big_lds_ok_ = true;                                                \
-        }                                                                      \
+        if (int rc_ = allow_big_lds<&k_tiles_sweep<NTHR, QQ, A>>())            \
+            return rc_;                                                        \
         hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A>), dim3(P->grid),       \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->tiles,      \
                            P->panels, P->shift, lag, SWEEP_SPIN_MAX,           \
@@ -1087,16 +1092,7 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                               (double)(P->max_nbk > 0 ? P->max_nbk : 1));
 #define CHN(NTHR, QQ)                                                          \
     do {                                                                       \
-        static bool big_lds_ok[64];                                            \
-        int dev_ = 0;                                                          \
-        HIP_RET(hipGetDevice(&dev_));                                          \
-        bool &big_lds_ok_ = big_lds_ok[dev_ & 63];                             \
-        if (!big_lds_ok_) { /* tiles above 64 KiB need the opt-in */           \
-            HIP_RET(hipFuncSetAttribute(                                       \
-                reinterpret_cast<const void *>(&k_tiles_chain<NTHR, QQ>),      \
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
-            big_lds_ok_ = true;                                                \
-        }                                                                      \
+        if (int rc_ = allow_big_lds<&k_tiles_chain<NTHR, QQ>>()) return rc_;   \
         hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>), dim3(P->tiles),         \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
                            P->shift, (unsigned)P->total, P->cb, P->cpanel,     \
@@ -1118,16 +1114,7 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     for (int p = 0; p < steps; ++p) {
 #define ST(NTHR, QQ)                                                           \
     do {                                                                       \
-        static bool big_lds_ok[64];                                            \
-        int dev_ = 0;                                                          \
-        HIP_RET(hipGetDevice(&dev_));                                          \
-        bool &big_lds_ok_ = big_lds_ok[dev_ & 63];                             \
-        if (!big_lds_ok_) { /* tiles above 64 KiB need the opt-in */           \
-            HIP_RET(hipFuncSetAttribute(                                       \
-                reinterpret_cast<const void *>(&k_tiles_step<NTHR, QQ>),       \
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
-            big_lds_ok_ = true;                                                \
-        }                                                                      \
+        if (int rc_ = allow_big_lds<&k_tiles_step<NTHR, QQ>>()) return rc_;    \
         hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>), dim3(P->tiles),          \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
                            P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,      \
