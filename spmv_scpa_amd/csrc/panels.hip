@@ -1098,7 +1098,11 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                            P->shift, (unsigned)P->total, P->cb, P->cpanel,     \
                            P->nbk, P->ent, P->val, x, y);                      \
     } while (0)
-        if (waves > 0 && waves < 8) CHN(256, 1);
+        if (variant & 2048) { /* tuning: two groups of 4 per lane */
+            if (waves > 0 && waves < 8) CHN(256, 2);
+            else CHN(512, 2);
+        }
+        else if (waves > 0 && waves < 8) CHN(256, 1);
         else if (waves > 8) CHN(1024, 1);
         else if (waves == 8 || per_bucket_c >= 3000.0) CHN(512, 1);
         else CHN(256, 1);
