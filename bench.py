@@ -270,11 +270,14 @@ def main():
             dist.broadcast(kk, 0)
             kernel = int(kk.item())
     if (labels[kernel] == "tile_panels" and use_dist and L == 1
-            and Mshard % (2 * D.HACK) == 0):
+            and Mshard % (2 * D.HACK) == 0
+            and (mat.panels_schedule() != "sweep" or args.force_exchange)):
         # the blocked path runs whole matrices only: hold the rank's rows as
         # two logical shards so that the all-gather of the first half runs
-        # under the kernel of the second (kernel time is unchanged: 2 x
-        # 1.70 ms vs 3.35 ms for 10M rows x 80M columns)
+        # under the kernel of the second.  Not for the sweep schedule: its
+        # launch wants every CU (phase counters), RCCL's kernels take some,
+        # so the overlap would only delay workgroups -- there the exchange
+        # follows the kernel.
         model = mat if mat.panels_info() is not None else None
         for m in mats:
             if m is not model:
@@ -393,6 +396,8 @@ def main():
             "kernel": kname,
             "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
             if tuned is not None else "fixed by --kernel",
+            "blocked_schedule": mat.panels_schedule()
+            if labels[kernel] == "tile_panels" else None,
             "kernel_launches_per_step": launches_per_step,
             "rows_per_gpu": Mloc, "logical_shards_per_gpu": L,
             "nnz_per_row": K, "nnz_global": nnz_global,

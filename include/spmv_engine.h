@@ -116,6 +116,8 @@ int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
 /* blocked copy with the schedule and tile height of `model`'s (shards of one
  * matrix: autotune one, build the others alike) */
 int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model);
+/* schedule of the blocked copy: 0 steps, 1 sweep, 2 chain; -ENOENT if none */
+int spmv_csr_panels_schedule(const spmv_csr_dev *A);
 int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ);
 int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A);
 /* download the device arrays into a host CSR (tests; generated matrices) */
@@ -145,6 +147,7 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols);
 int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries);
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model);
+int spmv_hll_panels_schedule(const spmv_hll_dev *H);
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major);
 int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H);

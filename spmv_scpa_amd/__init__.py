@@ -203,6 +203,8 @@ _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_csr_panels_schedule", C.c_int, C.c_void_p)
+_sig("spmv_hll_panels_schedule", C.c_int, C.c_void_p)
 _sig("spmv_csr_build_panels_like", C.c_int, C.c_void_p, C.c_void_p)
 _sig("spmv_hll_build_panels_like", C.c_int, C.c_void_p, C.c_void_p)
 _sig("spmv_hll_build_panels", C.c_int, C.c_void_p, C.c_int)
@@ -624,6 +626,11 @@ class CsrDevice:
         _check(_lib.spmv_csr_build_panels_like(self.h, model.h),
                "spmv_csr_build_panels_like")
 
+    def panels_schedule(self):
+        """-> "steps" / "sweep" / "chain", or None when not built"""
+        rc = _lib.spmv_csr_panels_schedule(self.h)
+        return None if rc < 0 else ("steps", "sweep", "chain")[rc]
+
     def panels_info(self):
         """-> dict(steps, tiles, panels, entries) or None when not built"""
         a, b, c, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
@@ -689,6 +696,11 @@ class HllDevice:
     def build_panels_like(self, model):
         _check(_lib.spmv_hll_build_panels_like(self.h, model.h),
                "spmv_hll_build_panels_like")
+
+    def panels_schedule(self):
+        """-> "steps" / "sweep" / "chain", or None when not built"""
+        rc = _lib.spmv_hll_panels_schedule(self.h)
+        return None if rc < 0 else ("steps", "sweep", "chain")[rc]
 
     def panels_info(self):
         """-> dict(steps, tiles, panels, entries) or None when not built"""

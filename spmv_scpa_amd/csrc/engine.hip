@@ -544,6 +544,20 @@ int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
     return A ? panels_info(A->panels, steps, tiles, panels, entries) : -EINVAL;
 }
 
+static int panels_schedule_of(const spmv_panels *P) {
+    if (!P)
+        return -ENOENT;
+    return panels_is_sweep(P) ? 1 : panels_is_chain(P) ? 2 : 0;
+}
+
+int spmv_csr_panels_schedule(const spmv_csr_dev *A) {
+    return A ? panels_schedule_of(A->panels) : -EINVAL;
+}
+
+int spmv_hll_panels_schedule(const spmv_hll_dev *H) {
+    return H ? panels_schedule_of(H->panels) : -EINVAL;
+}
+
 int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries) {
     return H ? panels_info(H->panels, steps, tiles, panels, entries) : -EINVAL;

@@ -56,7 +56,8 @@
 
 #define TILE_ROWS_STEPS 4096 /* "steps" schedule default: 32 KiB of LDS */
 #define SWEEP_WG_PER_CU 2
-#define SWEEP_SPIN_MAX 4096  /* polls before a wait gives up (perf only) */
+#define SWEEP_SPIN_MAX 512   /* polls (~1 us each) before a wait gives up:
+                                perf only, see phase_wait */
 #define CNT_STRIDE 32        /* one phase counter per 128-B line */
 #define SWEEP_TAIL 16384     /* zero slots behind the entries: >= 3 chunks */
 
@@ -588,13 +589,16 @@ __device__ __forceinline__ void phase_arrive(int *cnt) {
 }
 
 /* bounded: a miss only costs L2 locality */
-__device__ __forceinline__ void phase_wait(const int *cnt, int want, int spin) {
+/* returns false when the bound expired: the grid is not co-resident (another
+ * kernel holds CUs) -- the caller stops waiting for the rest of the launch */
+__device__ __forceinline__ bool phase_wait(const int *cnt, int want, int spin) {
     for (int i = 0; i < spin; ++i) {
         if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
             want)
-            return;
+            return true;
         __builtin_amdgcn_s_sleep(8);
     }
+    return false;
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -654,6 +658,9 @@ __global__ void __launch_bounds__(NT)
     const unsigned lowmask = (ABL & 2) ? 1023u : (1u << shift) - 1u;
     if (tid < 8)
         wave_done[tid] = 0;
+    bool synced = true; /* false once a wait expired: run on unsynchronised
+                           (costs L2 locality) instead of paying the bound at
+                           every panel */
 
     for (int r = 0; r < rounds; ++r) {
         const int t = r * grid + blockIdx.x;
@@ -720,8 +727,9 @@ __global__ void __launch_bounds__(NT)
         /* gather and add chunk `c`, loading the chunk after next into `f` */
         auto step = [&](sweep_chunk<Q> &c, sweep_chunk<Q> &f) {
             const int q = q0 + c.p;
-            if (c.first && !ready)
-                phase_wait(cnt + (size_t)(q - lag) * CNT_STRIDE, n_x, spin);
+            if (c.first && !ready && synced)
+                synced = phase_wait(cnt + (size_t)(q - lag) * CNT_STRIDE, n_x,
+                                    spin);
             const double *xp = x + ((int64_t)c.p << shift);
             double pr[Q][4], w[Q][4];
             unsigned rr[Q][4];
