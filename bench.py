@@ -354,6 +354,22 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in ev]
 
+    # the exchange by itself (kernel only / serial / overlapped)
+    exch_ms = None
+    if use_dist:
+        for _ in range(2):
+            sharded.exchange_only()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            sharded.exchange_only()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        exch_ms = (time.perf_counter() - t1) * 1e3 / 10
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -405,6 +421,7 @@ def main():
             "partition": "contiguous row ranges, x replicated, in-place "
                          "all-gather(y) over RCCL" if world > 1 else "single GPU",
             "chunks": chunks, "exchange": sharded.mode,
+            "exchange_ms_alone": round(exch_ms, 5) if exch_ms else None,
         },
         "roofline": {
             "bound": "hbm",

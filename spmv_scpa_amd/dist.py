@@ -210,6 +210,27 @@ class ShardedSpmv:
             self.mat.launch(self.kernel, d_x, d_y, waves_per_block=self.waves,
                             stream=st, rows=(a, b))
 
+    def exchange_only(self):
+        """the collectives of one step without the kernels (what the
+        exchange costs when nothing hides it)"""
+        if self.world == 1 and not self.force_exchange:
+            return
+        nb = len(self.bounds) - 1
+        if self.staged is not None:
+            for w in [self.staged.gather(c) for c in range(nb)]:
+                wait_all(w)
+            self.staged.finish()
+            return
+        pending = []
+        for c in range(nb):
+            if nb == 1:
+                pending.append(self.ex.gather_all(self.force_exchange))
+            else:
+                pending.append(self.ex.send_chunk(self.bounds[c],
+                                                  self.bounds[c + 1]))
+        for w in pending:
+            wait_all(w)
+
     def step(self, events=None):
         """one SpMV (+ exchange).  events = (start, stop) torch events
         recorded around the kernel launches on the current stream."""

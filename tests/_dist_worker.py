@@ -62,6 +62,8 @@ def main():
         got = y.numpy()
         assert not np.isnan(got).any(), (rank, it)
         assert np.array_equal(got, want), (rank, it)
+    sh.exchange_only()  # the collectives alone: y must come out the same
+    assert np.array_equal(y.numpy(), want), rank
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)
