@@ -1051,7 +1051,12 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         return -EINVAL;
     if (M == 0)
         return 0;
-    const size_t lds = (size_t)P->tile_rows * sizeof(double);
+    size_t lds = (size_t)P->tile_rows * sizeof(double);
+    if (const char *ev = getenv("SPMV_LDS_MIN")) { /* tuning: cap occupancy */
+        size_t o = (size_t)atoll(ev);
+        if (o > lds && o <= 160 * 1024 - 64)
+            lds = o;
+    }
     if (P->sweep) {
         /* variant (tuning): bits 4-6 lag override (1..7), bit 7 no phase
          * wait, bits 8-10 ablations, bit 11 one group of 4 per lane */
