@@ -118,6 +118,11 @@ int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
 int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model);
 /* schedule of the blocked copy: 0 steps, 1 sweep, 2 chain; -ENOENT if none */
 int spmv_csr_panels_schedule(const spmv_csr_dev *A);
+/* keep only the blocked copy: frees JA/AS, so the handle costs the HBM of
+ * the format it came from (12 B per entry).  Afterwards only the PANELS
+ * kernel id runs; the direct kernels, download, conversion and further
+ * builds return -ENODATA.  -ENOENT when no blocked copy was built. */
+int spmv_csr_release_source(spmv_csr_dev *A);
 int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ);
 int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A);
 /* download the device arrays into a host CSR (tests; generated matrices) */
@@ -148,6 +153,7 @@ int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries);
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model);
 int spmv_hll_panels_schedule(const spmv_hll_dev *H);
+int spmv_hll_release_source(spmv_hll_dev *H);
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major);
 int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H);

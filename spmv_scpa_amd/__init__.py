@@ -203,6 +203,8 @@ _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_csr_release_source", C.c_int, C.c_void_p)
+_sig("spmv_hll_release_source", C.c_int, C.c_void_p)
 _sig("spmv_csr_panels_schedule", C.c_int, C.c_void_p)
 _sig("spmv_hll_panels_schedule", C.c_int, C.c_void_p)
 _sig("spmv_csr_build_panels_like", C.c_int, C.c_void_p, C.c_void_p)
@@ -631,6 +633,10 @@ class CsrDevice:
         rc = _lib.spmv_csr_panels_schedule(self.h)
         return None if rc < 0 else ("steps", "sweep", "chain")[rc]
 
+    def release_source(self):
+        """keep only the blocked copy (frees JA/AS on the device)"""
+        _check(_lib.spmv_csr_release_source(self.h), "spmv_csr_release_source")
+
     def panels_info(self):
         """-> dict(steps, tiles, panels, entries) or None when not built"""
         a, b, c, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
@@ -701,6 +707,10 @@ class HllDevice:
         """-> "steps" / "sweep" / "chain", or None when not built"""
         rc = _lib.spmv_hll_panels_schedule(self.h)
         return None if rc < 0 else ("steps", "sweep", "chain")[rc]
+
+    def release_source(self):
+        """keep only the blocked copy (frees JA/AS on the device)"""
+        _check(_lib.spmv_hll_release_source(self.h), "spmv_hll_release_source")
 
     def panels_info(self):
         """-> dict(steps, tiles, panels, entries) or None when not built"""

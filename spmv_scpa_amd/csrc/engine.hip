@@ -463,6 +463,8 @@ int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A) {
 int spmv_csr_download(const spmv_csr_dev *A, sparse_csr **out) {
     if (!A || !out)
         return -EINVAL;
+    if (!A->ja && A->NZ > 0)
+        return -ENODATA; /* spmv_csr_release_source() */
     if (A->NZ > INT32_MAX)
         return -EOVERFLOW;
     sparse_csr *h = csr_alloc("device", A->M, A->N, (int)A->NZ);
@@ -485,6 +487,8 @@ fail:
 }
 
 int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols) {
+    if (A && !A->ja && A->NZ > 0)
+        return -ENODATA;
     if (!A)
         return -EINVAL;
     panels_free(A->panels);
@@ -493,6 +497,8 @@ int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols) {
 }
 
 int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
+    if (H && !H->ja && H->slots > 0)
+        return -ENODATA;
     if (!H)
         return -EINVAL;
     panels_free(H->panels);
@@ -505,6 +511,8 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
 int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
     if (!A || !model || !model->panels)
         return -EINVAL;
+    if (!A->ja && A->NZ > 0)
+        return -ENODATA;
     panels_free(A->panels);
     A->panels = NULL;
     const int sched = panels_is_sweep(model->panels)   ? 1
@@ -516,6 +524,8 @@ int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
     if (!H || !model || !model->panels)
         return -EINVAL;
+    if (!H->ja && H->slots > 0)
+        return -ENODATA;
     panels_free(H->panels);
     H->panels = NULL;
     const int sched = panels_is_sweep(model->panels)   ? 1
@@ -542,6 +552,36 @@ static int panels_info(const spmv_panels *P, int *steps, int *tiles,
 int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
                          int *panels, int64_t *entries) {
     return A ? panels_info(A->panels, steps, tiles, panels, entries) : -EINVAL;
+}
+
+/*
+ * Keep only the blocked copy: frees JA/AS (12 B per entry), so a handle that
+ * runs the blocked path costs the same HBM as the format it came from.
+ * Afterwards only the PANELS kernel id can be launched; the direct kernels,
+ * download, conversion and further build_panels calls return -ENODATA.
+ */
+int spmv_csr_release_source(spmv_csr_dev *A) {
+    if (!A)
+        return -EINVAL;
+    if (!A->panels)
+        return -ENOENT; /* nothing else could run the matrix */
+    (void)hipFree(A->ja);
+    (void)hipFree(A->as);
+    A->ja = NULL;
+    A->as = NULL;
+    return 0;
+}
+
+int spmv_hll_release_source(spmv_hll_dev *H) {
+    if (!H)
+        return -EINVAL;
+    if (!H->panels)
+        return -ENOENT;
+    (void)hipFree(H->ja);
+    (void)hipFree(H->as);
+    H->ja = NULL;
+    H->as = NULL;
+    return 0;
 }
 
 static int panels_schedule_of(const spmv_panels *P) {
@@ -577,6 +617,8 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                              opts ? opts->variant : 0, d_x, d_y,
                              (hipStream_t)stream);
     }
+    if (!A->ja && A->NZ > 0)
+        return -ENODATA; /* spmv_csr_release_source(): blocked path only */
     return csr_launch_kernel(A, kernel, pick_waves(opts, g_csr_waves),
                              opts ? opts->group : 0, opts ? opts->variant : 0,
                              d_x, d_y, row_begin,
@@ -686,6 +728,8 @@ int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
                       spmv_hll_dev **out) {
     if (!A || !out)
         return -EINVAL;
+    if (!A->ja && A->NZ > 0)
+        return -ENODATA;
     *out = NULL;
     const int M = A->M, nb = (M + 31) / 32;
     int rc = 0;
@@ -765,6 +809,8 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                              opts ? opts->variant : 0, d_x, d_y,
                              (hipStream_t)stream);
     }
+    if (!H->ja && H->slots > 0)
+        return -ENODATA; /* spmv_hll_release_source(): blocked path only */
     if (kernel == 1 && waves > 8)
         waves = 8; /* 6 KiB of LDS per wavefront, stay under 64 KiB */
     return hll_launch_kernel(H, kernel, waves, opts ? opts->variant : 0, d_x,

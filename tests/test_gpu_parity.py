@@ -481,6 +481,43 @@ def test_build_panels_like_copies_schedule_and_tile_height(
     A1.release()
 
 
+def test_release_source_keeps_only_the_blocked_copy(default_panel_schedule):
+    """spmv_*_release_source: JA/AS freed, the blocked path still runs, every
+    entry point that needs the source says -ENODATA."""
+    import errno
+    M, N = 20_000, 30_000
+    IRP, JA, AS = O.synth_csr(S.SYNTH_RAGGED, M, N, 12, 2000, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("rel", M, N, IRP, JA, AS)
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+    dA = S.CsrDevice.upload(A)
+    dH = dA.to_hll(True)
+    for m, blocked in ((dA, S.CSR_KERNEL_PANELS), (dH, S.HLL_KERNEL_PANELS)):
+        with pytest.raises(OSError) as ei:
+            m.release_source()  # no blocked copy yet
+        assert ei.value.errno == errno.ENOENT
+        S.set_panel_schedule("chain")
+        m.build_panels(0)
+        m.release_source()
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        m.launch(blocked, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, "blocked only")
+        for call in (lambda: m.launch(2, d_x.ptr, d_y.ptr),
+                     lambda: m.build_panels(0)):
+            with pytest.raises(OSError) as ei:
+                call()
+            assert ei.value.errno == errno.ENODATA
+    with pytest.raises(OSError) as ei:
+        dA.to_hll(True)
+    assert ei.value.errno == errno.ENODATA
+    dH.release()
+    dA.release()
+    S.csr_free(A)
+
+
 def test_autotune_picks_a_valid_kernel_and_stays_correct():
     """spmv_*_autotune: measured choice between the coalesced kernels and the
     2-D blocked path; whatever it picks must still match the oracle."""
