@@ -25,8 +25,9 @@ int g_hll_waves = 8;
 /*
  * The 2-D blocked path as a candidate.  `*bms` is the best direct kernel's
  * time on entry.  Near the stream rate (within 1.2x of it at 7 TB/s) nothing
- * is built.  Otherwise the steps layout is built with tiles of 8192 and of
- * 16384 rows and timed both as one chain launch and as one launch per step:
+ * is built.  Otherwise the steps layout is built at two tile heights (8192
+ * and 16384 rows for 10M rows, lower for smaller matrices) and timed both as
+ * one chain launch and as one launch per step:
  * column-sorted buckets turn the gathers of a banded / clustered / skewed
  * matrix into a few whole-line requests (chain, random W = 2^14: 0.63 vs
  * 1.19 ms direct; W = 2^17: 0.68 vs 1.58; W = 2^20: 0.89 vs 2.9; skewed rows
@@ -38,8 +39,8 @@ int g_hll_waves = 8;
  * overflow just drops the candidate.
  */
 template <class Build, class Time>
-static int tune_blocked(spmv_panels **slot, double stream_ms, double *bms,
-                        Build build, Time time_it) {
+static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
+                        double *bms, Build build, Time time_it) {
     if (*bms <= 1.2 * stream_ms)
         return 0;
     spmv_panels *const original = *slot; /* caller-built copy, if any */
@@ -81,9 +82,23 @@ static int tune_blocked(spmv_panels **slot, double stream_ms, double *bms,
         }
     };
     const bool far = *bms > 2.5 * stream_ms;
-    try_one(0, 8192);
-    if (!err)
-        try_one(0, 16384);
+    /* tile heights: tall tiles put more entries on a line of x, but the
+     * launch wants a few hundred of them (1M rows: 4096 rows 0.073 ms, 8192
+     * rows 0.109; 3M rows: 0.233 vs 0.267; 10M rows: 8192 or 16384) */
+    int t1 = 8192, t2 = 16384;
+    if (M < 4900000) {
+        t1 = 4096;
+        t2 = 8192;
+    }
+    if (M < 1500000) {
+        t1 = 256;
+        while (t1 * 2 <= M / 192 && t1 < 4096)
+            t1 *= 2;
+        t2 = t1 > 256 ? t1 / 2 : 0;
+    }
+    try_one(0, t1);
+    if (!err && t2)
+        try_one(0, t2);
     if (!err && far)
         try_one(1, 0);
     if (err) {
@@ -926,7 +941,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
         const double stream_ms =
             (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
         int rc = tune_blocked(
-            &H->panels, stream_ms, &bms,
+            &H->panels, H->M, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
                 return panels_from_hll(H, 0, sched, tile_rows, out);
             },
@@ -971,7 +986,7 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
     if (allow_panels) {
         const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
         int rc = tune_blocked(
-            &A->panels, stream_ms, &bms,
+            &A->panels, A->M, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
                 return panels_from_csr(A, 0, sched, tile_rows, out);
             },
