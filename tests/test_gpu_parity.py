@@ -382,9 +382,10 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
     dA = S.CsrDevice.upload(A)
     with pytest.raises(OSError):  # not built yet
         dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
+    assert dA.panels_schedule() is None
     dA.build_panels(pc)
     info = dA.panels_info()
-    assert info["entries"] == int(IRP[-1])
+    assert info["entries"] == int(IRP[-1]) and dA.panels_schedule() == sched
     assert ((info["steps"] == 1) if sched != "steps"
             else (info["steps"] <= info["panels"]))
     # sweep tuning bits (panels.hip): 16 = workgroups at most one panel
