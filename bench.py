@@ -269,20 +269,23 @@ def main():
             kk = torch.tensor([kernel], device=dev)
             dist.broadcast(kk, 0)
             kernel = int(kk.item())
+    nsplit = 2 if args.force_exchange and world == 1 else 4
     if (labels[kernel] == "tile_panels" and use_dist and L == 1
-            and Mshard % (2 * D.HACK) == 0
+            and Mshard % (nsplit * D.HACK) == 0
             and (mat.panels_schedule() != "sweep" or args.force_exchange)):
         # the blocked path runs whole matrices only: hold the rank's rows as
-        # two logical shards so that the all-gather of the first half runs
-        # under the kernel of the second.  Not for the sweep schedule: its
-        # launch wants every CU (phase counters), RCCL's kernels take some,
-        # so the overlap would only delay workgroups -- there the exchange
-        # follows the kernel.
+        # `nsplit` logical shards (4, like the row chunks of the direct
+        # kernels) so that the all-gather of one shard runs under the kernel
+        # of the next -- at 8 GPUs the exchange (560 MB in per GPU) is longer
+        # than the kernel of a matrix with locality.  Not for the sweep
+        # schedule: its launch wants every CU (phase counters), RCCL's
+        # kernels take some, so the overlap would only delay workgroups --
+        # there the exchange follows the kernel.
         model = mat if mat.panels_info() is not None else None
         for m in mats:
             if m is not model:
                 m.release()
-        L, Mshard = 2, Mshard // 2
+        L, Mshard = nsplit, Mshard // nsplit
         mats, nnz_local, slots = build_shards(L, Mshard)
         mat = mats[0]
         if model is not None:  # the tuned schedule and tile height
