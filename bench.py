@@ -265,10 +265,22 @@ def main():
         # the coalesced kernels and, if they run far below the stream rate,
         # the 2-D blocked path.  Every rank must take the same decision.
         kernel, tuned = mat.autotune(x.data_ptr(), y.data_ptr() + 8 * row0)
-        if world > 1:
-            kk = torch.tensor([kernel], device=dev)
+        if use_dist:
+            # rank 0's pick for all: kernel id and, for the blocked path, its
+            # schedule and tile height (they decide how the exchange is
+            # arranged below: every rank must issue the same collectives)
+            sched0 = {"steps": 0, "sweep": 1, "chain": 2}.get(
+                mat.panels_schedule(), -1)
+            kk = torch.tensor([kernel, sched0, mat.panels_tile_rows() or 0],
+                              device=dev)
             dist.broadcast(kk, 0)
-            kernel = int(kk.item())
+            kernel, sched0, tile0 = (int(v) for v in kk.tolist())
+            if labels[kernel] == "tile_panels":
+                want = ("steps", "sweep", "chain")[sched0]
+                if (mat.panels_schedule() != want
+                        or (want != "sweep"
+                            and mat.panels_tile_rows() != tile0)):
+                    mat.build_panels(0, want, tile0)
     nsplit = 2 if args.force_exchange and world == 1 else 4
     if (labels[kernel] == "tile_panels" and use_dist and L == 1
             and Mshard % (nsplit * D.HACK) == 0

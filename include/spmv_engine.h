@@ -118,6 +118,12 @@ int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
 int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model);
 /* schedule of the blocked copy: 0 steps, 1 sweep, 2 chain; -ENOENT if none */
 int spmv_csr_panels_schedule(const spmv_csr_dev *A);
+int spmv_csr_panels_tile_rows(const spmv_csr_dev *A); /* -ENOENT if none */
+/* blocked copy in an explicit schedule (0 steps, 1 sweep, 2 chain) and tile
+ * height (0: default; sweep sizes its own tiles): the ranks of a multi-GPU
+ * job build what rank 0 tuned */
+int spmv_csr_build_panels_as(spmv_csr_dev *A, int panel_cols, int sched,
+                             int tile_rows);
 /* keep only the blocked copy: frees JA/AS, so the handle costs the HBM of
  * the format it came from (12 B per entry).  Afterwards only the PANELS
  * kernel id runs; the direct kernels, download, conversion and further
@@ -153,6 +159,9 @@ int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries);
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model);
 int spmv_hll_panels_schedule(const spmv_hll_dev *H);
+int spmv_hll_panels_tile_rows(const spmv_hll_dev *H);
+int spmv_hll_build_panels_as(spmv_hll_dev *H, int panel_cols, int sched,
+                             int tile_rows);
 int spmv_hll_release_source(spmv_hll_dev *H);
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major);

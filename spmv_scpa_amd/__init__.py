@@ -203,6 +203,10 @@ _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_csr_panels_tile_rows", C.c_int, C.c_void_p)
+_sig("spmv_hll_panels_tile_rows", C.c_int, C.c_void_p)
+_sig("spmv_csr_build_panels_as", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+_sig("spmv_hll_build_panels_as", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 _sig("spmv_csr_release_source", C.c_int, C.c_void_p)
 _sig("spmv_hll_release_source", C.c_int, C.c_void_p)
 _sig("spmv_csr_panels_schedule", C.c_int, C.c_void_p)
@@ -620,9 +624,21 @@ class CsrDevice:
                                   stream), "spmv_csr_time")
         return ms[:iters]
 
-    def build_panels(self, panel_cols=0):
-        _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
-               "spmv_csr_build_panels")
+    def build_panels(self, panel_cols=0, sched=None, tile_rows=0):
+        """blocked copy in the process default schedule, or in an explicit
+        one ("steps" / "sweep" / "chain") and tile height"""
+        if sched is None:
+            _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
+                   "spmv_csr_build_panels")
+        else:
+            code = PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched)
+            _check(_lib.spmv_csr_build_panels_as(self.h, panel_cols, code,
+                                                 tile_rows),
+                   "spmv_csr_build_panels_as")
+
+    def panels_tile_rows(self):
+        rc = _lib.spmv_csr_panels_tile_rows(self.h)
+        return None if rc < 0 else rc
 
     def build_panels_like(self, model):
         _check(_lib.spmv_csr_build_panels_like(self.h, model.h),
@@ -695,9 +711,21 @@ class HllDevice:
                "spmv_hll_upload")
         return cls(h)
 
-    def build_panels(self, panel_cols=0):
-        _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
-               "spmv_hll_build_panels")
+    def build_panels(self, panel_cols=0, sched=None, tile_rows=0):
+        """blocked copy in the process default schedule, or in an explicit
+        one ("steps" / "sweep" / "chain") and tile height"""
+        if sched is None:
+            _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
+                   "spmv_hll_build_panels")
+        else:
+            code = PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched)
+            _check(_lib.spmv_hll_build_panels_as(self.h, panel_cols, code,
+                                                 tile_rows),
+                   "spmv_hll_build_panels_as")
+
+    def panels_tile_rows(self):
+        rc = _lib.spmv_hll_panels_tile_rows(self.h)
+        return None if rc < 0 else rc
 
     def build_panels_like(self, model):
         _check(_lib.spmv_hll_build_panels_like(self.h, model.h),

@@ -613,6 +613,38 @@ int spmv_hll_panels_schedule(const spmv_hll_dev *H) {
     return H ? panels_schedule_of(H->panels) : -EINVAL;
 }
 
+int spmv_csr_panels_tile_rows(const spmv_csr_dev *A) {
+    return !A ? -EINVAL : A->panels ? panels_tile_rows(A->panels) : -ENOENT;
+}
+
+int spmv_hll_panels_tile_rows(const spmv_hll_dev *H) {
+    return !H ? -EINVAL : H->panels ? panels_tile_rows(H->panels) : -ENOENT;
+}
+
+/* explicit schedule (0 steps, 1 sweep, 2 chain) and tile height (0: default;
+ * ignored by sweep): ranks of a multi-GPU job build what rank 0 tuned */
+int spmv_csr_build_panels_as(spmv_csr_dev *A, int panel_cols, int sched,
+                             int tile_rows) {
+    if (!A || sched < 0 || sched > 2)
+        return -EINVAL;
+    if (!A->ja && A->NZ > 0)
+        return -ENODATA;
+    panels_free(A->panels);
+    A->panels = NULL;
+    return panels_from_csr(A, panel_cols, sched, tile_rows, &A->panels);
+}
+
+int spmv_hll_build_panels_as(spmv_hll_dev *H, int panel_cols, int sched,
+                             int tile_rows) {
+    if (!H || sched < 0 || sched > 2)
+        return -EINVAL;
+    if (!H->ja && H->slots > 0)
+        return -ENODATA;
+    panels_free(H->panels);
+    H->panels = NULL;
+    return panels_from_hll(H, panel_cols, sched, tile_rows, &H->panels);
+}
+
 int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries) {
     return H ? panels_info(H->panels, steps, tiles, panels, entries) : -EINVAL;

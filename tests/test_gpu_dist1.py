@@ -22,6 +22,8 @@ pytestmark = pytest.mark.gpu
     ["--shards-per-gpu", "2", "--kernel", "4", "--window", "0"],
     # the blocked path with an exchange splits the rank's rows in two by itself
     ["--kernel", "4", "--window", "0", "--expect-shards", "2"],
+    # autotuned: the pick (kernel, blocked schedule, tile height) is broadcast
+    ["--kernel", "-1", "--window", "65536"],
 ])
 def test_bench_through_torchrun_one_rank(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -30,7 +32,7 @@ def test_bench_through_torchrun_one_rank(extra):
            "--master-port", "29577", os.path.join(S.ROOT, "bench.py"),
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu",
            "320000", "--window", "4096", "--kernel", "2", "--force-exchange",
-           "--no-cpu-baseline", "--no-extras"]
+           "--no-cpu-baseline", "--no-extras"]  # later flags override
     expect = None
     if "--expect-shards" in extra:
         i = extra.index("--expect-shards")
