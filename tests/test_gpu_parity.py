@@ -478,6 +478,21 @@ def test_build_panels_like_copies_schedule_and_tile_height(
             want, sc = O.synth_row_dot(S.SYNTH_RANDOM, 2 * M, N, 16, W, 0, 42,
                                        7, M + r)
             assert abs(y[r] - want) <= 1e-12 * sc
+    # explicit schedule and tile height (what the ranks of a multi-GPU job
+    # use to build rank 0's pick)
+    for sched, rows in (("chain", 2048), ("steps", 4096), ("sweep", 0)):
+        A1.build_panels(0, sched, rows)
+        assert A1.panels_schedule() == sched
+        if rows:
+            assert A1.panels_tile_rows() == rows
+        A1.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        y = d_y.to_numpy(np.float64, M)
+        want, sc = O.synth_row_dot(S.SYNTH_RANDOM, 2 * M, N, 16, W, 0, 42, 7,
+                                   M + 5)
+        assert abs(y[5] - want) <= 1e-12 * sc
+    with pytest.raises(OSError):
+        A1.build_panels(0, 3, 0)  # no such schedule
     A0.release()
     A1.release()
 
