@@ -255,7 +255,7 @@ __device__ __forceinline__ void stream_rows(int tid, int rows, const int *rowptr
 }
 
 __global__ void __launch_bounds__(STREAM_THREADS)
-    k_csr_stream(const int *__restrict__ rowblk,
+    k_csr_stream(const int2 *__restrict__ rowblk,
                  const unsigned char *__restrict__ mode,
                  const int *__restrict__ irp, const int *__restrict__ ja,
                  const double *__restrict__ as, const double *__restrict__ x,
@@ -267,8 +267,9 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int rb = blockIdx.x;
-    const int row_a = rowblk[rb], row_b = rowblk[rb + 1];
-    const int beg = irp[row_a], end = irp[row_b];
+    const int2 t_a = rowblk[rb], t_z = rowblk[rb + 1]; /* (row, entry) */
+    const int row_a = t_a.x, row_b = t_z.x;
+    const int beg = t_a.y, end = t_z.y;
     const int cnt = end - beg;
     const int rows = row_b - row_a;
 
@@ -459,8 +460,9 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     case 4: {
         if (A->n_rowblk > 0)
             hipLaunchKernelGGL(k_csr_stream, dim3(A->n_rowblk),
-                               dim3(STREAM_THREADS), 0, s, A->rowblk,
-                               A->rowblk_mode, A->irp, A->ja, A->as, x, y);
+                               dim3(STREAM_THREADS), 0, s,
+                               (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
+                               A->ja, A->as, x, y);
         break;
     }
     default:

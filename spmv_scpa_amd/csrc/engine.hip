@@ -323,9 +323,18 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     }
     build_rowblk(host_irp, d->M, tab, mode, &d->max_row_len);
     d->n_rowblk = (int)tab.size() - 1;
-    HIP_TRY(hipMalloc((void **)&d->rowblk, tab.size() * sizeof(int)));
-    HIP_TRY(hipMemcpy(d->rowblk, tab.data(), tab.size() * sizeof(int),
-                      hipMemcpyHostToDevice));
+    {
+        /* (first row, first entry) per range: the kernel learns both with one
+         * load instead of a load of the row and a dependent load of IRP */
+        std::vector<int> tab2(tab.size() * 2);
+        for (size_t k = 0; k < tab.size(); ++k) {
+            tab2[2 * k] = tab[k];
+            tab2[2 * k + 1] = host_irp[tab[k]];
+        }
+        HIP_TRY(hipMalloc((void **)&d->rowblk, tab2.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(d->rowblk, tab2.data(), tab2.size() * sizeof(int),
+                          hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
     HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
                       hipMemcpyHostToDevice));

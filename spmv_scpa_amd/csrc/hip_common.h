@@ -64,7 +64,8 @@ struct spmv_csr_dev {
     int *irp;   /* [M+1] */
     int *ja;    /* [NZ]  */
     double *as; /* [NZ]  */
-    /* stream kernel: workgroup k owns rows [rowblk[k], rowblk[k+1]) */
+    /* stream kernel: workgroup k owns rows [rowblk[2k], rowblk[2k+2]),
+     * entries [rowblk[2k+1], rowblk[2k+3]) */
     int *rowblk;
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
