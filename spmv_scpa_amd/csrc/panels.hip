@@ -1085,7 +1085,13 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         else if (abl == 3) { SW(256, 1, 3); }
         else if (abl == 4) { SW(256, 1, 4); }
         else if (abl == 7) { SW(256, 1, 7); }
-        else if (P->wgs_per_cu == 1) { if (variant & 2048) SW(1024, 2, 0); else SW(1024, 1, 0); }
+        else if (P->wgs_per_cu == 1) {
+            /* 512 lanes x 2 groups measured best with the 160 KiB tile
+             * (1.53 ms on config 3; 1024 x 1: 1.60); bit 11 flips the groups */
+            if (waves > 8) { if (variant & 2048) SW(1024, 2, 0); else SW(1024, 1, 0); }
+            else if (waves > 0 && waves < 8) { if (variant & 2048) SW(256, 1, 0); else SW(256, 2, 0); }
+            else { if (variant & 2048) SW(512, 1, 0); else SW(512, 2, 0); }
+        }
         else if (waves > 0 && waves < 8) { if (two) SW(256, 2, 0); else SW(256, 1, 0); }
         else if (waves >= 8) { if (two) SW(512, 2, 0); else SW(512, 1, 0); }
         else {
