@@ -11,13 +11,14 @@
  *
  * What: at upload the entries are bucketed by (row tile, column panel): a
  * tile is a range of consecutive rows whose slice of y fits LDS, a panel is
- * 2^18 columns (2 MiB of x).  Entries are stored tile-major and, inside a
- * tile, in panel order, 12 B each: one 32-bit word (row-in-tile << shift |
- * column-in-panel) and the fp64 value.  Products are added into the LDS tile
- * with the hardware LDS fp64 atomic (ds_add_f64): no segmented reduction, no
- * ordering inside a bucket.
+ * up to 2^18 columns (2 MiB of x).  Entries are stored tile-major and,
+ * inside a tile, in panel order, 12 B each: one 32-bit word (row-in-tile <<
+ * shift | column-in-panel) and the fp64 value; every bucket is column-sorted
+ * and laid out in blocks of 256 entries (block_ent_slot).  Products are
+ * added into the LDS tile with the hardware LDS fp64 atomic (ds_add_f64): no
+ * segmented reduction, no row-length sensitivity.
  *
- * Schedule "steps" (tiles of 1024 rows): ONE LAUNCH PER STEP; in step s
+ * Schedule "steps" (tiles of 32 .. 16384 rows): ONE LAUNCH PER STEP; in step s
  * workgroup t adds the s-th non-empty bucket of tile t into its y slice
  * (coalesced read-modify-write through LDS; a tile has one owner per launch,
  * launches are stream-ordered, step 0 starts from zero).  Every CU gathers
@@ -27,8 +28,8 @@
  * inside one panel, which is where this schedule wins: with the buckets
  * column-sorted a banded or skewed matrix turns into a pure stream.
  *
- * Schedule "sweep" (tiles of up to 8160 rows, 2 resident workgroups per CU):
- * ONE persistent launch; a workgroup keeps its tile of y in LDS while it
+ * Schedule "sweep" (one workgroup per CU with a tile of up to 20448 rows,
+ * or two with up to 10208 rows each, all resident): ONE persistent launch; a workgroup keeps its tile of y in LDS while it
  * walks the panels in order and writes y once.  The workgroups of an XCD are
  * kept within `lag` panels of each other by per-XCD phase counters (one
  * agent-scope add per workgroup and phase, relaxed polls): the wait is only
