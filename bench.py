@@ -400,11 +400,16 @@ def main():
             dist.destroy_process_group()
         return
 
+    wtxt = ("column window W=%s"
+            % ("N (anywhere)" if args.window <= 0 else str(W)))
+    if args.family == "banded":
+        wtxt = "columns s..s+K-1 around the diagonal"
+    elif args.family == "stencil":
+        wtxt = "grid edge %s" % ("cbrt(N)" if args.window <= 0 else str(W))
     workload = ("%s %s %dx%d per GPU (%dx%d global), hack 32, %d nnz/row, "
-                "column window W=%s, seed %d"
+                "%s, seed %d"
                 % (args.family, args.format.upper(), Mloc, Nglob, Mglob, Nglob,
-                   K, "N (anywhere)" if args.window <= 0 else str(W),
-                   MATRIX_SEED))
+                   K, wtxt, MATRIX_SEED))
     if L > 1:
         workload += ", %d logical shards of %d rows per GPU" % (L, Mshard)
     traffic = measured_traffic(workload, kname) if world == 1 else None
