@@ -46,6 +46,9 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
     spmv_panels *const original = *slot; /* caller-built copy, if any */
     spmv_panels *keep = NULL;            /* best blocked copy so far */
     int err = 0;
+    /* a blocked copy costs 12 B per entry: it has to win by 5 % over the
+     * direct kernels (not over another blocked candidate) to be kept */
+    const double direct_ms = *bms;
     /* build + time one candidate (steps layout: in both launch modes); keeps
      * it when it beats everything so far */
     auto try_one = [&](int sched, int tile_rows) {
@@ -73,7 +76,7 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
         }
         panels_set_chain(cand, best_chain);
         *slot = original;
-        if (!err && best_m < *bms) {
+        if (!err && best_m < *bms && best_m < 0.95 * direct_ms) {
             *bms = best_m;
             panels_free(keep);
             keep = cand;
