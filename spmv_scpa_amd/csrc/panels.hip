@@ -629,7 +629,8 @@ template <int Q> struct sweep_chunk {
     u32x4 en[Q];
     f64x2 va[Q], vb[Q];
     int live[Q];      /* entry u of the lane exists iff live > 64 u */
-    int p;            /* wave-uniform: panel (>= panels: past the end) */
+    int p;            /* wave-uniform: phase / panel (>= panels: past the end) */
+    int pa;           /* wave-uniform, sweep: the panel visited in phase p */
     bool first, last; /* wave-uniform: first / last chunk of its bucket */
 };
 
@@ -638,7 +639,7 @@ template <int NT, int Q, int ABL = 0> /* ABL: timing ablations, 1 = no LDS
                                          window (L1 hits) */
 __global__ void __launch_bounds__(NT)
     k_tiles_sweep(int M, int tile_rows, int tiles, int panels, int shift,
-                  int lag, int spin, unsigned total,
+                  int lag, int spin, int stagger, unsigned total,
                   const int64_t *__restrict__ bptr,
                   const int *__restrict__ blen,
                   const unsigned *__restrict__ tent,
@@ -680,13 +681,19 @@ __global__ void __launch_bounds__(NT)
         const int *bl = blen + (int64_t)t * panels;
         bool ready = !(lag > 0 && q0 >= lag); /* panel 0 of a later round */
 
-        /* position of the next chunk to load (wave-uniform) */
-        int fp = 0;
-        unsigned fk = (unsigned)bp[0], fe = fk + (unsigned)bl[0];
+        /* position of the next chunk to load (wave-uniform).  All XCDs visit
+         * the panels in the same order: the first one to touch a panel pulls
+         * it into the Infinity Cache for the other seven.  (`stagger`, tuning
+         * bit 12: phase p of XCD k visits panel p + k * panels / 8 instead --
+         * no gain at 10 M columns, 2.97 -> 3.79 ms at 80 M.) */
+        const int poff = stagger ? (int)((long long)xcd * panels / 8) : 0;
+        int fp = 0, fpa = poff % panels;
+        unsigned fk = (unsigned)bp[fpa], fe = fk + (unsigned)bl[fpa];
         bool ffirst = true;
 
         auto fill = [&](sweep_chunk<Q> &c) {
             c.p = fp;
+            c.pa = fpa;
             c.first = ffirst;
             c.last = fk + CH >= fe;
 #pragma unroll
@@ -713,10 +720,11 @@ __global__ void __launch_bounds__(NT)
                     ffirst = false;
                 } else {
                     fp += 1;
+                    fpa = fpa + 1 < panels ? fpa + 1 : 0;
                     ffirst = true;
                     if (fp < panels) {
-                        fk = (unsigned)bp[fp];
-                        fe = fk + (unsigned)bl[fp];
+                        fk = (unsigned)bp[fpa];
+                        fe = fk + (unsigned)bl[fpa];
                     } else { /* past the end: zeros of the tail */
                         fk = total;
                         fe = total;
@@ -731,7 +739,7 @@ __global__ void __launch_bounds__(NT)
             if (c.first && !ready && synced)
                 synced = phase_wait(cnt + (size_t)(q - lag) * CNT_STRIDE, n_x,
                                     spin);
-            const double *xp = x + ((int64_t)c.p << shift);
+            const double *xp = x + ((int64_t)c.pa << shift);
             double pr[Q][4], w[Q][4];
             unsigned rr[Q][4];
             int on[Q];
@@ -1060,7 +1068,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     }
     if (P->sweep) {
         /* variant (tuning): bits 4-6 lag override (1..7), bit 7 no phase
-         * wait, bits 8-10 ablations, bit 11 one group of 4 per lane */
+         * wait, bits 8-10 ablations, bit 11 the other group count, bit 12
+         * staggered panel order */
         int lag = (variant >> 4) & 7;
         if (lag == 0) /* measured best: 6 for 1 MiB panels, 3 for 2 MiB ones,
                          7 when there are hundreds of them (80 M columns:
@@ -1076,8 +1085,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A>), dim3(P->grid),       \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->tiles,      \
                            P->panels, P->shift, lag, SWEEP_SPIN_MAX,           \
-                           (unsigned)P->total, P->bptr, P->blen, P->ent,       \
-                           P->val, x, y, P->phase_cnt);                        \
+                           !!(variant & 4096), (unsigned)P->total, P->bptr,    \
+                           P->blen, P->ent, P->val, x, y, P->phase_cnt);       \
     } while (0)
         const int abl = (variant >> 8) & 7;
         const int two = !((variant >> 11) & 1); /* 2 groups of 4 per lane */
