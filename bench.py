@@ -61,6 +61,13 @@ def parse_args():
                     help="BASELINE config 5 as a FIXED problem: 8 logical "
                          "shards of --rows-per-gpu rows (80M x 80M), 8/N per "
                          "GPU; strong scaling over N = 1, 2, 4, 8")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo"],
+                    help="halo: only the rows within --halo-rows of another "
+                         "rank's range travel (opt-in; NOT the all-gather "
+                         "path BASELINE names; for matrices whose columns "
+                         "stay near the diagonal)")
+    ap.add_argument("--halo-rows", type=int, default=0,
+                    help="default: half the column window, rounded up to 32")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise RCCL and run the y exchange even with "
                          "one rank (exercises the multi-GPU path on a "
@@ -322,10 +329,23 @@ def main():
     if labels[kernel] == "tile_panels" or L > 1:
         chunks = 1  # the blocked path runs whole shards only; with logical
         #             shards the shard is the unit of overlap
+    halo = 0
+    if args.exchange == "halo":
+        halo = args.halo_rows
+        if halo <= 0:
+            if args.family == "banded":
+                halo = K
+            elif args.window > 0 and args.family != "stencil":
+                halo = (W + 1) // 2
+            else:
+                raise SystemExit("--exchange halo needs --halo-rows (or a "
+                                 "column window)")
+        halo = -(-halo // D.HACK) * D.HACK
     sharded = D.ShardedSpmv(mats if L > 1 else mat, kernel, rank, world, Mloc,
                             x, y,
                             waves_per_block=args.waves, chunks=chunks,
-                            force_exchange=args.force_exchange)
+                            force_exchange=args.force_exchange,
+                            mode="halo" if halo else None, halo_rows=halo)
 
     # ---- result check: rows of y recomputed from the workload definition ----
     sharded.step()
@@ -333,10 +353,18 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     rows = np.concatenate([[0, Mloc - 1], rng.integers(0, Mloc, 256)])
     if world > 1:  # and rows every OTHER rank computed: the exchange
-        others = [r for r in range(world) if r != rank]
-        rows = np.concatenate(
-            [rows] + [np.array([0, Mloc // 2, Mloc - 1]) + (r - rank) * Mloc
-                      for r in others])
+        extra = []
+        for r in range(world):
+            if r == rank:
+                continue
+            if halo:  # only what lies within the halo of this rank's rows
+                _, recv = sharded.halo_slices(r)
+                if recv:
+                    extra.append(np.array([recv[0], recv[1] - 1]) - row0)
+            else:
+                extra.append(np.array([0, Mloc // 2, Mloc - 1])
+                             + (r - rank) * Mloc)
+        rows = np.concatenate([rows] + extra)
     got = y[row0 + torch.as_tensor(rows, device=dev)].cpu().numpy()
     checked = 0
     for g, r in zip(got, rows):
@@ -442,6 +470,7 @@ def main():
                          "all-gather(y) over RCCL" if world > 1 else "single GPU",
             "chunks": chunks, "exchange": sharded.mode,
             "exchange_ms_alone": round(exch_ms, 5) if exch_ms else None,
+            "halo_rows": halo or None,
         },
         "roofline": {
             "bound": "hbm",

@@ -43,6 +43,29 @@ def main():
         else:
             out.copy_(res)
 
+    if mode == "halo":
+        # `chunks` = halo rows: only rows near another rank's range travel
+        H = chunks
+        sh = D.ShardedSpmv(None, 0, rank, world, rows_per_rank, x, y,
+                           mode="halo", halo_rows=H, compute=compute)
+        fI, fJ, fA = O.synth_csr(kind, M, N, K, W, 42)
+        want = O.csr_spmv(fI, fJ, fA, x.numpy())
+        for it in range(2):
+            y.fill_(float("nan"))
+            sh.step()
+            got = y.numpy()
+            lo, hi = max(0, row0 - H), min(M, row0 + rows_per_rank + H)
+            assert np.array_equal(got[lo:hi], want[lo:hi]), (rank, it)
+            assert np.isnan(got[:lo]).all() and np.isnan(got[hi:]).all()
+        y.fill_(float("nan"))
+        y[row0:row0 + rows_per_rank] = torch.from_numpy(
+            want[row0:row0 + rows_per_rank])
+        sh.exchange_only()
+        assert np.array_equal(y.numpy()[lo:hi], want[lo:hi]), rank
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank %d ok" % rank)
+        return
     if mode == "shards":
         # `chunks` logical shards per rank (bench.py --strong): the shard is
         # the unit of overlap, whatever `chunks` says

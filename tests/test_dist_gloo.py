@@ -53,7 +53,12 @@ def run_world(world, mode, chunks, rows):
                                                (3, "staged", 5),
                                                (2, "staged", 3),
                                                (2, "shards", 4),
-                                               (2, "shards", 1)])
+                                               (2, "shards", 1),
+                                               # halo rows: < a fragment, a
+                                               # whole fragment and a half
+                                               (3, "halo", 64),
+                                               (3, "halo", 960),
+                                               (2, "halo", 32)])
 def test_sharded_spmv_gloo(world, mode, chunks):
     run_world(world, mode, chunks, rows=640)
 

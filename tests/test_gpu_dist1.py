@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
     ["--kernel", "4", "--window", "0", "--expect-shards", "2"],
     # autotuned: the pick (kernel, blocked schedule, tile height) is broadcast
     ["--kernel", "-1", "--window", "65536"],
+    # opt-in halo exchange (a world of one has nobody to send to)
+    ["--exchange", "halo"],
 ])
 def test_bench_through_torchrun_one_rank(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -50,6 +52,9 @@ def test_bench_through_torchrun_one_rank(extra):
         assert j["config"]["logical_shards_per_gpu"] == L
         assert j["config"]["rows_per_gpu"] == 320000 * L
         assert j["config"]["exchange"] == "staged"
+    if "--exchange" in extra:
+        assert j["config"]["exchange"] == "halo"
+        assert j["config"]["halo_rows"] == 2048  # half of --window 4096
     if expect:
         assert j["config"]["logical_shards_per_gpu"] == expect
         assert j["config"]["rows_per_gpu"] == 320000
