@@ -49,6 +49,7 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
     /* a blocked copy costs 12 B per entry: it has to win by 5 % over the
      * direct kernels (not over another blocked candidate) to be kept */
     const double direct_ms = *bms;
+    double last_m = 1e300; /* time of the candidate tried last */
     /* build + time one candidate (steps layout: in both launch modes); keeps
      * it when it beats everything so far */
     auto try_one = [&](int sched, int tile_rows) {
@@ -62,20 +63,34 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
         }
         *slot = cand;
         double best_m = 1e300;
-        int best_chain = 0;
+        int best_chain = 0, best_waves = 0;
         for (int chain = (sched == 0 ? 1 : 0); chain >= 0 && !err; --chain) {
             panels_set_chain(cand, chain);
-            double m = 0.0;
-            rc = time_it(&m);
-            if (rc)
-                err = rc;
-            else if (m < best_m) {
-                best_m = m;
-                best_chain = chain;
+            /* tall tiles leave room for one workgroup per CU: 1024 lanes
+             * (16 wavefronts) or the 512 of the heuristic, whichever runs
+             * faster (W = 2^20 at 20448 rows: 0.80 vs 0.86 ms; W = N: 1.77
+             * vs 1.63) */
+            for (int waves = 0; waves <= (sched == 0 && chain &&
+                                          tile_rows >= 16384 ? 16 : 0);
+                 waves += 16) {
+                panels_set_waves(cand, waves);
+                double m = 0.0;
+                rc = time_it(&m);
+                if (rc) {
+                    err = rc;
+                    break;
+                }
+                if (m < best_m) {
+                    best_m = m;
+                    best_chain = chain;
+                    best_waves = waves;
+                }
             }
         }
+        panels_set_waves(cand, best_waves);
         panels_set_chain(cand, best_chain);
         *slot = original;
+        last_m = err ? 1e300 : best_m;
         if (!err && best_m < *bms && best_m < 0.95 * direct_ms) {
             *bms = best_m;
             panels_free(keep);
@@ -100,8 +115,12 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
         t2 = t1 > 256 ? t1 / 2 : 0;
     }
     try_one(0, t1);
+    const double m1 = last_m;
     if (!err && t2)
         try_one(0, t2);
+    /* taller still (160 KiB of LDS, one workgroup per CU) when height paid */
+    if (!err && t2 == 16384 && last_m < m1)
+        try_one(0, 20448);
     if (!err && far)
         try_one(1, 0);
     if (err) {
@@ -544,8 +563,11 @@ int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
     A->panels = NULL;
     const int sched = panels_is_sweep(model->panels)   ? 1
                       : panels_is_chain(model->panels) ? 2 : 0;
-    return panels_from_csr(A, 0, sched, panels_tile_rows(model->panels),
-                           &A->panels);
+    int rc = panels_from_csr(A, 0, sched, panels_tile_rows(model->panels),
+                             &A->panels);
+    if (!rc)
+        panels_set_waves(A->panels, panels_waves(model->panels));
+    return rc;
 }
 
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
@@ -557,8 +579,11 @@ int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
     H->panels = NULL;
     const int sched = panels_is_sweep(model->panels)   ? 1
                       : panels_is_chain(model->panels) ? 2 : 0;
-    return panels_from_hll(H, 0, sched, panels_tile_rows(model->panels),
-                           &H->panels);
+    int rc = panels_from_hll(H, 0, sched, panels_tile_rows(model->panels),
+                             &H->panels);
+    if (!rc)
+        panels_set_waves(H->panels, panels_waves(model->panels));
+    return rc;
 }
 
 static int panels_info(const spmv_panels *P, int *steps, int *tiles,

@@ -115,6 +115,8 @@ int panels_is_sweep(const spmv_panels *P);
 int panels_tile_rows(const spmv_panels *P);
 int panels_is_chain(const spmv_panels *P);
 void panels_set_chain(spmv_panels *P, int chain);
+void panels_set_waves(spmv_panels *P, int waves);
+int panels_waves(const spmv_panels *P);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s);
 void panels_free(spmv_panels *p);

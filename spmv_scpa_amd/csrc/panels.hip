@@ -70,6 +70,8 @@ struct spmv_panels {
     int tiles;       /* row tiles */
     int sweep;       /* built for the persistent schedule */
     int chain;       /* steps layout, launched as one chain launch */
+    int waves_hint;  /* wavefronts per workgroup when the caller passes 0
+                        (set by the autotuner; 0 = the built-in heuristic) */
     int grid;        /* sweep: workgroups of the launch */
     int wgs_per_cu;  /* sweep: workgroups sharing a CU's LDS */
     int64_t nnz;     /* entries kept */
@@ -384,7 +386,7 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
      * 2^20 (1.18) and for skewed rows (0.21) -- spmv_*_autotune tries these.
      * sweep: sweep_tile_rows(). */
     long long tr = TILE_ROWS_STEPS;
-    int grid = 0, tile_max = 16384 /* steps: 128 KiB of LDS */, per_cu = 0;
+    int grid = 0, tile_max = 20448 /* steps: 160 KiB of LDS */, per_cu = 0;
     int want_shift = 18; /* 2^18 columns = 2 MiB of x: half of an XCD's L2 */
     if (panel_cols > 0)
         want_shift = bits_for((long long)panel_cols + 1) - 1; /* floor(log2) */
@@ -1061,6 +1063,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     if (M == 0)
         return 0;
     size_t lds = (size_t)P->tile_rows * sizeof(double);
+    if (waves <= 0)
+        waves = P->waves_hint;
     if (const char *ev = getenv("SPMV_LDS_MIN")) { /* tuning: cap occupancy */
         size_t o = (size_t)atoll(ev);
         if (o > lds && o <= 160 * 1024 - 64)
@@ -1190,6 +1194,11 @@ int panels_is_chain(const spmv_panels *P) { return P ? P->chain : 0; }
 void panels_set_chain(spmv_panels *P, int chain) {
     if (P && !P->sweep)
         P->chain = chain != 0;
+}
+int panels_waves(const spmv_panels *P) { return P ? P->waves_hint : 0; }
+void panels_set_waves(spmv_panels *P, int waves) {
+    if (P)
+        P->waves_hint = waves > 0 ? waves : 0;
 }
 int panels_tile_rows(const spmv_panels *P) { return P ? P->tile_rows : 0; }
 
