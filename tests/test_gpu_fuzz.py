@@ -28,7 +28,7 @@ def _cases(n, seed):
             K = 4
         W = int(rng.choice([16, 1_000, 70_000, 1 << 30]))
         pc = int(rng.choice([0, 64, 1_000, 4_096]))
-        tile = int(rng.choice([32, 96, 1_024, 8_192, 16_384]))
+        tile = int(rng.choice([32, 96, 1_024, 8_192, 16_384, 20_448]))
         out.append((i, kind, M, N, K, W, pc, tile))
     return out
 

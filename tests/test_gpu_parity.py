@@ -416,7 +416,7 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
     S.csr_free(A)
 
 
-@pytest.mark.parametrize("tile_rows", [32, 2048, 16384])
+@pytest.mark.parametrize("tile_rows", [32, 2048, 16384, 20448])
 def test_steps_schedule_tile_heights(tile_rows, default_panel_schedule,
                                      monkeypatch):
     """The steps schedule at the tile heights the autotuner tries (16 KiB and
