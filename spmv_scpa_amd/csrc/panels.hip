@@ -429,7 +429,9 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
         shift = 32 - rbits;
     const int panels = (int)((((int64_t)(N > 0 ? N : 1) - 1) >> shift) + 1);
     const int tiles = (int)(((long long)M + tr - 1) / tr);
-    if ((uint64_t)(tiles > 0 ? tiles : 1) * (uint64_t)panels >= 0xffffffffull)
+    /* bucket tables are indexed with int (hipCUB scan length) */
+    if ((uint64_t)(tiles > 0 ? tiles : 1) * (uint64_t)panels >=
+        (uint64_t)INT32_MAX)
         return -EOVERFLOW;
 
     spmv_panels *P = (spmv_panels *)calloc(1, sizeof *P);
