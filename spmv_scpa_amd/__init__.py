@@ -559,9 +559,9 @@ class DevBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and _lib is not None:  # None at interpreter shutdown
             _lib.spmv_dev_free(self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         self.free()
@@ -681,9 +681,9 @@ class CsrDevice:
         return HllDevice(h)
 
     def release(self):
-        if self.h:
+        if self.h and _lib is not None:  # None at interpreter shutdown
             _lib.spmv_csr_release(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.release()
@@ -781,9 +781,9 @@ class HllDevice:
         return ms[:iters]
 
     def release(self):
-        if self.h:
+        if self.h and _lib is not None:
             _lib.spmv_hll_release(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.release()
@@ -880,9 +880,9 @@ class MultiGpu:
         return y
 
     def destroy(self):
-        if self.h:
+        if self.h and _lib is not None:
             _lib.spmv_mgpu_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.destroy()
