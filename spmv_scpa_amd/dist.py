@@ -401,6 +401,11 @@ def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
         dHb = dB.to_hll(True)
         row("config2 banded1M hll_threads_col_major flushed", dHb,
             med(dHb.time(1, dx, dy, 2, 20, 512 << 20, args.waves, stream=st)))
+        best, _ = dB.autotune(dx, dy, True)
+        row("config2 banded1M csr_%s (autotuned pick) flushed"
+            % S.CSR_KERNEL_LABELS[best], dB,
+            med(dB.time(best, dx, dy, 2, 20, 512 << 20, args.waves,
+                        stream=st)))
         dHb.release()
         dB.release()
     except OSError as e:
