@@ -56,6 +56,9 @@ def run_world(world, mode, chunks, rows):
                                                (2, "shards", 1),
                                                # halo rows: < a fragment, a
                                                # whole fragment and a half
+                                               # the node's real widths
+                                               (4, "staged", 4),
+                                               (8, "staged", 4),
                                                (3, "halo", 64),
                                                (3, "halo", 960),
                                                (2, "halo", 32)])
