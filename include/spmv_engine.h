@@ -84,6 +84,29 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
 #define SPMV_CSR_KERNEL_PANELS 5
 #define SPMV_HLL_KERNEL_PANELS 4
 
+/*
+ * Explicit build options of the blocked copy (spmv_*_build_panels_opts).
+ * Everything a build depends on travels in this struct -- the library reads
+ * no environment variable and, apart from the process default schedule of
+ * spmv_set_panel_schedule(), keeps no mutable global: two host threads may
+ * build and launch different handles concurrently.  Zero-initialise; 0 means
+ * "default" in every field except `sched`.
+ */
+typedef struct spmv_panel_opts {
+    int sched;            /* -1 process default, 0 steps, 1 sweep, 2 chain */
+    int panel_cols;       /* columns per panel (rounded down to 2^k); 0: 2^18 */
+    int tile_rows;        /* rows per tile of steps / chain (32..20448); 0: 4096;
+                             the sweep schedule sizes its own tiles */
+    int sweep_wgs_per_cu; /* sweep: workgroups sharing a CU's LDS (1..8);
+                             0: chosen per matrix */
+    int reserve_cus;      /* sweep: compute units left OUT of the persistent
+                             grid so that another kernel (RCCL's all-gather of
+                             the previous shard) runs beside it; 0: none */
+    int lds_min;          /* launch with at least this many bytes of dynamic
+                             LDS (caps workgroups per CU); 0: the tile */
+    int reserved[2];      /* must be 0 */
+} spmv_panel_opts;
+
 /* ---- CSR handle ---- */
 typedef struct spmv_csr_dev spmv_csr_dev;
 
@@ -101,13 +124,14 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          double *d_y, int row_begin, int row_end,
                          void *stream);
 int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols);
-/* schedule the NEXT build_panels calls prepare: 1 = "sweep" (one persistent
- * launch over all panels with phase counters; for rows that reach far beyond
- * an L2 of x; default), 2 = "chain" (one launch, a workgroup walks its
- * tile's non-empty buckets; for banded / clustered / skewed matrices),
- * 0 = "steps" (same layout as chain, one launch per non-empty panel step).
- * -EINVAL otherwise.  Environment SPMV_PANEL_SCHED=steps|sweep|chain sets
- * the initial value.  spmv_*_autotune tries them all. */
+int spmv_csr_build_panels_opts(spmv_csr_dev *A, const spmv_panel_opts *opts);
+/* schedule the NEXT spmv_*_build_panels() calls prepare: 1 = "sweep" (one
+ * persistent launch over all panels with phase counters; for rows that reach
+ * far beyond an L2 of x; initial value), 2 = "chain" (one launch, a workgroup
+ * walks its tile's non-empty buckets; for banded / clustered / skewed
+ * matrices), 0 = "steps" (same layout as chain, one launch per non-empty
+ * panel step).  -EINVAL otherwise.  spmv_*_autotune tries them all and
+ * spmv_*_build_panels_opts / _as name the schedule explicitly. */
 int spmv_set_panel_schedule(int sched);
 /* geometry of the blocked copy: kernel launches per SpMV (steps), row
  * tiles, column panels, entries kept; -ENOENT when it is not built */
@@ -153,8 +177,11 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                            const spmv_launch_opts *opts, const double *d_x,
                            double *d_y, int blk_begin, int blk_end,
                            void *stream);
-/* HLL source: slots whose value is exactly 0.0 (all pads) are dropped */
+/* HLL source: pad slots (JA == -1 on the host; remembered in a bitmap when
+ * the pads are rewritten at upload) are dropped; explicit zeros are kept,
+ * as from a CSR source */
 int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols);
+int spmv_hll_build_panels_opts(spmv_hll_dev *H, const spmv_panel_opts *opts);
 int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries);
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model);

@@ -387,13 +387,13 @@ static void launch_subwave_p(int r0, int r1, int threads, bool remap,
                            x, y);
 }
 
-static int g_subwave_passes = 8; /* tuning knob (variant bits 2-3) */
-
+/* passes: independent row groups per wavefront (tuning, variant bits 2-3;
+ * carried per launch -- the launch path keeps no process-global state) */
 template <int G>
-static void launch_subwave(int r0, int r1, int threads, bool remap,
+static void launch_subwave(int passes, int r0, int r1, int threads, bool remap,
                            const spmv_csr_dev *A, const double *x, double *y,
                            hipStream_t s) {
-    switch (g_subwave_passes) {
+    switch (passes) {
     case 2:
         launch_subwave_p<G, 2>(r0, r1, threads, remap, A, x, y, s);
         break;
@@ -410,7 +410,7 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                       int variant, const double *x, double *y, int r0, int r1,
                       hipStream_t s) {
     const bool remap = !(variant & 1);
-    g_subwave_passes = (variant & 4) ? 4 : (variant & 8) ? 2 : 8;
+    const int passes = (variant & 4) ? 4 : (variant & 8) ? 2 : 8;
     if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
         return -EINVAL;
     if (r0 == r1)
@@ -435,19 +435,19 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     case 2:
         switch (pick_group(A, group)) {
         case 2:
-            launch_subwave<2>(r0, r1, threads, remap, A, x, y, s);
+            launch_subwave<2>(passes, r0, r1, threads, remap, A, x, y, s);
             break;
         case 4:
-            launch_subwave<4>(r0, r1, threads, remap, A, x, y, s);
+            launch_subwave<4>(passes, r0, r1, threads, remap, A, x, y, s);
             break;
         case 8:
-            launch_subwave<8>(r0, r1, threads, remap, A, x, y, s);
+            launch_subwave<8>(passes, r0, r1, threads, remap, A, x, y, s);
             break;
         case 16:
-            launch_subwave<16>(r0, r1, threads, remap, A, x, y, s);
+            launch_subwave<16>(passes, r0, r1, threads, remap, A, x, y, s);
             break;
         default:
-            launch_subwave<32>(r0, r1, threads, remap, A, x, y, s);
+            launch_subwave<32>(passes, r0, r1, threads, remap, A, x, y, s);
             break;
         }
         break;

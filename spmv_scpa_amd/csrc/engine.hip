@@ -271,7 +271,8 @@ __global__ void k_block_width(int M, const int *irp, int *width) {
 
 __global__ void k_hll_fill(int M, int col_major, const int *irp,
                            const int *cja, const double *cas,
-                           const int64_t *off, int *ja, double *as) {
+                           const int64_t *off, int *ja, double *as,
+                           unsigned *padmask) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= M)
         return;
@@ -290,6 +291,7 @@ __global__ void k_hll_fill(int M, int col_major, const int *irp,
         } else {
             ja[t] = last;
             as[t] = 0.0;
+            atomicOr(padmask + (t >> 5), 1u << (t & 31));
         }
     }
 }
@@ -552,6 +554,26 @@ int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
     return panels_from_hll(H, panel_cols, -1, 0, &H->panels);
 }
 
+int spmv_csr_build_panels_opts(spmv_csr_dev *A, const spmv_panel_opts *opts) {
+    if (!A)
+        return -EINVAL;
+    if (!A->ja && A->NZ > 0)
+        return -ENODATA;
+    panels_free(A->panels);
+    A->panels = NULL;
+    return panels_from_csr_opts(A, opts, &A->panels);
+}
+
+int spmv_hll_build_panels_opts(spmv_hll_dev *H, const spmv_panel_opts *opts) {
+    if (!H)
+        return -EINVAL;
+    if (!H->ja && H->slots > 0)
+        return -ENODATA;
+    panels_free(H->panels);
+    H->panels = NULL;
+    return panels_from_hll_opts(H, opts, &H->panels);
+}
+
 /* same schedule and tile height as `model`'s blocked copy (shards of one
  * matrix: tune one, build the others alike) */
 int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
@@ -561,10 +583,9 @@ int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
         return -ENODATA;
     panels_free(A->panels);
     A->panels = NULL;
-    const int sched = panels_is_sweep(model->panels)   ? 1
-                      : panels_is_chain(model->panels) ? 2 : 0;
-    int rc = panels_from_csr(A, 0, sched, panels_tile_rows(model->panels),
-                             &A->panels);
+    spmv_panel_opts o;
+    panels_get_opts(model->panels, &o);
+    int rc = panels_from_csr_opts(A, &o, &A->panels);
     if (!rc)
         panels_set_waves(A->panels, panels_waves(model->panels));
     return rc;
@@ -577,10 +598,9 @@ int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
         return -ENODATA;
     panels_free(H->panels);
     H->panels = NULL;
-    const int sched = panels_is_sweep(model->panels)   ? 1
-                      : panels_is_chain(model->panels) ? 2 : 0;
-    int rc = panels_from_hll(H, 0, sched, panels_tile_rows(model->panels),
-                             &H->panels);
+    spmv_panel_opts o;
+    panels_get_opts(model->panels, &o);
+    int rc = panels_from_hll_opts(H, &o, &H->panels);
     if (!rc)
         panels_set_waves(H->panels, panels_waves(model->panels));
     return rc;
@@ -631,8 +651,10 @@ int spmv_hll_release_source(spmv_hll_dev *H) {
         return -ENOENT;
     (void)hipFree(H->ja);
     (void)hipFree(H->as);
+    (void)hipFree(H->padmask);
     H->ja = NULL;
     H->as = NULL;
+    H->padmask = NULL;
     return 0;
 }
 
@@ -727,6 +749,7 @@ void spmv_hll_release(spmv_hll_dev *d) {
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->off);
+    (void)hipFree(d->padmask);
     panels_free(d->panels);
     free(d);
 }
@@ -748,6 +771,11 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
     HIP_TRY(hipMalloc((void **)&d->ja, ((size_t)d->slots + 64) * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&d->as, ((size_t)d->slots + 64) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&d->off, ((size_t)nb + 1) * sizeof(int64_t)));
+    {
+        const size_t words = ((size_t)d->slots + 31) / 32 + 1;
+        HIP_TRY(hipMalloc((void **)&d->padmask, words * sizeof(unsigned)));
+        HIP_TRY(hipMemset(d->padmask, 0, words * sizeof(unsigned)));
+    }
     HIP_TRY(hipMemcpy(d->off, host_off, ((size_t)nb + 1) * sizeof(int64_t),
                       hipMemcpyHostToDevice));
     *out = d;
@@ -841,7 +869,7 @@ int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
     if (M > 0) {
         hipLaunchKernelGGL(k_hll_fill, dim3((M + 255) / 256), dim3(256), 0, 0,
                            M, d->col_major, A->irp, A->ja, A->as, d->off,
-                           d->ja, d->as);
+                           d->ja, d->as, d->padmask);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }

@@ -12,6 +12,12 @@
 #include "spmv_engine.h"
 
 #define WAVE 64 /* gfx950 wavefront */
+/* MI355X: 8 accelerator dies, workgroups are dealt to them round-robin.  The
+ * library is built for gfx950 only (Makefile) and refuses other devices
+ * (spmv_set_device / panels_build check the arch name), so this is a
+ * build-time constant rather than a queried property -- HIP exposes no XCD
+ * count. */
+#define NUM_XCD 8
 
 /* HIP status -> negative errno (the host API's error convention) */
 static inline int hip_errno(hipError_t e) {
@@ -84,6 +90,9 @@ struct spmv_hll_dev {
     int *ja;       /* [S] pads already rewritten */
     double *as;    /* [S] */
     int64_t *off;  /* [nb+1] slot offset of each block */
+    unsigned *padmask; /* [(S+31)/32] bit t set: slot t was a pad (JA == -1)
+                          before the rewrite; read only when the blocked copy
+                          is built */
     spmv_panels *panels; /* optional column-panel copy (kernel 4) */
 };
 
@@ -111,6 +120,11 @@ int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out);
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out);
+int panels_from_csr_opts(const spmv_csr_dev *A, const spmv_panel_opts *o,
+                         spmv_panels **out);
+int panels_from_hll_opts(const spmv_hll_dev *H, const spmv_panel_opts *o,
+                         spmv_panels **out);
+void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o);
 int panels_is_sweep(const spmv_panels *P);
 int panels_tile_rows(const spmv_panels *P);
 int panels_is_chain(const spmv_panels *P);

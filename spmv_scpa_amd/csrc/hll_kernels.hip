@@ -39,9 +39,12 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 /* pad rewrite on the device (reference cuda_hll.cu:173-195 does it on  */
 /* the host, block by block): pad -> previous valid column, or 0.        */
 /* ------------------------------------------------------------------ */
+/* also records which slots were pads (bit t of padmask, zeroed by the    */
+/* caller): the blocked copy drops exactly those, never an explicit zero */
 __global__ void k_hll_fix_pads(int M, int col_major,
                                const int64_t *__restrict__ off,
-                               int *__restrict__ ja) {
+                               int *__restrict__ ja,
+                               unsigned *__restrict__ padmask) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= M)
         return;
@@ -53,18 +56,23 @@ __global__ void k_hll_fix_pads(int M, int col_major,
     for (int j = 0; j < w; ++j) {
         int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
         int c = ja[t];
-        if (c < 0)
+        if (c < 0) {
             ja[t] = last;
-        else
+            atomicOr(padmask + (t >> 5), 1u << (t & 31));
+        } else {
             last = c;
+        }
     }
 }
 
 int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s) {
     if (H->M == 0)
         return 0;
+    HIP_RET(hipMemsetAsync(H->padmask, 0,
+                           (((size_t)H->slots + 31) / 32 + 1) * sizeof(unsigned),
+                           s));
     hipLaunchKernelGGL(k_hll_fix_pads, dim3((H->M + 255) / 256), dim3(256), 0,
-                       s, H->M, H->col_major, H->off, H->ja);
+                       s, H->M, H->col_major, H->off, H->ja, H->padmask);
     return hip_errno(hipGetLastError());
 }
 

@@ -51,7 +51,9 @@
  * are reproducible to rounding (tests hold them to 1e-12 of the row scale),
  * not bitwise.
  */
+#include <atomic>
 #include <hipcub/hipcub.hpp>
+#include <string.h>
 
 #include "hip_common.h"
 
@@ -74,6 +76,8 @@ struct spmv_panels {
                         (set by the autotuner; 0 = the built-in heuristic) */
     int grid;        /* sweep: workgroups of the launch */
     int wgs_per_cu;  /* sweep: workgroups sharing a CU's LDS */
+    int reserve_cus; /* sweep: CUs left out of the grid (spmv_panel_opts) */
+    int lds_min;     /* launch with at least this much dynamic LDS; 0: tile */
     int64_t nnz;     /* entries kept */
     int64_t total;   /* slots of ENT/VAL in use (bucket padding included) */
     unsigned *ent;   /* [nnz] row-in-tile << shift | column-in-panel */
@@ -87,7 +91,7 @@ struct spmv_panels {
     int *cpanel;     /* DEVICE [tiles*panels] panel of that bucket */
     int *nbk;        /* DEVICE [tiles] non-empty buckets per tile */
     int max_nbk;     /* launches needed = max over tiles */
-    int *phase_cnt;  /* DEVICE sweep: [8 XCDs][rounds*panels] arrival counters */
+    int *phase_cnt;  /* DEVICE sweep: [NUM_XCD][rounds*panels] arrival counters */
     size_t phase_cnt_bytes;
 };
 
@@ -130,8 +134,8 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
 __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
                                 int col_major, const int64_t *__restrict__ off,
                                 const int *__restrict__ ja,
-                                const double *__restrict__ as, uint64_t *key,
-                                unsigned *idx) {
+                                const unsigned *__restrict__ padmask,
+                                uint64_t *key, unsigned *idx) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= M)
         return;
@@ -145,11 +149,12 @@ __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
     const unsigned low = (1u << shift) - 1u;
     for (int j = 0; j < w; ++j) {
         int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
-        /* pads carry the value 0.0 (hip_hll.h); a slot that is exactly zero
-         * contributes nothing and is dropped */
+        /* only PAD slots are dropped (bitmap written when the pads were
+         * rewritten, hll_kernels.hip); an explicit zero is an entry like any
+         * other, exactly as from a CSR source */
         const unsigned c = (unsigned)ja[t];
-        key[t] = as[t] != 0.0 ? ((tk + (c >> shift)) << shift) | (c & low)
-                              : dropped;
+        const bool pad = (padmask[t >> 5] >> (t & 31)) & 1u;
+        key[t] = !pad ? ((tk + (c >> shift)) << shift) | (c & low) : dropped;
         idx[t] = (unsigned)t;
     }
 }
@@ -307,32 +312,15 @@ __global__ void k_max_int(int n, const int *__restrict__ v, int *out) {
     atomicMax(out, m);
 }
 
-/* 0 steps, 1 sweep, 2 chain; -1: not decided (env or default) */
-static int g_panel_sched = -1;
-
-static int panel_schedule(void) {
-    if (g_panel_sched < 0) {
-        const char *ev = getenv("SPMV_PANEL_SCHED");
-        g_panel_sched = (ev && !strcmp(ev, "steps")) ? 0
-                        : (ev && !strcmp(ev, "chain")) ? 2 : 1;
-    }
-    return g_panel_sched;
-}
+/* process default of spmv_*_build_panels(): 0 steps, 1 sweep, 2 chain.  The
+ * only process-wide setting of this file; builds that must not depend on it
+ * pass spmv_panel_opts.sched (spmv_*_build_panels_opts / _as). */
+static std::atomic<int> g_panel_sched{1};
 
 extern "C" int spmv_set_panel_schedule(int sched) {
     if (sched < 0 || sched > 2)
         return -EINVAL;
-    g_panel_sched = sched;
-    return 0;
-}
-
-/* workgroups per CU of the sweep launch: 0 = choose per matrix */
-static int sweep_wgs_override(void) {
-    if (const char *ev = getenv("SPMV_SWEEP_WGS")) { /* tuning override */
-        int o = atoi(ev);
-        if (o >= 1 && o <= 8)
-            return o;
-    }
+    g_panel_sched.store(sched, std::memory_order_relaxed);
     return 0;
 }
 
@@ -367,17 +355,27 @@ static int bits_for(long long n) { /* smallest b with 2^b >= n */
     return b;
 }
 
-static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
-                        int tile_rows, int nb,
-                        const int *irp_or_null, const int64_t *off_or_null,
-                        int col_major, const int *ja, const double *as,
-                        spmv_panels **out) {
+static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
+                        int nb, const int *irp_or_null,
+                        const int64_t *off_or_null, int col_major,
+                        const int *ja, const double *as,
+                        const unsigned *padmask, spmv_panels **out) {
     int rc = 0;
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
+    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, {0, 0}};
+    if (!o)
+        o = &dflt;
+    if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
+        o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
+        o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > 160 * 1024 - 64 ||
+        o->reserved[0] || o->reserved[1])
+        return -EINVAL;
+    const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
+    int sched = o->sched;
     if (sched < 0)
-        sched = panel_schedule();
+        sched = g_panel_sched.load(std::memory_order_relaxed);
     const int sweep = sched == 1;
     /* tile height.  steps: the taller the tile, the more entries of a bucket
      * share a line of x (fewer L2 requests) but the fewer workgroups there
@@ -398,8 +396,10 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
          * L2 requests: 1.61 vs 1.77 ms on config 3.  It needs buckets that
          * fill its 4096-slot chunks, so it is taken only above 4000 entries
          * per bucket (80 M columns, 1071 per bucket: 4.85 vs 3.35 ms). */
-        const int cus = device_cus();
-        per_cu = sweep_wgs_override();
+        int cus = device_cus();
+        if (o->reserve_cus > 0) /* keep at least one XCD's worth of CUs */
+            cus = cus - o->reserve_cus >= NUM_XCD ? cus - o->reserve_cus : NUM_XCD;
+        per_cu = o->sweep_wgs_per_cu;
         if (per_cu == 0) {
             const int tm = sweep_tile_rows_max(1);
             const long long tr1 = sweep_tile_rows(M, cus, tm);
@@ -418,11 +418,6 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
     }
     if (!sweep && tile_rows >= 32 && tile_rows <= tile_max)
         tr = tile_rows / 32 * 32;
-    if (const char *ev = getenv("SPMV_TILE_ROWS")) { /* tuning override */
-        long long o = atoll(ev);
-        if (o >= 32 && o <= tile_max)
-            tr = o / 32 * 32;
-    }
     const int rbits = bits_for(tr);
     int shift = want_shift;
     if (shift > 32 - rbits) /* row-in-tile and column-in-panel share a word */
@@ -446,6 +441,8 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
     P->chain = sched == 2;
     P->grid = sweep ? (grid < tiles ? grid : (tiles > 0 ? tiles : 1)) : 0;
     P->wgs_per_cu = per_cu;
+    P->reserve_cus = sweep ? o->reserve_cus : 0;
+    P->lds_min = o->lds_min;
     uint64_t *key[2] = {NULL, NULL};
     unsigned *idx[2] = {NULL, NULL};
     uint64_t *skey = NULL;
@@ -471,7 +468,8 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
         else
             hipLaunchKernelGGL(k_keys_from_hll, dim3((M + 255) / 256),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
-                               col_major, off_or_null, ja, as, key[0], idx[0]);
+                               col_major, off_or_null, ja, padmask, key[0],
+                               idx[0]);
         HIP_TRY(hipGetLastError());
         {
             hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
@@ -568,8 +566,8 @@ static int panels_build(int M, int N, int64_t slots, int panel_cols, int sched,
     }
     if (sweep) {
         const size_t rounds = ((size_t)tiles + P->grid - 1) / P->grid;
-        P->phase_cnt_bytes =
-            8 * (rounds ? rounds : 1) * (size_t)panels * CNT_STRIDE * sizeof(int);
+        P->phase_cnt_bytes = NUM_XCD * (rounds ? rounds : 1) * (size_t)panels *
+                             CNT_STRIDE * sizeof(int);
         HIP_TRY(hipMalloc((void **)&P->phase_cnt, P->phase_cnt_bytes));
     }
     *out = P;
@@ -657,8 +655,8 @@ __global__ void __launch_bounds__(NT)
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
     /* workgroups are dealt to the XCDs round-robin */
-    const int xcd = blockIdx.x & 7;
-    const int n_x = grid / 8 + (xcd < (grid & 7) ? 1 : 0);
+    const int xcd = blockIdx.x % NUM_XCD;
+    const int n_x = grid / NUM_XCD + (xcd < (grid % NUM_XCD) ? 1 : 0);
     const int rounds = (tiles + grid - 1) / grid;
     int *cnt = phase_cnt + (size_t)xcd * rounds * panels * CNT_STRIDE;
     const unsigned lowmask = (ABL & 2) ? 1023u : (1u << shift) - 1u;
@@ -690,7 +688,7 @@ __global__ void __launch_bounds__(NT)
          * it into the Infinity Cache for the other seven.  (`stagger`, tuning
          * bit 12: phase p of XCD k visits panel p + k * panels / 8 instead --
          * no gain at 10 M columns, 2.97 -> 3.79 ms at 80 M.) */
-        const int poff = stagger ? (int)((long long)xcd * panels / 8) : 0;
+        const int poff = stagger ? (int)((long long)xcd * panels / NUM_XCD) : 0;
         int fp = 0, fpa = poff % panels;
         unsigned fk = (unsigned)bp[fpa], fe = fk + (unsigned)bl[fpa];
         bool ffirst = true;
@@ -1046,14 +1044,17 @@ __global__ void __launch_bounds__(NT)
 
 /* tiles above 64 KiB of LDS need the opt-in, once per kernel and device */
 template <auto Kernel> static int allow_big_lds(void) {
-    static bool done[64];
+    /* one bit per device; setting the attribute twice from two host threads
+     * that race here is harmless (idempotent), losing a set bit is not */
+    static std::atomic<unsigned long long> done{0};
     int dev = 0;
     HIP_RET(hipGetDevice(&dev));
-    if (!done[dev & 63]) {
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
         HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 64));
-        done[dev & 63] = true;
+        done.fetch_or(bit, std::memory_order_release);
     }
     return 0;
 }
@@ -1067,11 +1068,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     size_t lds = (size_t)P->tile_rows * sizeof(double);
     if (waves <= 0)
         waves = P->waves_hint;
-    if (const char *ev = getenv("SPMV_LDS_MIN")) { /* tuning: cap occupancy */
-        size_t o = (size_t)atoll(ev);
-        if (o > lds && o <= 160 * 1024 - 64)
-            lds = o;
-    }
+    if ((size_t)P->lds_min > lds) /* tuning: caps workgroups per CU */
+        lds = (size_t)P->lds_min;
     if (P->sweep) {
         /* variant (tuning): bits 4-6 lag override (1..7), bit 7 no phase
          * wait, bits 8-10 ablations, bit 11 the other group count, bit 12
@@ -1179,16 +1177,41 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
  * as one chain launch), < 0 = the process default (spmv_set_panel_schedule /
  * SPMV_PANEL_SCHED); tile_rows: rows per tile of the steps layout (0 =
  * default, up to 16384) */
+int panels_from_csr_opts(const spmv_csr_dev *A, const spmv_panel_opts *o,
+                         spmv_panels **out) {
+    return panels_build(A->M, A->N, A->NZ, o, 0, A->irp, NULL, 0, A->ja, A->as,
+                        NULL, out);
+}
+
+int panels_from_hll_opts(const spmv_hll_dev *H, const spmv_panel_opts *o,
+                         spmv_panels **out) {
+    if (H->slots > 0 && !H->padmask)
+        return -ENODATA;
+    return panels_build(H->M, H->N, H->slots, o, H->nb, NULL, H->off,
+                        H->col_major, H->ja, H->as, H->padmask, out);
+}
+
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    return panels_build(A->M, A->N, A->NZ, panel_cols, sched, tile_rows, 0,
-                        A->irp, NULL, 0, A->ja, A->as, out);
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, {0, 0}};
+    return panels_from_csr_opts(A, &o, out);
 }
 
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    return panels_build(H->M, H->N, H->slots, panel_cols, sched, tile_rows,
-                        H->nb, NULL, H->off, H->col_major, H->ja, H->as, out);
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, {0, 0}};
+    return panels_from_hll_opts(H, &o, out);
+}
+
+/* the options a copy was built with (build_panels_like) */
+void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
+    memset(o, 0, sizeof *o);
+    o->sched = P->sweep ? 1 : P->chain ? 2 : 0;
+    o->panel_cols = 0;
+    o->tile_rows = P->sweep ? 0 : P->tile_rows;
+    o->sweep_wgs_per_cu = P->sweep ? P->wgs_per_cu : 0;
+    o->reserve_cus = P->reserve_cus;
+    o->lds_min = P->lds_min;
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }

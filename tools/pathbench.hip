@@ -1,0 +1,167 @@
+/*
+ * pathbench.hip -- round-2 probe: can the scalar data path (s_load through
+ * the scalar cache) pull a once-read stream into the XCD L2 fast enough to
+ * take the entry stream of the blocked SpMV off the CU's vector-memory queue?
+ *
+ *   scalar   W persistent waves per CU walk a 2 GiB buffer with
+ *            s_load_dwordx16 (64 B) or s_load_dword at a stride of 64 or
+ *            128 B, up to 8 loads outstanding per wave -> bytes touched / s
+ *   vector   the same walk with one dwordx4 per lane (reference rate)
+ *
+ * Build: hipcc --offload-arch=gfx950 -O3 tools/pathbench.hip -o tools/pathbench
+ * Result of the MI355X run: profiles/r02_pathbench_mi355x.txt
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
+
+/* each wave owns a contiguous slice; 8 scalar loads in flight, then a wait */
+template <int WIDE>
+__global__ void k_scalar_walk(const char *__restrict__ buf, size_t bytes,
+                              int stride, int *sink) {
+    const size_t waves = (size_t)gridDim.x * (blockDim.x / 64);
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const size_t slice = (bytes / waves) & ~(size_t)1023;
+    const char *p = buf + wave * slice;
+    const char *e = p + slice;
+    unsigned acc = 0;
+    for (; p + 8 * (size_t)stride <= e; p += 8 * (size_t)stride) {
+        /* readfirstlane returns int: go through unsigned, or a low word with
+         * bit 31 set sign-extends into the high word (the round's first GPU
+         * call faulted on exactly that) */
+        const unsigned a_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)p);
+        const unsigned a_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)p >> 32));
+        const uint64_t a = (uint64_t)a_lo | ((uint64_t)a_hi << 32);
+        unsigned r0, r1, r2, r3, r4, r5, r6, r7;
+        if (WIDE) {
+            /* 8 x s_load_dwordx16: 16 SGPRs each; keep only one dword live */
+            typedef unsigned u16v __attribute__((ext_vector_type(16)));
+            u16v v0, v1, v2, v3;
+            asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
+                         "s_load_dwordx16 %1, %5, 0x0\n\t"
+                         "s_load_dwordx16 %2, %6, 0x0\n\t"
+                         "s_load_dwordx16 %3, %7, 0x0\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                         : "s"(a), "s"(a + stride), "s"(a + 2 * (uint64_t)stride),
+                           "s"(a + 3 * (uint64_t)stride)
+                         : "memory");
+            r0 = v0[0]; r1 = v1[0]; r2 = v2[0]; r3 = v3[0];
+            asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
+                         "s_load_dwordx16 %1, %5, 0x0\n\t"
+                         "s_load_dwordx16 %2, %6, 0x0\n\t"
+                         "s_load_dwordx16 %3, %7, 0x0\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                         : "s"(a + 4 * (uint64_t)stride), "s"(a + 5 * (uint64_t)stride),
+                           "s"(a + 6 * (uint64_t)stride), "s"(a + 7 * (uint64_t)stride)
+                         : "memory");
+            r4 = v0[0]; r5 = v1[0]; r6 = v2[0]; r7 = v3[0];
+        } else {
+            asm volatile("s_load_dword %0, %8, 0x0\n\t"
+                         "s_load_dword %1, %9, 0x0\n\t"
+                         "s_load_dword %2, %10, 0x0\n\t"
+                         "s_load_dword %3, %11, 0x0\n\t"
+                         "s_load_dword %4, %12, 0x0\n\t"
+                         "s_load_dword %5, %13, 0x0\n\t"
+                         "s_load_dword %6, %14, 0x0\n\t"
+                         "s_load_dword %7, %15, 0x0\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4),
+                           "=&s"(r5), "=&s"(r6), "=&s"(r7)
+                         : "s"(a), "s"(a + stride), "s"(a + 2 * (uint64_t)stride),
+                           "s"(a + 3 * (uint64_t)stride), "s"(a + 4 * (uint64_t)stride),
+                           "s"(a + 5 * (uint64_t)stride), "s"(a + 6 * (uint64_t)stride),
+                           "s"(a + 7 * (uint64_t)stride)
+                         : "memory");
+        }
+        acc += r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+    }
+    if (acc == 0x12345678u)
+        *sink = (int)acc;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_vector_walk(const char *__restrict__ buf, size_t bytes, int *sink) {
+    const size_t waves = (size_t)gridDim.x * (blockDim.x / 64);
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const size_t slice = (bytes / waves) & ~(size_t)4095;
+    const char *p = buf + wave * slice + (threadIdx.x & 63) * 16;
+    const char *e = buf + (wave + 1) * slice;
+    unsigned acc = 0;
+    for (; p + 4096 <= e; p += 4096) {
+        u32x4 a = __builtin_nontemporal_load((const u32x4 *)p);
+        u32x4 b = __builtin_nontemporal_load((const u32x4 *)(p + 1024));
+        u32x4 c = __builtin_nontemporal_load((const u32x4 *)(p + 2048));
+        u32x4 d = __builtin_nontemporal_load((const u32x4 *)(p + 3072));
+        acc += a[0] ^ b[1] ^ c[2] ^ d[3];
+    }
+    if (acc == 0x12345678u)
+        *sink = (int)acc;
+}
+
+template <class F> static double time_ms(F f, int iters) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i)
+        f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms / iters;
+}
+
+int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
+    const size_t bytes = (size_t)2 << 30;
+    char *buf;
+    int *sink;
+    CK(hipMalloc(&buf, bytes));
+    CK(hipMalloc(&sink, 4));
+    CK(hipMemset(buf, 1, bytes));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device: %s CUs=%d\n", prop.gcnArchName, cus);
+    printf("== vector walk (dwordx4 nt, 4 KiB per wave step), 2 GiB\n");
+    for (int wpc : {4, 8, 16, 32}) {
+        double ms = time_ms([&] {
+            hipLaunchKernelGGL(k_vector_walk, dim3(cus * wpc / 4), dim3(256), 0, 0, buf, bytes, sink);
+        }, 3);
+        printf("waves/CU %2d : %8.3f ms  %8.1f GB/s\n", wpc, ms, bytes / ms / 1e6);
+    }
+    printf("== scalar walk, 8 loads in flight per wave\n");
+    for (int wide : {1, 0})
+        for (int stride : {64, 128})
+            for (int wpc : {4, 8, 16, 32}) {
+                double ms = time_ms([&] {
+                    if (wide)
+                        hipLaunchKernelGGL(k_scalar_walk<1>, dim3(cus * wpc / 4), dim3(256), 0, 0,
+                                           buf, bytes, stride, sink);
+                    else
+                        hipLaunchKernelGGL(k_scalar_walk<0>, dim3(cus * wpc / 4), dim3(256), 0, 0,
+                                           buf, bytes, stride, sink);
+                }, 2);
+                const double touched = (double)bytes / stride; /* loads */
+                printf("%-16s stride %3d waves/CU %2d : %8.3f ms  %7.2f Gload/s  "
+                       "(%8.1f GB/s of lines covered)\n",
+                       wide ? "s_load_dwordx16" : "s_load_dword", stride, wpc, ms,
+                       touched / ms / 1e6, bytes / ms / 1e6);
+            }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    printf("done\n");
+    return 0;
+}
