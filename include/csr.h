@@ -60,8 +60,14 @@ sparse_csr *io_load_csr(const char *path);
 
 /*
  * Binary sidecar of a loaded matrix (new): header + the three
- * CSR arrays.  io_load_csr_cached(path) reads "<path>.bin" when it is at
- * least as new as the text file, else parses the text and writes it.
+ * CSR arrays.  io_load_csr_cached(path) reads "<path>.bin" only when its
+ * header names exactly this text file (size and mtime to the nanosecond),
+ * else parses the text and replaces the sidecar (written under a temporary
+ * name and rename()d into place, so concurrent loaders never see a torn
+ * file).  Every load validates the arrays (IRP monotone from 0 to NZ, every
+ * JA in [0, N)): csr_load_bin returns ERR_PTR(-EINVAL) for a foreign header,
+ * -EIO for a truncated file, -EILSEQ for arrays that are not a CSR matrix,
+ * -ESTALE (cached path only, then re-parsed) for another file's sidecar.
  */
 int csr_save_bin(const sparse_csr *A, const char *path);
 sparse_csr *csr_load_bin(const char *path);

@@ -90,6 +90,14 @@ class LaunchOpts(C.Structure):
                 ("variant", C.c_int), ("reserved", C.c_int * 5)]
 
 
+class PanelOpts(C.Structure):
+    """spmv_panel_opts (include/spmv_engine.h)"""
+    _fields_ = [("sched", C.c_int), ("panel_cols", C.c_int),
+                ("tile_rows", C.c_int), ("sweep_wgs_per_cu", C.c_int),
+                ("reserve_cus", C.c_int), ("lds_min", C.c_int),
+                ("reserved", C.c_int * 2)]
+
+
 _CSRp = C.POINTER(SparseCSR)
 _HLLp = C.POINTER(SparseHLL)
 
@@ -202,6 +210,8 @@ _sig("spmv_csr_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
 _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
+_sig("spmv_csr_build_panels_opts", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
+_sig("spmv_hll_build_panels_opts", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_csr_panels_tile_rows", C.c_int, C.c_void_p)
 _sig("spmv_hll_panels_tile_rows", C.c_int, C.c_void_p)
@@ -304,6 +314,27 @@ def set_panel_schedule(sched):
     "steps" / "sweep" / "chain", or 0 / 1 / 2 (True = sweep, False = steps)"""
     code = PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched)
     _check(_lib.spmv_set_panel_schedule(code), "spmv_set_panel_schedule")
+
+
+def _env_int(name, lo, hi):
+    try:
+        v = int(os.environ.get(name, "0"))
+    except ValueError:
+        return 0
+    return v if lo <= v <= hi else 0
+
+
+def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
+                reserve_cus=0, lds_min=0):
+    o = PanelOpts()
+    o.sched = -1 if sched is None else (
+        PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched))
+    o.panel_cols = panel_cols
+    o.tile_rows = tile_rows or _env_int("SPMV_TILE_ROWS", 32, 20448)
+    o.sweep_wgs_per_cu = sweep_wgs_per_cu or _env_int("SPMV_SWEEP_WGS", 1, 8)
+    o.reserve_cus = reserve_cus
+    o.lds_min = lds_min or _env_int("SPMV_LDS_MIN", 1, 160 * 1024 - 64)
+    return o
 
 
 def device_info(d=0):
@@ -624,17 +655,17 @@ class CsrDevice:
                                   stream), "spmv_csr_time")
         return ms[:iters]
 
-    def build_panels(self, panel_cols=0, sched=None, tile_rows=0):
+    def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
+                     sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0):
         """blocked copy in the process default schedule, or in an explicit
-        one ("steps" / "sweep" / "chain") and tile height"""
-        if sched is None:
-            _check(_lib.spmv_csr_build_panels(self.h, panel_cols),
-                   "spmv_csr_build_panels")
-        else:
-            code = PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched)
-            _check(_lib.spmv_csr_build_panels_as(self.h, panel_cols, code,
-                                                 tile_rows),
-                   "spmv_csr_build_panels_as")
+        one ("steps" / "sweep" / "chain"), with explicit build options
+        (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
+        SPMV_SWEEP_WGS and SPMV_LDS_MIN of tools/README.md are read HERE, in
+        the harness -- the library itself reads no environment."""
+        o = _panel_opts(panel_cols, sched, tile_rows, sweep_wgs_per_cu,
+                        reserve_cus, lds_min)
+        _check(_lib.spmv_csr_build_panels_opts(self.h, C.byref(o)),
+               "spmv_csr_build_panels_opts")
 
     def panels_tile_rows(self):
         rc = _lib.spmv_csr_panels_tile_rows(self.h)
@@ -711,17 +742,17 @@ class HllDevice:
                "spmv_hll_upload")
         return cls(h)
 
-    def build_panels(self, panel_cols=0, sched=None, tile_rows=0):
+    def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
+                     sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0):
         """blocked copy in the process default schedule, or in an explicit
-        one ("steps" / "sweep" / "chain") and tile height"""
-        if sched is None:
-            _check(_lib.spmv_hll_build_panels(self.h, panel_cols),
-                   "spmv_hll_build_panels")
-        else:
-            code = PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched)
-            _check(_lib.spmv_hll_build_panels_as(self.h, panel_cols, code,
-                                                 tile_rows),
-                   "spmv_hll_build_panels_as")
+        one ("steps" / "sweep" / "chain"), with explicit build options
+        (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
+        SPMV_SWEEP_WGS and SPMV_LDS_MIN of tools/README.md are read HERE, in
+        the harness -- the library itself reads no environment."""
+        o = _panel_opts(panel_cols, sched, tile_rows, sweep_wgs_per_cu,
+                        reserve_cus, lds_min)
+        _check(_lib.spmv_hll_build_panels_opts(self.h, C.byref(o)),
+               "spmv_hll_build_panels_opts")
 
     def panels_tile_rows(self):
         rc = _lib.spmv_hll_panels_tile_rows(self.h)
@@ -886,3 +917,9 @@ class MultiGpu:
 
     def __del__(self):
         self.destroy()
+
+
+# experiment knob of the harness (tools/README.md): the library reads no
+# environment, so its process default schedule is set from here
+if os.environ.get("SPMV_PANEL_SCHED") in PANEL_SCHED:
+    _lib.spmv_set_panel_schedule(PANEL_SCHED[os.environ["SPMV_PANEL_SCHED"]])

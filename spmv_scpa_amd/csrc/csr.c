@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "csr.h"
 #include "err.h"
@@ -370,18 +371,35 @@ done:
 /* binary sidecar: the three CSR arrays behind a small header           */
 /* ------------------------------------------------------------------ */
 
-#define CSR_BIN_MAGIC 0x31525343564d5053ull /* "SPMVCSR1" */
+#define CSR_BIN_MAGIC 0x32525343564d5053ull /* "SPMVCSR2" */
 
+/*
+ * The sidecar is a cache of a parse, never a second source of truth: it
+ * names the text file it was made from (size and mtime to the nanosecond,
+ * exact match required), it is validated structurally before anything is
+ * handed on (a corrupt or foreign file must not reach a GPU kernel, where
+ * x[JA[k]] would fault), and it appears atomically (written under a
+ * temporary name, then rename()d: ranks that load the same .mtx at the same
+ * time each write their own temporary and the last rename wins whole).
+ */
 struct csr_bin_header {
     uint64_t magic;
     int32_t M, N, NZ, pad;
+    int64_t src_size;       /* bytes of the .mtx; -1: not tied to a file */
+    int64_t src_mtime_sec;  /* st_mtim of the .mtx */
+    int64_t src_mtime_nsec;
     char name[MAX_NAME];
 };
 
-int csr_save_bin(const sparse_csr *A, const char *path) {
+static int csr_write_bin(const sparse_csr *A, const char *path,
+                         const struct stat *src) {
     if (IS_ERR_OR_NULL(A) || !path)
         return -EINVAL;
-    FILE *f = fopen(path, "wb");
+    char tmp[MAX_PATH * 4 + 32];
+    if (snprintf(tmp, sizeof tmp, "%s.tmp.%ld", path, (long)getpid()) >=
+        (int)sizeof tmp)
+        return -ENAMETOOLONG;
+    FILE *f = fopen(tmp, "wb");
     if (!f)
         return -errno;
     struct csr_bin_header h;
@@ -390,6 +408,9 @@ int csr_save_bin(const sparse_csr *A, const char *path) {
     h.M = A->M;
     h.N = A->N;
     h.NZ = A->NZ;
+    h.src_size = src ? (int64_t)src->st_size : -1;
+    h.src_mtime_sec = src ? (int64_t)src->st_mtim.tv_sec : 0;
+    h.src_mtime_nsec = src ? (int64_t)src->st_mtim.tv_nsec : 0;
     memcpy(h.name, A->name, MAX_NAME);
     int ok = fwrite(&h, sizeof h, 1, f) == 1 &&
              fwrite(A->IRP, sizeof(int), (size_t)A->M + 1, f) == (size_t)A->M + 1 &&
@@ -397,19 +418,61 @@ int csr_save_bin(const sparse_csr *A, const char *path) {
              fwrite(A->AS, sizeof(double), (size_t)A->NZ, f) == (size_t)A->NZ;
     if (fclose(f) != 0)
         ok = 0;
-    return ok ? 0 : -EIO;
+    if (ok && rename(tmp, path) != 0)
+        ok = 0;
+    if (!ok) {
+        int e = errno ? -errno : -EIO;
+        (void)remove(tmp);
+        return e == 0 ? -EIO : e;
+    }
+    return 0;
 }
 
-sparse_csr *csr_load_bin(const char *path) {
+int csr_save_bin(const sparse_csr *A, const char *path) {
+    return csr_write_bin(A, path, NULL);
+}
+
+/* IRP starts at 0, never decreases, ends at NZ; every column is in [0, N) */
+static int csr_arrays_valid(const sparse_csr *A) {
+    const int M = A->M, N = A->N, NZ = A->NZ;
+    if (A->IRP[0] != 0 || A->IRP[M] != NZ)
+        return 0;
+    int bad = 0;
+#pragma omp parallel for reduction(| : bad) schedule(static)
+    for (int i = 0; i < M; ++i)
+        bad |= A->IRP[i + 1] < A->IRP[i];
+#pragma omp parallel for reduction(| : bad) schedule(static)
+    for (int k = 0; k < NZ; ++k)
+        bad |= (unsigned)A->JA[k] >= (unsigned)N;
+    return !bad;
+}
+
+static sparse_csr *csr_read_bin(const char *path, const struct stat *src) {
     FILE *f = fopen(path, "rb");
     if (!f)
         return ERR_PTR(-errno);
     struct csr_bin_header h;
+    struct stat st;
     sparse_csr *A = NULL;
     int rc = 0;
     if (fread(&h, sizeof h, 1, f) != 1 || h.magic != CSR_BIN_MAGIC ||
         h.M < 0 || h.N < 0 || h.NZ < 0) {
         rc = -EINVAL;
+        goto out;
+    }
+    /* made from exactly this text file? (size and mtime to the nanosecond) */
+    if (src && (h.src_size != (int64_t)src->st_size ||
+                h.src_mtime_sec != (int64_t)src->st_mtim.tv_sec ||
+                h.src_mtime_nsec != (int64_t)src->st_mtim.tv_nsec)) {
+        rc = -ESTALE;
+        goto out;
+    }
+    /* the file must hold exactly the arrays the header promises */
+    if (fstat(fileno(f), &st) != 0 ||
+        (uint64_t)st.st_size !=
+            sizeof h + ((uint64_t)h.M + 1) * sizeof(int) +
+                (uint64_t)h.NZ * (sizeof(int) + sizeof(double))) {
+        rc = -EIO;
         goto out;
     }
     h.name[MAX_NAME - 1] = '\0';
@@ -421,9 +484,10 @@ sparse_csr *csr_load_bin(const char *path) {
     }
     if (fread(A->IRP, sizeof(int), (size_t)h.M + 1, f) != (size_t)h.M + 1 ||
         fread(A->JA, sizeof(int), (size_t)h.NZ, f) != (size_t)h.NZ ||
-        fread(A->AS, sizeof(double), (size_t)h.NZ, f) != (size_t)h.NZ ||
-        A->IRP[0] != 0 || A->IRP[h.M] != h.NZ)
+        fread(A->AS, sizeof(double), (size_t)h.NZ, f) != (size_t)h.NZ)
         rc = -EIO;
+    else if (!csr_arrays_valid(A))
+        rc = -EILSEQ; /* not a CSR matrix: corrupt or foreign file */
 out:
     fclose(f);
     if (rc) {
@@ -433,24 +497,31 @@ out:
     return A;
 }
 
-/* "<path>.bin" next to the text file: read it when it is at least as new as
- * the .mtx, otherwise parse the text and (best effort) write the sidecar */
+sparse_csr *csr_load_bin(const char *path) {
+    if (!path)
+        return ERR_PTR(-EINVAL);
+    return csr_read_bin(path, NULL);
+}
+
+/* "<path>.bin" next to the text file: read it when it was made from exactly
+ * this .mtx and passes validation, otherwise parse the text and (best
+ * effort) replace the sidecar */
 sparse_csr *io_load_csr_cached(const char *path) {
     char bin[MAX_PATH * 4];
-    struct stat st_txt, st_bin;
-    if (snprintf(bin, sizeof bin, "%s.bin", path) >= (int)sizeof bin)
+    struct stat st_txt;
+    if (!path)
+        return ERR_PTR(-EINVAL);
+    if (snprintf(bin, sizeof bin, "%s.bin", path) >= (int)sizeof bin ||
+        stat(path, &st_txt) != 0)
         return io_load_csr(path);
-    if (stat(path, &st_txt) == 0 && stat(bin, &st_bin) == 0 &&
-        st_bin.st_mtime >= st_txt.st_mtime) {
-        sparse_csr *A = csr_load_bin(bin);
-        if (!IS_ERR(A)) {
-            extract_matrix_name(path, A->name);
-            return A;
-        }
+    sparse_csr *A = csr_read_bin(bin, &st_txt);
+    if (!IS_ERR(A)) {
+        extract_matrix_name(path, A->name);
+        return A;
     }
-    sparse_csr *A = io_load_csr(path);
+    A = io_load_csr(path);
     if (!IS_ERR(A))
-        (void)csr_save_bin(A, bin);
+        (void)csr_write_bin(A, bin, &st_txt);
     return A;
 }
 

@@ -329,12 +329,17 @@ static int sweep_tile_rows_max(int per_cu) {
     return (int)((160 * 1024 - 64 * per_cu) / per_cu / 8 / 32 * 32);
 }
 
+/* compute units of the current device; -ENODEV unless it is a gfx950 (the
+ * XCD count and dispatch order the sweep schedule relies on, NUM_XCD, are
+ * facts of that chip; the code objects are built for it alone anyway) */
 static int device_cus(void) {
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipGetDeviceProperties(&prop, dev) != hipSuccess)
-        return 256;
+        return -ENODEV;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return -ENODEV;
     return prop.multiProcessorCount;
 }
 
@@ -397,6 +402,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
          * fill its 4096-slot chunks, so it is taken only above 4000 entries
          * per bucket (80 M columns, 1071 per bucket: 4.85 vs 3.35 ms). */
         int cus = device_cus();
+        if (cus < 0)
+            return cus;
         if (o->reserve_cus > 0) /* keep at least one XCD's worth of CUs */
             cus = cus - o->reserve_cus >= NUM_XCD ? cus - o->reserve_cus : NUM_XCD;
         per_cu = o->sweep_wgs_per_cu;
@@ -587,8 +594,8 @@ fail:
 /* ------------------------------------------------------------------ */
 /* schedule "sweep": one persistent launch                               */
 /* ------------------------------------------------------------------ */
-__device__ __forceinline__ void phase_arrive(int *cnt) {
-    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void phase_arrive(int *cnt, int n = 1) {
+    __hip_atomic_fetch_add(cnt, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* bounded: a miss only costs L2 locality */
@@ -649,19 +656,19 @@ __global__ void __launch_bounds__(NT)
                   const double *__restrict__ x, double *__restrict__ y,
                   int *phase_cnt) {
     extern __shared__ double ytile[];
-    __shared__ int wave_done[8];
     constexpr int WAVES = NT / WAVE;
     constexpr unsigned CH = NT * Q * 4;
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
-    /* workgroups are dealt to the XCDs round-robin */
+    /* workgroups are dealt to the XCDs round-robin.  Every WAVEFRONT arrives
+     * at the phase counter itself when it has finished a panel (no
+     * workgroup-local arrival ring that a wave running panels ahead could
+     * wrap): a phase is complete at n_x * WAVES arrivals. */
     const int xcd = blockIdx.x % NUM_XCD;
-    const int n_x = grid / NUM_XCD + (xcd < (grid % NUM_XCD) ? 1 : 0);
+    const int n_x = (grid / NUM_XCD + (xcd < (grid % NUM_XCD) ? 1 : 0)) * WAVES;
     const int rounds = (tiles + grid - 1) / grid;
     int *cnt = phase_cnt + (size_t)xcd * rounds * panels * CNT_STRIDE;
     const unsigned lowmask = (ABL & 2) ? 1023u : (1u << shift) - 1u;
-    if (tid < 8)
-        wave_done[tid] = 0;
     bool synced = true; /* false once a wait expired: run on unsynchronised
                            (costs L2 locality) instead of paying the bound at
                            every panel */
@@ -672,7 +679,7 @@ __global__ void __launch_bounds__(NT)
         if (t >= tiles) { /* no tile this round: arrive at all its phases */
             if (tid == 0)
                 for (int p = 0; p < panels; ++p)
-                    phase_arrive(cnt + (size_t)(q0 + p) * CNT_STRIDE);
+                    phase_arrive(cnt + (size_t)(q0 + p) * CNT_STRIDE, WAVES);
             continue;
         }
         for (int i = tid; i < tile_rows; i += NT)
@@ -780,15 +787,8 @@ __global__ void __launch_bounds__(NT)
                 }
             if (last) {
                 ready = lag <= 0 || q + 1 < lag || polled >= n_x;
-                if ((tid & (WAVE - 1)) == 0) {
-                    /* the wave of the workgroup that finishes the panel last
-                     * arrives for all of them */
-                    const int old = atomicAdd(&wave_done[q & 7], 1);
-                    if (old == WAVES - 1) {
-                        wave_done[q & 7] = 0;
-                        phase_arrive(cnt + (size_t)q * CNT_STRIDE);
-                    }
-                }
+                if ((tid & (WAVE - 1)) == 0)
+                    phase_arrive(cnt + (size_t)q * CNT_STRIDE);
             }
         };
 

@@ -287,7 +287,8 @@ def test_config3_random_hll_full_size_properties(W):
     # per round (10M rows: 2 rounds of 256 tiles of <= 20448 rows with
     # 2^17-column panels, or of 512 tiles of <= 10208 rows with 2^18)
     assert info["entries"] == M * K and info["steps"] == 1
-    assert (info["tiles"], info["panels"]) in ((512, 77), (1022, 39))
+    # (which tile / panel geometry the build picks is a tuning decision:
+    # tests/test_gpu_tuning.py, not a parity matter)
     for tag, fn in (("hll1", lambda: dH.launch(1, d_x.ptr, d_y.ptr)),
                     ("hll2", lambda: dH.launch(2, d_x.ptr, d_y.ptr)),
                     ("hll4", lambda: dH.launch(S.HLL_KERNEL_PANELS, d_x.ptr,
@@ -329,7 +330,7 @@ def test_config5_one_shard_of_the_8_gpu_problem():
     want = np.array([O.synth_row_dot(S.SYNTH_RANDOM, 8 * M, N, K, W, 0, 42, 7,
                                      row0 + int(g)) for g in rows])
     best, ms = dH.autotune(d_x.ptr, d_y.ptr)
-    assert best == S.HLL_KERNEL_PANELS  # 6 ms direct vs ~3.4 ms blocked
+    assert 0 <= best < len(S.HLL_KERNEL_LABELS)  # which one: test_gpu_tuning
     ys = {}
     for tag, k in (("direct", 2), ("autotuned", best)):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)

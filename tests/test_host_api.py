@@ -360,3 +360,98 @@ def test_parallel_loader_falls_back_on_unclean_tokens(tmp_path):
             with pytest.raises(OSError) as ei:
                 S.io_load_csr(q)
             assert ei.value.errno == -rc, (name, ei.value.errno, rc)
+
+
+# ---- the .bin sidecar is a validated cache tied to its source ----
+_HDR = 8 + 16 + 24 + 64  # magic, M N NZ pad, src size/sec/nsec, name[MAX_NAME]
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sidecar_case(tmp_path):
+    import shutil
+    p = str(tmp_path / "gen.mtx")
+    shutil.copy(os.path.join(GOLD, "gen.mtx"), p)
+    A = S.io_load_csr_cached(p)  # parses the text, writes the sidecar
+    I, J, V = (a.copy() for a in S.csr_arrays(A))
+    S.csr_free(A)
+    assert os.path.exists(p + ".bin")
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    assert os.path.getsize(p + ".bin") == _HDR + 4 * len(I) + 12 * len(J)
+    return p, I, J, V
+
+
+def test_sidecar_is_used_only_for_its_own_source(tmp_path):
+    p, I, J, V = _sidecar_case(tmp_path)
+    off_as = _HDR + 4 * len(I) + 4 * len(J)
+    with open(p + ".bin", "r+b") as f:  # a VALID sidecar with another value:
+        f.seek(off_as)                  # proves the cache is what is read
+        f.write(np.float64(123.25).tobytes())
+    A = S.io_load_csr_cached(p)
+    assert S.csr_arrays(A)[2][0] == 123.25
+    S.csr_free(A)
+    # same size, same second, other nanosecond: stale -> re-parsed, replaced
+    st = os.stat(p)
+    txt = open(p).read().replace("1.5", "2.5")
+    open(p, "w").write(txt)
+    sec = st.st_mtime_ns // 10**9
+    os.utime(p, ns=(st.st_atime_ns, sec * 10**9 + (st.st_mtime_ns + 7) % 10**9))
+    assert os.stat(p).st_size == st.st_size
+    A = S.io_load_csr_cached(p)
+    assert S.csr_arrays(A)[2][0] == 2.5
+    S.csr_free(A)
+    B = S.csr_load_bin(p + ".bin")  # the replaced sidecar holds the new parse
+    assert S.csr_arrays(B)[2][0] == 2.5
+    S.csr_free(B)
+    # a sidecar saved without a source (csr_save_bin) or from another file
+    # is never trusted by the cached loader
+    other = str(tmp_path / "sym.mtx")
+    import shutil
+    shutil.copy(os.path.join(GOLD, "sym.mtx"), other)
+    C2 = S.io_load_csr(other)
+    S.csr_save_bin(C2, p + ".bin")
+    S.csr_free(C2)
+    A = S.io_load_csr_cached(p)
+    assert A.contents.M == 4 and S.csr_arrays(A)[2][0] == 2.5
+    S.csr_free(A)
+
+
+@pytest.mark.parametrize("what", ["ja_range", "ja_negative", "irp_order",
+                                  "irp_end", "truncated", "extra", "magic"])
+def test_corrupt_sidecar_never_reaches_the_kernels(tmp_path, what):
+    import errno
+    p, I, J, V = _sidecar_case(tmp_path)
+    b = p + ".bin"
+    with open(b, "r+b") as f:
+        if what == "ja_range":
+            f.seek(_HDR + 4 * len(I) + 4 * 2)
+            f.write(np.int32(5).tobytes())  # N = 5: first invalid column
+        elif what == "ja_negative":
+            f.seek(_HDR + 4 * len(I))
+            f.write(np.int32(-1).tobytes())
+        elif what == "irp_order":
+            f.seek(_HDR + 4 * 1)
+            f.write(np.int32(4).tobytes())  # IRP = 0 4 3 6 7
+        elif what == "irp_end":
+            f.seek(_HDR + 4 * (len(I) - 1))
+            f.write(np.int32(6).tobytes())
+        elif what == "truncated":
+            f.truncate(os.path.getsize(b) - 8)
+        elif what == "extra":
+            f.seek(0, 2)
+            f.write(b"\0" * 8)
+        elif what == "magic":
+            f.write(b"SPMVCSR1")  # round 1's format is refused, not misread
+    want = {"truncated": errno.EIO, "extra": errno.EIO,
+            "magic": errno.EINVAL}.get(what, errno.EILSEQ)
+    with pytest.raises(OSError) as e:
+        S.csr_load_bin(b)
+    assert e.value.errno == want
+    # the cached loader falls back to the text and repairs the sidecar
+    A = S.io_load_csr_cached(p)
+    gI, gJ, gV = S.csr_arrays(A)
+    assert np.array_equal(gI, I) and np.array_equal(gJ, J)
+    assert np.array_equal(bits(gV), bits(V))
+    S.csr_free(A)
+    B = S.csr_load_bin(b)
+    assert np.array_equal(S.csr_arrays(B)[1], J)
+    S.csr_free(B)
