@@ -2,12 +2,15 @@
 """bench.py -- headline benchmark of the MI355X SpMV engine.
 
 Metric (BASELINE.json): fp64 SpMV GFLOP/s + achieved HBM GB/s (% of the
-8 TB/s roofline) at 1/2/4/8 MI355X.  Workload (BASELINE.json configs[2], the
-one the >=60 %-of-roofline target is quoted on; configs[4] at 8 GPUs):
-synthetic random HLL, hack 32, 32 nnz/row, 10M rows PER GPU (weak scaling),
-N = 10M x n_gpus columns, rows partitioned by contiguous ranges, x replicated,
-every rank computes its y fragment with the HLL kernel and the fragments are
-all-gathered in place over RCCL (torch.distributed backend "nccl").
+8 TB/s roofline) at 1/2/4/8 MI355X.  Default workload (BASELINE.json
+configs[2], the one the >=60 %-of-roofline target is quoted on; configs[4]
+at 8 GPUs): synthetic random HLL, hack 32, 32 nnz/row, 10M rows PER GPU (weak
+scaling), N = 10M x n_gpus columns ANYWHERE (W = N, the family's worst case),
+rows partitioned by contiguous ranges, x replicated, every rank computes its
+y fragment and the fragments are all-gathered in place over RCCL
+(torch.distributed backend "nccl").  SURVEY 8d asks for W = N and the banded
+members of the family side by side: `roofline.variants` carries W = 2^20 and
+W = 2^17 measured in the same run.
 
 A step = one SpMV over the whole matrix (+ the all-gather of y when N > 1),
 inputs resident in HBM.  value = 2 * nnz_global / step time, in GFLOP/s
@@ -15,6 +18,8 @@ inputs resident in HBM.  value = 2 * nnz_global / step time, in GFLOP/s
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+    python bench.py --config 4     # nlpkkt160-sized .mtx through the loader
+    python bench.py --config 2     # 1M banded CSR, 16/row, flushed
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +28,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,23 +38,31 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ROWS_PER_GPU = 10_000_000
 NNZ_PER_ROW = 32
 MATRIX_SEED, X_SEED = 42, 7
+FAMILIES = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3, "stencil": 4}
+# the reference's thread ladder (src/main.c:176-180) + serial + all cores
+REF_LADDER = (2, 4, 8, 16, 32, 40)
+METRIC = ("fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), "
+          "1/2/4/8 MI355X")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
+                    help="BASELINE.json config: 3 = 10M x 10M random HLL "
+                         "(headline, default), 2 = 1M banded CSR (flushed), "
+                         "4 = nlpkkt160-sized .mtx through the loader (CSR)")
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--nnz-row", type=int, default=NNZ_PER_ROW)
     ap.add_argument("--window", type=int, default=0,
                     help="column window W of the random family; 0 = N "
                          "(columns anywhere: the worst case)")
-    ap.add_argument("--family", default="random",
-                    choices=["banded", "random", "ragged", "kkt", "stencil"])
+    ap.add_argument("--family", default="random", choices=sorted(FAMILIES))
     ap.add_argument("--format", default="hll", choices=["hll", "csr"])
     ap.add_argument("--kernel", type=int, default=-1,
-                    help="kernel id (hip_hll.h / hip_csr.h); -1 = default")
+                    help="kernel id (hip_hll.h / hip_csr.h); -1 = autotuned")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--chunks", type=int, default=0,
                     help="N>1: split each shard into row chunks and overlap "
@@ -61,113 +75,155 @@ def parse_args():
                     help="BASELINE config 5 as a FIXED problem: 8 logical "
                          "shards of --rows-per-gpu rows (80M x 80M), 8/N per "
                          "GPU; strong scaling over N = 1, 2, 4, 8")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N>1: skip the extra fixed-problem measurement "
+                         "reported in config.strong")
+    ap.add_argument("--reserve-cus", type=int, default=8,
+                    help="N>1, sweep schedule: compute units left to RCCL's "
+                         "kernels in the overlapped arrangement")
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo"],
                     help="halo: only the rows within --halo-rows of another "
                          "rank's range travel (opt-in; NOT the all-gather "
-                         "path BASELINE names; for matrices whose columns "
-                         "stay near the diagonal)")
-    ap.add_argument("--halo-rows", type=int, default=0,
-                    help="default: half the column window, rounded up to 32")
+                         "path BASELINE names)")
+    ap.add_argument("--halo-rows", type=int, default=0)
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise RCCL and run the y exchange even with "
                          "one rank (exercises the multi-GPU path on a "
                          "1-GPU box)")
+    ap.add_argument("--mtx", default="",
+                    help="--config 4: Matrix Market file (default: "
+                         "$SPMV_MTX_DIR/nlpkkt160.mtx, else the generated "
+                         "nlpkkt160-shaped file)")
+    ap.add_argument("--kkt-n", type=int, default=160,
+                    help="--config 4: grid edge of the generated file")
+    ap.add_argument("--cpu-csv-dir", default="",
+                    help="where the cpu_baseline leg appends serial.csv / "
+                         "omp.csv rows (reference schema); default "
+                         "gpurun_out/cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(family, K, W):
-    """The reference's own serial + OpenMP CPU path (oracle/_ref/ref_fast,
-    built from /root/reference/src by oracle/build_ref.sh) on a bounded
-    sample of the same workload; falls back to the oracle port."""
-    rows = 2_000_000
-    kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3,
-            "stencil": 4}[family]
-    host = os.cpu_count() or 1
-    # the GPU box gives one GPU's share of the host (16 cores): time the
-    # reference's ladder up to 32 threads and report the best
-    ladder = [t for t in (4, 8, 16, 32) if t <= host] or [host]
-    cores = max(ladder)
-    sample = ("%s %dx%d, %d nnz/row, W=%d (same generator, %d of the %d rows)"
-              % (family, rows, rows, K, W, rows, ROWS_PER_GPU))
+# ---------------------------------------------------------------- CPU baseline
+def host_cpus():
+    """(threads visible to this process, cgroup CPU quota or None)"""
+    try:
+        vis = len(os.sched_getaffinity(0))
+    except AttributeError:
+        vis = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    return vis, quota
+
+
+def thread_ladder(nproc):
+    """serial is always timed; OpenMP at the reference's counts and at all
+    visible hardware threads"""
+    return sorted({t for t in REF_LADDER if t <= nproc} | {nproc})
+
+
+def log_cpu_rows(S, out_dir, name, M, N, nnz, runs):
+    """append the runs to serial.csv / omp.csv through the product's logger
+    (reference schema, logger.c:19-54)"""
+    import ctypes as C
+    os.makedirs(out_dir, exist_ok=True)
+    if S._lib.logger_init(os.fsencode(out_dir)) != 0:
+        return None
+    hdr = S.SparseCSR()
+    hdr.name = name.encode()[:63]
+    hdr.M, hdr.N, hdr.NZ = M, N, nnz
+    for r in runs:
+        if r["format"] != "CSR":
+            continue
+        b = S.Bench()
+        b.duration_ms, b.gflops = r["median_ms"], r["gflops"]
+        if r["bench"] == "serial":
+            S._lib.log_csr_serial_benchmark(C.byref(hdr), b)
+        else:
+            bo = S.BenchOmp()
+            bo.name = r["bench"].encode()
+            bo.bench, bo.num_threads = b, r["threads"]
+            S._lib.log_csr_omp_benchmark(C.byref(hdr), bo)
+    S._lib.logger_close()
+    return out_dir
+
+
+def cpu_baseline(S, kind, M, N, K, W, csv_dir, name, reps=2):
+    """The reference's own serial + OpenMP CSR path (oracle/_ref/ref_fast,
+    built from /root/reference/src by oracle/build_ref.sh with the
+    reference's flags) on the SAME full-size input, thread ladder
+    {1, 2, 4, 8, 16, 32, 40, nproc} (src/main.c:176-180 + all cores),
+    OMP_PROC_BIND=close.  Wall time is bounded by `reps` and by leaving out
+    the HLL legs (the reference's serial csr_to_hll alone takes ~15 s at this
+    size), never by shrinking the matrix.  Falls back to the oracle port."""
+    nproc, quota = host_cpus()
+    ladder = thread_ladder(nproc)
+    sample = ("full size: %s %dx%d, %d nnz/row, W=%s, same generator and "
+              "seeds as the GPU run; CSR serial + omp_guided + omp_nnz, "
+              "median of %d" % (name, M, N, K,
+                                "N" if W >= 2 * N else str(W), reps))
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_fast")
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close",
-               OMP_PLACES="cores")
+    env = dict(os.environ, OMP_NUM_THREADS=str(max(ladder)),
+               OMP_PROC_BIND="close", OMP_PLACES="cores", REF_TIME_HLL="0")
+    err = "oracle/_ref/ref_fast not present"
     if os.path.exists(ref):
         try:
+            t0 = time.time()
             out = subprocess.run(
-                [ref, "time", str(kind), str(rows), str(rows), str(K), str(W),
-                 str(MATRIX_SEED), str(X_SEED), "3"] + [str(t) for t in ladder],
-                capture_output=True, text=True, timeout=600, env=env, check=True)
-            runs = json.loads(out.stdout)["runs"]
+                [ref, "time", str(kind), str(M), str(N), str(K), str(W),
+                 str(MATRIX_SEED), str(X_SEED), str(reps)]
+                + [str(t) for t in ladder],
+                capture_output=True, text=True, timeout=900, env=env,
+                check=True)
+            res = json.loads(out.stdout)
+            runs = res["runs"]
             best = max(runs, key=lambda r: r["gflops"])
-            serial = [r for r in runs if r["bench"] == "serial"
-                      and r["format"] == "CSR"][0]
+            serial = [r for r in runs if r["bench"] == "serial"][0]
+            logged = log_cpu_rows(S, csv_dir, name, M, N, res["nnz"], runs)
             return {"value": round(best["gflops"], 3), "unit": "GFLOP/s",
                     "cores": best["threads"], "kind": "reference",
                     "sample": sample,
                     "best": "%s %s" % (best["format"], best["bench"]),
                     "serial_csr_gflops": round(serial["gflops"], 3),
-                    "host_cores": host, "runs": runs}
+                    "host_threads": nproc, "cpu_quota": quota,
+                    "ladder": [[r["bench"], r["threads"],
+                                round(r["gflops"], 3)] for r in runs],
+                    "csv_dir": logged, "wall_s": round(time.time() - t0, 1)}
         except Exception as e:  # pragma: no cover - depends on the box
             err = "ref_fast failed: %r" % (e,)
-    else:
-        err = "oracle/_ref/ref_fast not present"
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
-    IRP, JA, AS = O.synth_csr(kind, rows, rows, K, W, MATRIX_SEED)
-    x = O.synth_x(X_SEED, 0, rows)
+    rows = min(M, 2_000_000)  # the port is serial numpy/C glue: keep it short
+    IRP, JA, AS = O.synth_csr(kind, rows, N, K, W, MATRIX_SEED)
+    x = O.synth_x(X_SEED, 0, N)
     ms1 = O.time_csr_ms(IRP, JA, AS, x, 1, 3)
-    msn = O.time_csr_ms(IRP, JA, AS, x, cores, 3)
-    best_ms, thr = (ms1, 1) if ms1 <= msn else (msn, cores)
+    msn = O.time_csr_ms(IRP, JA, AS, x, nproc, 3)
+    best_ms, thr = (ms1, 1) if ms1 <= msn else (msn, nproc)
     return {"value": round(2.0 * len(JA) / (best_ms * 1e6), 3),
-            "unit": "GFLOP/s", "cores": thr, "kind": "port", "sample": sample,
-            "note": err, "host_cores": host}
+            "unit": "GFLOP/s", "cores": thr, "kind": "port",
+            "sample": "first %d rows of: %s" % (rows, sample), "note": err,
+            "host_threads": nproc}
 
 
-# ---- the synthetic workload definition (include/spmv_synth.h) in Python,
-# for the in-bench result check: a few rows of y are recomputed from the
-# counter-based generator itself (not from the oracle library, which only
-# the tests and the cpu_baseline leg may touch).
-_M64 = (1 << 64) - 1
-
-
-def _mix(z):
-    z = (z + 0x9E3779B97F4A7C15) & _M64
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
-    return z ^ (z >> 31)
-
-
-def _hash2(seed, a, b):
-    return _mix((_mix(seed ^ ((a * 0xD1342543DE82EF95) & _M64)) + b) & _M64)
-
-
-def _u01(h):
-    return (h >> 11) * (1.0 / 9007199254740992.0)
-
-
-def synth_row_dot(kind, N, K, W, seed, xseed, g):
-    """(dot, sum|terms|) of global row g with x, banded (0) / random (1)."""
-    if kind == 0:
-        st = min(max(g - K // 2, 0), N - K)
-        cols = [st + j for j in range(K)]
-    elif kind == 1:
-        half = W // 2
-        lo, hi = max(g - half, 0), min(g + (W - half), N)
-        if lo >= hi:
-            lo, hi = 0, N
-        cols = sorted(lo + int(_u01(_hash2(seed ^ 0x636f6c, g, t)) * (hi - lo))
-                      for t in range(K))
-    else:
-        return None
+# ---- result check without the oracle: rows regenerated by the host-side C
+# generator of the product library (include/spmv_synth.h, csr_generate) --
+# the same definition the device generator implements, compiled for the CPU
+def host_row_dot(S, kind, N, K, W, seed, xseed, g):
+    """(dot, sum |terms|) of global row g of the synthetic family with x"""
+    A = S.csr_generate(kind, 1, N, K, W, g, seed)
+    _, JA, AS = S.csr_arrays(A)
     acc = sab = 0.0
-    for j, c in enumerate(cols):
-        v = 2.0 * _u01(_hash2(seed ^ 0x76616c, g, j)) - 1.0
-        p = v * _u01(_hash2(xseed, 0x78, c))
+    for c, v in zip(JA.tolist(), AS.tolist()):
+        p = v * float(S.vec_synth(1, xseed, c)[0])
         acc += p
         sab += abs(p)
+    S.csr_free(A)
     return acc, sab
 
 
@@ -188,6 +244,267 @@ def measured_traffic(workload, kname):
     return best
 
 
+def workload_name(family, fmt, Mloc, Nglob, Mglob, K, window, W, L=1, Mshard=0):
+    wtxt = "column window W=%s" % ("N (anywhere)" if window <= 0 else str(W))
+    if family == "banded":
+        wtxt = "columns s..s+K-1 around the diagonal"
+    elif family == "stencil":
+        wtxt = "grid edge %s" % ("cbrt(N)" if window <= 0 else str(W))
+    s = ("%s %s %dx%d per GPU (%dx%d global), hack 32, %d nnz/row, %s, seed %d"
+         % (family, fmt.upper(), Mloc, Nglob, Mglob, Nglob, K, wtxt,
+            MATRIX_SEED))
+    if L > 1:
+        s += ", %d logical shards of %d rows per GPU" % (L, Mshard)
+    return s
+
+
+def roofline_dict(alg_bytes, kern_ms, kname, nnz, traffic):
+    import numpy as np
+    kavg = float(np.mean(kern_ms))
+    achieved = alg_bytes / (kavg * 1e6)
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": round(traffic["bytes_per_launch"]) if traffic else None,
+        "traffic_source": ("profiles/" + traffic["source"]
+                           + " (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, "
+                           "separate passes)") if traffic else None,
+        "kernel": kname, "algorithmic_bytes_per_launch": alg_bytes,
+        "kernel_ms_avg": round(kavg, 5),
+        "kernel_ms_min": round(float(np.min(kern_ms)), 5),
+        "kernel_gflops": round(2.0 * nnz / (kavg * 1e6), 2),
+    }
+
+
+# ------------------------------------------------------ secondary measurements
+def window_variants(S, torch, x, y, Mloc, Nglob, K, fmt_family):
+    """roofline.variants: the banded members of the headline family (SURVEY
+    8d: "report W = N and W = 2^20"), autotuned like the headline, 20
+    event-timed launches each."""
+    import numpy as np
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for tag, W in (("W=2^20", 1 << 20), ("W=2^17", 1 << 17)):
+        try:
+            dA = S.CsrDevice.generate(FAMILIES["random"], Mloc, Nglob, K, W, 0,
+                                      MATRIX_SEED)
+            dH = dA.to_hll(True)
+            dA.release()
+            best, _ = dH.autotune(x.data_ptr(), y.data_ptr())
+            ms = dH.time(best, x.data_ptr(), y.data_ptr(), 3, 20, 0, 0,
+                         stream=st)
+            kname = "hll_" + S.HLL_KERNEL_LABELS[best]
+            wl = workload_name("random", "hll", Mloc, Nglob, Mloc, K, W, W)
+            tr = measured_traffic(wl, kname)
+            b = dH.algorithmic_bytes
+            out[tag] = {
+                "kernel": kname,
+                "schedule": dH.panels_schedule()
+                if best == S.HLL_KERNEL_PANELS else None,
+                "kernel_ms": round(float(np.mean(ms)), 5),
+                "gflops": round(2.0 * dH.NZ / (float(np.mean(ms)) * 1e6), 1),
+                "achieved": round(b / (float(np.mean(ms)) * 1e6), 1),
+                "frac": round(b / (float(np.mean(ms)) * 1e6) / HBM_PEAK_GBPS, 4),
+                "traffic": round(tr["bytes_per_launch"]) if tr else None,
+                "profile": ("profiles/" + tr["source"]) if tr else None,
+            }
+            dH.release()
+        except OSError as e:  # e.g. out of memory on a smaller card
+            out[tag] = {"error": str(e)}
+    return out
+
+
+def extra_measurements(S, torch, mat, x, y, Mloc, Nglob, K):
+    """compact secondary numbers, [kernel_ms, GFLOP/s, roofline fraction]
+    per tag: the direct HLL kernels on the headline matrix (kernel 1 is the
+    literal north-star form), the banded 10M matrix, and BASELINE config 2
+    (1M banded CSR; 212 MB < Infinity Cache, so every launch follows a
+    512 MiB flush)."""
+    import numpy as np
+    st = torch.cuda.current_stream().cuda_stream
+    dx, dy = x.data_ptr(), y.data_ptr()
+    out = {}
+
+    def row(tag, m, ms):
+        ms = float(np.median(ms))
+        out[tag] = [round(ms, 4), round(2.0 * m.NZ / (ms * 1e6), 1),
+                    round(m.algorithmic_bytes / (ms * 1e6) / HBM_PEAK_GBPS, 4)]
+
+    try:
+        if hasattr(mat, "num_blocks") and mat.col_major:
+            for k in (1, 2):
+                row("W=N hll_%s" % S.HLL_KERNEL_NAMES[k], mat,
+                    mat.time(k, dx, dy, 2, 8, 0, 0, stream=st))
+        dA = S.CsrDevice.generate(FAMILIES["banded"], Mloc, Nglob, K, 0, 0,
+                                  MATRIX_SEED)
+        dH = dA.to_hll(True)
+        row("banded10M hll_threads_col_major", dH,
+            dH.time(1, dx, dy, 2, 10, 0, 0, stream=st))
+        row("banded10M csr_stream", dA,
+            dA.time(4, dx, dy, 2, 10, 0, 0, stream=st))
+        dH.release()
+        dA.release()
+        dB = S.CsrDevice.generate(FAMILIES["banded"], 1_000_000, 1_000_000, 16,
+                                  0, 0, MATRIX_SEED)
+        for k in (1, 2, 4):
+            row("config2 csr_%s flushed" % S.CSR_KERNEL_NAMES[k], dB,
+                dB.time(k, dx, dy, 2, 20, 512 << 20, 0, stream=st))
+        best, _ = dB.autotune(dx, dy, True)
+        row("config2 autotuned csr_%s flushed" % S.CSR_KERNEL_LABELS[best],
+            dB, dB.time(best, dx, dy, 2, 20, 512 << 20, 0, stream=st))
+        dB.release()
+    except OSError as e:
+        out["error"] = str(e)
+    return out
+
+
+# ------------------------------------------------------------------ config 4/2
+def single_matrix_bench(args, S, torch, dev):
+    """--config 4 (.mtx through the loader, CSR) and --config 2 (1M banded
+    CSR, flushed): one GPU, one matrix, autotuned CSR kernel."""
+    import numpy as np
+    st = torch.cuda.current_stream().cuda_stream
+    info = {}
+    t_setup = time.time()
+    if args.config == 4:
+        path = args.mtx
+        real = os.path.join(os.environ.get("SPMV_MTX_DIR", ""), "nlpkkt160.mtx")
+        if not path and os.environ.get("SPMV_MTX_DIR") and os.path.exists(real):
+            path = real
+        if not path:
+            gen = os.path.join(ROOT, "spmv_scpa_amd", "bin", "gen_kkt_mtx")
+            path = os.path.join(tempfile.gettempdir(),
+                                "spmv_kkt%d.mtx" % args.kkt_n)
+            if not os.path.exists(path):
+                t0 = time.time()
+                subprocess.run([gen, str(args.kkt_n), path + ".part"],
+                               check=True, capture_output=True)
+                os.replace(path + ".part", path)
+                info["mtx_write_s"] = round(time.time() - t0, 2)
+            info["source"] = ("generated nlpkkt160-shaped KKT file "
+                              "(tools/gen_kkt_mtx.c, %d^3 grid)" % args.kkt_n)
+        else:
+            info["source"] = path
+        had_bin = os.path.exists(path + ".bin")
+        t0 = time.time()
+        A = S.io_load_csr_cached(path)
+        info["load_s"] = round(time.time() - t0, 2)
+        info["loaded_from"] = ".bin sidecar" if had_bin else \
+            ".mtx text (sidecar written)"
+        if not had_bin:
+            S.csr_free(A)
+            t0 = time.time()
+            A = S.io_load_csr_cached(path)
+            info["bin_load_s"] = round(time.time() - t0, 2)
+        M, N, NZ = A.contents.M, A.contents.N, A.contents.NZ
+        name = A.contents.name.decode()
+        xh = S.vec_random(N)  # the reference's x for .mtx runs
+        dA = S.CsrDevice.upload(A)
+        x = torch.from_numpy(xh).to(dev)
+        flush = 0
+        workload = ("%s.mtx %dx%d, %d nnz after symmetric expansion, CSR "
+                    "(BASELINE config 4: nlpkkt160; %s)"
+                    % (name, M, N, NZ, info["source"]))
+    else:
+        M = N = 1_000_000
+        A = None
+        dA = S.CsrDevice.generate(FAMILIES["banded"], M, N, 16, 0, 0,
+                                  MATRIX_SEED)
+        NZ = dA.NZ
+        x = torch.empty(N, dtype=torch.float64, device=dev)
+        S.dev_fill_synth(x.data_ptr(), N, X_SEED, 0, st)
+        flush = 512 << 20  # 212 MB working set < 256 MiB Infinity Cache
+        workload = ("banded CSR 1000000x1000000, 16 nnz/row (BASELINE "
+                    "config 2), 512 MiB flush between launches")
+    y = torch.zeros(M, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    if args.kernel >= 0:
+        kernel, tuned = args.kernel, None
+    else:
+        kernel, tuned = dA.autotune(x.data_ptr(), y.data_ptr())
+    kname = "csr_" + S.CSR_KERNEL_LABELS[kernel]
+    t_setup = time.time() - t_setup
+
+    # result check: rows of y against the rows of the HOST matrix
+    dA.launch(kernel, x.data_ptr(), y.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(1234)
+    rows = np.concatenate([[0, M - 1], rng.integers(0, M, 256)])
+    got = y[torch.as_tensor(rows, device=dev)].cpu().numpy()
+    if A is not None:
+        IRP, JA, AS = S.csr_arrays(A)
+        xh_ = x.cpu().numpy()
+        for g, r in zip(got, rows):
+            c, v = JA[IRP[r]:IRP[r + 1]], AS[IRP[r]:IRP[r + 1]]
+            t = v * xh_[c]
+            if abs(g - t.sum()) > 1e-6 * max(abs(t.sum()), 1e-3 * np.abs(t).sum()):
+                raise SystemExit("parity check failed on row %d" % r)
+    else:
+        for g, r in zip(got, rows):
+            want, scale = host_row_dot(S, FAMILIES["banded"], N, 16, 0,
+                                       MATRIX_SEED, X_SEED, int(r))
+            if abs(g - want) > 1e-6 * max(abs(want), 1e-3 * scale):
+                raise SystemExit("parity check failed on row %d" % r)
+
+    # warm-up + EXACTLY K timed steps (flushed between steps for config 2:
+    # the flush is outside the per-step events, wall time is not the metric)
+    for _ in range(args.warmup):
+        dA.launch(kernel, x.data_ptr(), y.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    if flush:
+        kern_ms = dA.time(kernel, x.data_ptr(), y.data_ptr(), 0, args.steps,
+                          flush, args.waves, stream=st)
+        ms_per_step = float(np.mean(kern_ms))
+    else:
+        ev = [(torch.cuda.Event(enable_timing=True),
+               torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record()
+            dA.launch(kernel, x.data_ptr(), y.data_ptr(),
+                      waves_per_block=args.waves, stream=st)
+            b.record()
+        torch.cuda.synchronize()
+        ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
+        kern_ms = [a.elapsed_time(b) for a, b in ev]
+    alg = dA.algorithmic_bytes
+    out = {
+        "metric": METRIC, "value": round(2.0 * NZ / (ms_per_step * 1e6), 2),
+        "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic" if args.config == 2 or "generated" in
+        info.get("source", "") else "file",
+        "config": dict({"workload": workload, "kernel": kname,
+                        "kernel_choice": "autotuned (spmv_csr_autotune)"
+                        if tuned is not None else "fixed by --kernel",
+                        "blocked_schedule": dA.panels_schedule()
+                        if kernel == S.CSR_KERNEL_PANELS else None,
+                        "rows": M, "nnz": NZ}, **info),
+        "roofline": roofline_dict(alg, kern_ms, kname, NZ,
+                                  measured_traffic(workload, kname)),
+        "setup_s": round(t_setup, 2), "rows_checked": len(rows),
+    }
+    if not args.no_extras:
+        ex = {}
+        for k in (1, 2, 4):
+            ms = float(np.median(dA.time(k, x.data_ptr(), y.data_ptr(), 2, 10,
+                                         flush, args.waves, stream=st)))
+            ex["csr_" + S.CSR_KERNEL_NAMES[k]] = [
+                round(ms, 4), round(2.0 * NZ / (ms * 1e6), 1),
+                round(alg / (ms * 1e6) / HBM_PEAK_GBPS, 4)]
+        out["extras"] = ex
+    if not args.no_cpu_baseline and args.config == 2:
+        out["cpu_baseline"] = cpu_baseline(
+            S, FAMILIES["banded"], M, N, 16, 0,
+            args.cpu_csv_dir or os.path.join(ROOT, "gpurun_out", "cpu_baseline"),
+            "banded1M", reps=3)
+    print(json.dumps(out))
+
+
+# ------------------------------------------------------------------------ main
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -208,6 +525,10 @@ def main():
     torch.cuda.set_device(local_rank)
     S.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.config != 3:
+        if world > 1:
+            raise SystemExit("--config %d is a single-GPU line" % args.config)
+        return single_matrix_bench(args, S, torch, dev)
     use_dist = world > 1 or args.force_exchange
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,9 +547,7 @@ def main():
     Mglob = Mloc * world
     Nglob = Mglob
     W = args.window if args.window > 0 else 2 * Nglob  # >= 2N: anywhere
-    kind = {"banded": S.SYNTH_BANDED, "random": S.SYNTH_RANDOM,
-            "ragged": S.SYNTH_RAGGED, "kkt": S.SYNTH_KKT,
-            "stencil": S.SYNTH_STENCIL}[args.family]
+    kind = FAMILIES[args.family]
     row0 = rank * Mloc
 
     # ---- build the shard(s) in HBM (device-side generator + converter) ----
@@ -240,12 +559,12 @@ def main():
     torch.cuda.synchronize()
     tuned = None
 
-    def build_shards(count, rows):
-        """`count` logical shards of `rows` rows covering this rank's range"""
+    def build_shards(count, rows, first_row=row0, ncols=Nglob, w=W):
+        """`count` logical shards of `rows` rows starting at `first_row`"""
         out, nnz, stored = [], 0, 0
         for j in range(count):
-            dA = S.CsrDevice.generate(kind, rows, Nglob, K, W, row0 + j * rows,
-                                      MATRIX_SEED)
+            dA = S.CsrDevice.generate(kind, rows, ncols, K, w,
+                                      first_row + j * rows, MATRIX_SEED)
             nnz += dA.NZ
             if args.format == "hll":
                 col_major = True if args.kernel in (-1, 4) else \
@@ -270,63 +589,51 @@ def main():
     else:
         # kernel chosen by measurement (spmv_*_autotune) on the first shard:
         # the coalesced kernels and, if they run far below the stream rate,
-        # the 2-D blocked path.  Every rank must take the same decision.
+        # the 2-D blocked path.  Every rank must take the same decision:
+        # rank 0's pick -- kernel id and, for the blocked path, its schedule
+        # and tile height -- is broadcast (they decide how the exchange is
+        # arranged below: every rank must issue the same collectives).
         kernel, tuned = mat.autotune(x.data_ptr(), y.data_ptr() + 8 * row0)
         if use_dist:
-            # rank 0's pick for all: kernel id and, for the blocked path, its
-            # schedule and tile height (they decide how the exchange is
-            # arranged below: every rank must issue the same collectives)
-            sched0 = {"steps": 0, "sweep": 1, "chain": 2}.get(
-                mat.panels_schedule(), -1)
-            kk = torch.tensor([kernel, sched0, mat.panels_tile_rows() or 0],
-                              device=dev)
-            dist.broadcast(kk, 0)
-            kernel, sched0, tile0 = (int(v) for v in kk.tolist())
-            if labels[kernel] == "tile_panels":
-                want = ("steps", "sweep", "chain")[sched0]
-                if (mat.panels_schedule() != want
-                        or (want != "sweep"
-                            and mat.panels_tile_rows() != tile0)):
-                    mat.build_panels(0, want, tile0)
+            mine = D.Pick(kernel, mat.panels_schedule(),
+                          mat.panels_tile_rows() or 0)
+            pick = D.agree_on_pick(dist, mine, dev)
+            kernel = pick.kernel
+            if labels[kernel] == "tile_panels" and not pick.same_build(mine):
+                mat.build_panels(0, pick.schedule, pick.tile_rows)
+    blocked = labels[kernel] == "tile_panels"
+    if blocked and mat.panels_info() is None:
+        mat.build_panels(0)
+    arrangement = None
+    sweep = blocked and mat.panels_schedule() == "sweep"
     nsplit = 2 if args.force_exchange and world == 1 else 4
-    if (labels[kernel] == "tile_panels" and use_dist and L == 1
-            and Mshard % (nsplit * D.HACK) == 0
-            and (mat.panels_schedule() != "sweep" or args.force_exchange)):
+    if (blocked and not sweep and use_dist and L == 1
+            and Mshard % (nsplit * D.HACK) == 0):
         # the blocked path runs whole matrices only: hold the rank's rows as
         # `nsplit` logical shards (4, like the row chunks of the direct
         # kernels) so that the all-gather of one shard runs under the kernel
         # of the next -- at 8 GPUs the exchange (560 MB in per GPU) is longer
-        # than the kernel of a matrix with locality.  Not for the sweep
-        # schedule: its launch wants every CU (phase counters), RCCL's
-        # kernels take some, so the overlap would only delay workgroups --
-        # there the exchange follows the kernel.
-        model = mat if mat.panels_info() is not None else None
-        for m in mats:
-            if m is not model:
-                m.release()
+        # than the kernel of a matrix with locality.
+        model = mat
+        for m in mats[1:]:
+            m.release()
         L, Mshard = nsplit, Mshard // nsplit
         mats, nnz_local, slots = build_shards(L, Mshard)
+        for m in mats:  # the tuned schedule and tile height
+            m.build_panels_like(model)
+        model.release()
         mat = mats[0]
-        if model is not None:  # the tuned schedule and tile height
-            for m in mats:
-                m.build_panels_like(model)
-            model.release()
-    if labels[kernel] == "tile_panels":
-        if mat.panels_info() is None:
-            mat.build_panels(0)
+        arrangement = "chain: %d logical shards, all-gather of shard c " \
+                      "under the kernel of c+1" % L
+    if blocked:
         for m in mats[1:]:  # the tuned shard's schedule and tile height
             if m.panels_info() is None:
                 m.build_panels_like(mat)
     kname = prefix + labels[kernel]
-    pinfo = mat.panels_info() if labels[kernel] == "tile_panels" else None
-    launches_per_step = (pinfo["steps"] if pinfo else 1) * L
-    # per step and GPU; one launch per logical shard
-    alg_bytes = sum(m.algorithmic_bytes for m in mats)
     torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
 
     chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
-    if labels[kernel] == "tile_panels" or L > 1:
+    if blocked or L > 1:
         chunks = 1  # the blocked path runs whole shards only; with logical
         #             shards the shard is the unit of overlap
     halo = 0
@@ -341,11 +648,77 @@ def main():
                 raise SystemExit("--exchange halo needs --halo-rows (or a "
                                  "column window)")
         halo = -(-halo // D.HACK) * D.HACK
-    sharded = D.ShardedSpmv(mats if L > 1 else mat, kernel, rank, world, Mloc,
-                            x, y,
-                            waves_per_block=args.waves, chunks=chunks,
-                            force_exchange=args.force_exchange,
-                            mode="halo" if halo else None, halo_rows=halo)
+
+    def make_sharded(ms, rows_total=Mloc, xx=x, yy=y):
+        return D.ShardedSpmv(ms if len(ms) > 1 else ms[0], kernel, rank, world,
+                             rows_total, xx, yy, waves_per_block=args.waves,
+                             chunks=chunks,
+                             force_exchange=args.force_exchange,
+                             mode="halo" if halo else None, halo_rows=halo)
+
+    sharded = make_sharded(mats)
+
+    def time_steps(sh, n):
+        """barrier-bracketed wall time of n steps, max over ranks, in ms/step"""
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            sh.step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                         device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3 / n
+
+    if (sweep and use_dist and L == 1 and not halo
+            and Mshard % (2 * D.HACK) == 0):
+        # The sweep launch is persistent and wants its whole grid resident
+        # (phase counters), so by default the exchange FOLLOWS the kernel.
+        # Alternative: two logical shards, each swept by a grid that leaves
+        # --reserve-cus compute units free, the all-gather of the first half
+        # running beside the sweep of the second.  Whether RCCL's kernels and
+        # the persistent grid share the chip well is a property of the node:
+        # both arrangements are timed here (5 steps each, max over ranks) and
+        # the faster one is kept -- the same "choose by measurement" rule as
+        # the kernel selector, and every rank sees the same reduced times.
+        try:
+            alt, nnz_alt, slots_alt = build_shards(2, Mshard // 2)
+            for m in alt:
+                m.build_panels(0, "sweep", reserve_cus=args.reserve_cus)
+            sh_alt = make_sharded(alt)
+            for s_ in (sharded, sh_alt):
+                s_.step()
+            t_serial = time_steps(sharded, 5)
+            t_split = time_steps(sh_alt, 5)
+            arrangement = ("sweep: exchange after the kernel %.3f ms/step vs "
+                           "2 logical shards on %d fewer CUs with overlapped "
+                           "all-gather %.3f ms/step"
+                           % (t_serial, args.reserve_cus, t_split))
+            if t_split < t_serial:
+                for m in mats:
+                    m.release()
+                mats, sharded, L, Mshard = alt, sh_alt, 2, Mshard // 2
+                nnz_local, slots, mat = nnz_alt, slots_alt, alt[0]
+                arrangement += " -> overlapped"
+            else:
+                for m in alt:
+                    m.release()
+                arrangement += " -> exchange after the kernel"
+        except OSError as e:
+            arrangement = "sweep: overlapped arrangement not built (%s)" % e
+    pinfo = mat.panels_info() if blocked else None
+    launches_per_step = (pinfo["steps"] if pinfo else 1) * L
+    # per step and GPU (SURVEY 8d); one launch per logical shard
+    alg_bytes = sum(m.algorithmic_bytes for m in mats)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
 
     # ---- result check: rows of y recomputed from the workload definition ----
     sharded.step()
@@ -368,15 +741,14 @@ def main():
     got = y[row0 + torch.as_tensor(rows, device=dev)].cpu().numpy()
     checked = 0
     for g, r in zip(got, rows):
-        ref = synth_row_dot(kind, Nglob, K, W, MATRIX_SEED, X_SEED,
-                            row0 + int(r))
-        if ref is None:
-            break
-        want, scale = ref
+        want, scale = host_row_dot(S, kind, Nglob, K, W, MATRIX_SEED, X_SEED,
+                                   row0 + int(r))
         checked += 1
         if abs(g - want) > 1e-6 * max(abs(want), 1e-3 * scale):
             raise SystemExit("parity check failed on row %d: %r vs %r"
                              % (row0 + r, g, want))
+    if checked == 0:
+        raise SystemExit("no row of y was checked")
 
     # ---- warm-up, then EXACTLY K timed steps ----
     for _ in range(args.warmup):
@@ -413,37 +785,42 @@ def main():
         torch.cuda.synchronize()
         exch_ms = (time.perf_counter() - t1) * 1e3 / 10
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(nnz_local)], dtype=torch.float64,
+                     device=dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        tm = t[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ts = t[1:].clone()
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)  # ragged / kkt: nnz differs
+        elapsed, nnz_global = float(tm.item()), int(ts.item())
+    else:
+        nnz_global = nnz_local
     ms_per_step = elapsed * 1e3 / args.steps
-    nnz_global = nnz_local * world
     value = 2.0 * nnz_global / (ms_per_step * 1e6)
-    kavg = float(np.mean(kern_ms))
-    achieved = alg_bytes / (kavg * 1e6)  # GB/s, this rank's kernel
+
+    # ---- N > 1: the fixed-problem reading of config 5 (80M x 80M, 8 logical
+    # shards of 10M rows, 8/N per GPU), so that a scaling run can be read
+    # against the ">= 6x y-throughput at 8 GPUs" target: rows/s of the SAME
+    # problem at every N; the 1-GPU denominator is a committed measurement.
+    strong = None
+    if (world > 1 and not args.strong and not args.no_strong_leg
+            and 8 % world == 0 and args.family == "random"
+            and args.window <= 0):
+        strong = strong_leg(args, S, D, torch, dist, dev, rank, world, kernel,
+                            mat, blocked, build_shards, make_sharded,
+                            time_steps, Mglob, Mshard * L)
 
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
         return
 
-    wtxt = ("column window W=%s"
-            % ("N (anywhere)" if args.window <= 0 else str(W)))
-    if args.family == "banded":
-        wtxt = "columns s..s+K-1 around the diagonal"
-    elif args.family == "stencil":
-        wtxt = "grid edge %s" % ("cbrt(N)" if args.window <= 0 else str(W))
-    workload = ("%s %s %dx%d per GPU (%dx%d global), hack 32, %d nnz/row, "
-                "%s, seed %d"
-                % (args.family, args.format.upper(), Mloc, Nglob, Mglob, Nglob,
-                   K, wtxt, MATRIX_SEED))
-    if L > 1:
-        workload += ", %d logical shards of %d rows per GPU" % (L, Mshard)
+    workload = workload_name(args.family, args.format, Mloc, Nglob, Mglob, K,
+                             args.window, W, L, Mshard)
     traffic = measured_traffic(workload, kname) if world == 1 else None
+    roof = roofline_dict(alg_bytes, kern_ms, kname, nnz_local, traffic)
     out = {
-        "metric": "fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), "
-                  "1/2/4/8 MI355X",
+        "metric": METRIC,
         "value": round(value, 2),
         "unit": "GFLOP/s",
         "n_gpus": world,
@@ -460,8 +837,7 @@ def main():
             "kernel": kname,
             "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
             if tuned is not None else "fixed by --kernel",
-            "blocked_schedule": mat.panels_schedule()
-            if labels[kernel] == "tile_panels" else None,
+            "blocked_schedule": mat.panels_schedule() if blocked else None,
             "kernel_launches_per_step": launches_per_step,
             "rows_per_gpu": Mloc, "logical_shards_per_gpu": L,
             "nnz_per_row": K, "nnz_global": nnz_global,
@@ -469,37 +845,77 @@ def main():
             "partition": "contiguous row ranges, x replicated, in-place "
                          "all-gather(y) over RCCL" if world > 1 else "single GPU",
             "chunks": chunks, "exchange": sharded.mode,
+            "exchange_arrangement": arrangement,
             "exchange_ms_alone": round(exch_ms, 5) if exch_ms else None,
             "halo_rows": halo or None,
+            "rows_per_s": round(Mglob / (ms_per_step * 1e-3), 1),
+            "strong": strong,
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": round(traffic["bytes_per_launch"]) if traffic else None,
-            "traffic_source": ("profiles/" + traffic["source"]
-                               + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                               "separate passes, FETCH_SIZE x2)") if traffic
-            else None,
-            "kernel": kname,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms_avg": round(kavg, 5),
-            "kernel_ms_min": round(float(np.min(kern_ms)), 5),
-            "kernel_gflops": round(2.0 * nnz_local / (kavg * 1e6), 2),
-        },
+        "roofline": roof,
         "setup_s": round(t_setup, 2),
         "rows_checked": checked,
     }
+    single = world == 1 and L == 1 and not args.force_exchange
+    if (single and not args.no_extras and args.family == "random"
+            and args.window <= 0 and args.format == "hll"):
+        roof["variants"] = window_variants(S, torch, x, y, Mloc, Nglob, K,
+                                           args.family)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.family, K, W)
-    if world == 1 and L == 1 and not args.no_extras:
-        out["extras"] = D.extra_measurements(S, torch, mat, args, x, y, Mloc,
-                                             Nglob, K, kind)
+        out["cpu_baseline"] = cpu_baseline(
+            S, kind, Mloc, Nglob, K, W,
+            args.cpu_csv_dir or os.path.join(ROOT, "gpurun_out", "cpu_baseline"),
+            "%s%dM" % (args.family, Mloc // 1_000_000))
+    if single and not args.no_extras:
+        out["extras"] = extra_measurements(S, torch, mat, x, y, Mloc, Nglob, K)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+# committed 1-GPU measurement of the fixed 80M x 80M problem (8 logical
+# shards on one MI355X, `bench.py --strong`, gpurun_out/call73.log of round 1;
+# DESIGN.md section 7): the denominator of the >= 6x reading
+STRONG_ONE_GPU_MS = 26.7
+
+
+def strong_leg(args, S, D, torch, dist, dev, rank, world, kernel, model,
+               blocked, build_shards, make_sharded, time_steps, Mglob_weak,
+               _unused):
+    """The fixed 80M x 80M problem at this N: 8/N logical shards of 10M rows
+    per GPU with global columns, built with rank 0's pick.  At N = 8 this IS
+    the weak-scaling workload (one shard per GPU), so nothing is rebuilt.
+    Returns a small dict; any failure is reported, never fatal."""
+    rows, total = args.rows_per_gpu, 8 * args.rows_per_gpu
+    try:
+        if world == 8 and Mglob_weak == total:
+            return {"problem": "80M x 80M, 8 shards of 10M rows: identical to "
+                               "this line's workload at N = 8",
+                    "one_gpu_ms_per_step": STRONG_ONE_GPU_MS,
+                    "note": "speedup vs 1 GPU = one_gpu_ms_per_step / "
+                            "ms_per_step of this line"}
+        per = 8 // world
+        xs = torch.empty(total, dtype=torch.float64, device=dev)
+        ys = torch.zeros(total, dtype=torch.float64, device=dev)
+        S.dev_fill_synth(xs.data_ptr(), total, X_SEED, 0,
+                         torch.cuda.current_stream().cuda_stream)
+        ms_, _, _ = build_shards(per, rows, rank * per * rows, total, 2 * total)
+        if blocked:
+            for m in ms_:
+                m.build_panels_like(model)
+        sh = make_sharded(ms_, per * rows, xs, ys)
+        sh.step()
+        ms = time_steps(sh, 5)
+        for m in ms_:
+            m.release()
+        del xs, ys
+        return {"problem": "80M x 80M fixed, %d logical shards of 10M rows "
+                           "per GPU" % per,
+                "ms_per_step": round(ms, 4),
+                "rows_per_s": round(total / (ms * 1e-3), 1),
+                "one_gpu_ms_per_step": STRONG_ONE_GPU_MS,
+                "speedup_vs_1gpu": round(STRONG_ONE_GPU_MS / ms, 3)}
+    except Exception as e:  # noqa: BLE001 - secondary figure
+        return {"error": repr(e)}
 
 
 if __name__ == "__main__":

@@ -257,8 +257,13 @@ static int cmd_time(int argc, char **a) {
     vec x = vec_create((size_t)s.N);
     for (int i = 0; i < s.N; ++i)
         x.data[i] = synth_x(xseed, i);
-    sparse_hll *H = csr_to_hll(A, false);
-    if (IS_ERR(H))
+    /* REF_TIME_HLL=0 skips the HLL legs: the reference's csr_to_hll is a
+     * serial loop with two mallocs per hack block (hll.c:19-95), ~15 s for
+     * the 10M x 32 matrix -- bench.py bounds its CPU leg with it */
+    const char *eh = getenv("REF_TIME_HLL");
+    const int with_hll = !(eh && eh[0] == '0');
+    sparse_hll *H = with_hll ? csr_to_hll(A, false) : NULL;
+    if (with_hll && IS_ERR(H))
         return 2;
     double t_prep = wall_ms() - t0;
     double d[64];
@@ -287,14 +292,16 @@ static int cmd_time(int argc, char **a) {
         vec_put(&b.data);
     }
     EMIT("CSR", "serial", 1);
-    for (int r = 0; r < reps; ++r) {
-        bench b;
-        if (bench_hll_serial(H, x.data, &b))
-            return 2;
-        d[r] = b.duration_ms;
-        vec_put(&b.data);
+    if (with_hll) {
+        for (int r = 0; r < reps; ++r) {
+            bench b;
+            if (bench_hll_serial(H, x.data, &b))
+                return 2;
+            d[r] = b.duration_ms;
+            vec_put(&b.data);
+        }
+        EMIT("HLL", "serial", 1);
     }
-    EMIT("HLL", "serial", 1);
 
     for (int k = 8; k < argc; ++k) {
         int thr = atoi(a[k]);
@@ -319,14 +326,15 @@ static int cmd_time(int argc, char **a) {
             vec_put(&b.bench.data);
         }
         EMIT("CSR", "omp_nnz", used);
-        for (int r = 0; r < reps; ++r) {
+        for (int r = 0; with_hll && r < reps; ++r) {
             bench_omp b = {.num_threads = thr};
             if (bench_hll_omp(H, x.data, &b))
                 return 2;
             d[r] = b.bench.duration_ms;
             vec_put(&b.bench.data);
         }
-        EMIT("HLL", "omp_guided", thr);
+        if (with_hll)
+            EMIT("HLL", "omp_guided", thr);
     }
     printf("]}\n");
     return 0;

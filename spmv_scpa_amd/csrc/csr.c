@@ -13,6 +13,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -118,6 +120,91 @@ static int scan_double(const char **pp, const char *end, double *out) {
     *out = v;
     *pp = stop;
     return 1;
+}
+
+/*
+ * Correctly rounded conversion of a plain decimal token "[+-]ddd[.ddd]"
+ * without strtod: with at most 15 significant digits the digits form an
+ * integer below 2^53 and 10^k (k <= 22 fraction digits) is exact in binary64,
+ * so ONE IEEE division rounds once -- the value strtod returns (Clinger's
+ * fast path).  Returns 0 (caller uses strtod) for anything else: exponents,
+ * hex, inf/nan, longer mantissas.
+ */
+static int fast_decimal(const char *p, const char *e, double *out) {
+    static const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,
+                                   1e8,  1e9,  1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                   1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    int neg = 0, digits = 0, frac = 0, seen_dot = 0, any = 0;
+    unsigned long long m = 0;
+    if (p < e && (*p == '-' || *p == '+'))
+        neg = (*p++ == '-');
+    for (; p < e; ++p) {
+        const char c = *p;
+        if (c >= '0' && c <= '9') {
+            any = 1;
+            if (m || c != '0')
+                ++digits; /* significant digits: leading zeros are free */
+            if (digits > 15)
+                return 0;
+            m = m * 10 + (unsigned)(c - '0');
+            frac += seen_dot;
+        } else if (c == '.' && !seen_dot) {
+            seen_dot = 1;
+        } else {
+            return 0;
+        }
+    }
+    if (!any || frac > 22)
+        return 0;
+    const double v = (double)m / p10[frac];
+    *out = neg ? -v : v;
+    return 1;
+}
+
+/*
+ * The file image.  Regular files are mapped (no copy; the pages are faulted
+ * in by the threads that tokenise them); the parsers need a NUL behind the
+ * text, which the zero-filled tail of the last page provides unless the size
+ * is an exact multiple of the page size -- then, and for pipes, the file is
+ * read into a buffer.
+ */
+struct file_image {
+    char *text;
+    size_t len;
+    size_t mapped; /* bytes to munmap; 0: `text` is malloc'ed */
+};
+
+static void image_release(struct file_image *im) {
+    if (im->mapped)
+        munmap(im->text, im->mapped);
+    else
+        free(im->text);
+    im->text = NULL;
+}
+
+static int read_whole_file(const char *path, char **buf, size_t *len);
+
+static int image_open(const char *path, struct file_image *im) {
+    memset(im, 0, sizeof *im);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0)
+        return -errno;
+    struct stat st;
+    const long page = sysconf(_SC_PAGESIZE);
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 &&
+        page > 0 && (st.st_size % page) != 0) {
+        void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            close(fd);
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            im->text = m;
+            im->len = (size_t)st.st_size;
+            im->mapped = (size_t)st.st_size;
+            return 0;
+        }
+    }
+    close(fd);
+    return read_whole_file(path, &im->text, &im->len);
 }
 
 static int read_whole_file(const char *path, char **buf, size_t *len) {
@@ -237,11 +324,16 @@ static int parse_entries_parallel(const char *text, size_t off, size_t len,
                     ej[ent] = v;
             } else {
                 char *stop;
-                double v = strtod(p, &stop);
-                if (stop != text + e)
-                    dirty = 1;
-                else
+                double v;
+                if (fast_decimal(p, text + e, &v)) {
                     ev[ent] = v;
+                } else {
+                    v = strtod(p, &stop);
+                    if (stop != text + e)
+                        dirty = 1;
+                    else
+                        ev[ent] = v;
+                }
             }
             ++g;
             k = e;
@@ -254,11 +346,12 @@ static int parse_entries_parallel(const char *text, size_t off, size_t len,
 }
 
 sparse_csr *io_load_csr(const char *path) {
-    char *text = NULL;
-    size_t len = 0;
-    int rc = read_whole_file(path, &text, &len);
+    struct file_image im;
+    int rc = image_open(path, &im);
     if (rc)
         return ERR_PTR(rc);
+    const char *text = im.text;
+    const size_t len = im.len;
 
     int *ei = NULL, *ej = NULL, *fill = NULL;
     double *ev = NULL;
@@ -340,22 +433,57 @@ sparse_csr *io_load_csr(const char *path) {
         A->IRP[r + 1] = A->IRP[r] + fill[r];
     memset(fill, 0, ((size_t)M + 1) * sizeof *fill);
 
-    /* stable scatter: an entry, then its mirror image (csr.c:138-145) */
-    for (int e = 0; e < nz0; ++e) {
-        int i = ei[e], j = ej[e];
-        double v = pattern ? 1.0 : ev[e];
-        size_t at = (size_t)A->IRP[i] + (size_t)fill[i]++;
-        A->JA[at] = j;
-        A->AS[at] = v;
-        if (mirror && i != j) {
-            size_t bt = (size_t)A->IRP[j] + (size_t)fill[j]++;
-            A->JA[bt] = i;
-            A->AS[bt] = v;
+    /* stable scatter: an entry, then its mirror image (csr.c:138-145).
+     * Every thread walks the whole entry list in file order and places what
+     * lands in ITS row range (ranges of about equal nnz): the order inside a
+     * row is the sequential one, rows have one writer, no atomics -- and the
+     * fresh pages of JA/AS are first touched by the thread that fills them. */
+    {
+        int T = nz0 >= 100000 ? omp_get_max_threads() : 1;
+        if (T > 64)
+            T = 64;
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+            int r0, r1;
+            if (nt == 1) {
+                r0 = 0;
+                r1 = M;
+            } else { /* first row whose offset reaches the thread's share */
+                int cut[2];
+                for (int s = 0; s < 2; ++s) {
+                    const long long want = stored * (long long)(t + s) / nt;
+                    int lo = 0, hi = M;
+                    while (lo < hi) {
+                        int mid = lo + (hi - lo) / 2;
+                        if (A->IRP[mid] < want)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    cut[s] = (t + s == nt) ? M : lo;
+                }
+                r0 = cut[0];
+                r1 = cut[1];
+            }
+            for (int e = 0; e < nz0; ++e) {
+                const int i = ei[e], j = ej[e];
+                if (i >= r0 && i < r1) {
+                    const size_t at = (size_t)A->IRP[i] + (size_t)fill[i]++;
+                    A->JA[at] = j;
+                    A->AS[at] = pattern ? 1.0 : ev[e];
+                }
+                if (mirror && i != j && j >= r0 && j < r1) {
+                    const size_t bt = (size_t)A->IRP[j] + (size_t)fill[j]++;
+                    A->JA[bt] = i;
+                    A->AS[bt] = pattern ? 1.0 : ev[e];
+                }
+            }
         }
     }
 
 done:
-    free(text);
+    image_release(&im);
     free(ei);
     free(ej);
     free(ev);
@@ -482,12 +610,48 @@ static sparse_csr *csr_read_bin(const char *path, const struct stat *src) {
         A = NULL;
         goto out;
     }
-    if (fread(A->IRP, sizeof(int), (size_t)h.M + 1, f) != (size_t)h.M + 1 ||
-        fread(A->JA, sizeof(int), (size_t)h.NZ, f) != (size_t)h.NZ ||
-        fread(A->AS, sizeof(double), (size_t)h.NZ, f) != (size_t)h.NZ)
-        rc = -EIO;
-    else if (!csr_arrays_valid(A))
-        rc = -EILSEQ; /* not a CSR matrix: corrupt or foreign file */
+    {
+        /* the three arrays lie back to back behind the header; pread them in
+         * 32 MiB pieces from all threads (first touch + copy in parallel:
+         * 2.8 GB of nlpkkt160-sized arrays in 0.6 s instead of 3 s) */
+        const int fd = fileno(f);
+        const uint64_t nI = ((uint64_t)h.M + 1) * sizeof(int);
+        const uint64_t nJ = (uint64_t)h.NZ * sizeof(int);
+        const uint64_t nV = (uint64_t)h.NZ * sizeof(double);
+        const uint64_t total = nI + nJ + nV, piece = (uint64_t)32 << 20;
+        const long long pieces = (long long)((total + piece - 1) / piece);
+        int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+        for (long long k = 0; k < pieces; ++k) {
+            uint64_t a = (uint64_t)k * piece;
+            const uint64_t z = a + piece < total ? a + piece : total;
+            while (a < z && !bad) { /* a piece may straddle two arrays */
+                char *dst;
+                uint64_t lim;
+                if (a < nI) {
+                    dst = (char *)A->IRP + a;
+                    lim = nI;
+                } else if (a < nI + nJ) {
+                    dst = (char *)A->JA + (a - nI);
+                    lim = nI + nJ;
+                } else {
+                    dst = (char *)A->AS + (a - nI - nJ);
+                    lim = total;
+                }
+                const uint64_t want = (z < lim ? z : lim) - a;
+                const ssize_t got = pread(fd, dst, (size_t)want,
+                                          (off_t)(sizeof h + a));
+                if (got <= 0)
+                    bad = 1;
+                else
+                    a += (uint64_t)got;
+            }
+        }
+        if (bad)
+            rc = -EIO;
+        else if (!csr_arrays_valid(A))
+            rc = -EILSEQ; /* not a CSR matrix: corrupt or foreign file */
+    }
 out:
     fclose(f);
     if (rc) {

@@ -57,6 +57,44 @@ def chunk_bounds(rows, chunks, align=HACK):
     return [v for i, v in enumerate(b) if i == 0 or v > b[i - 1]]
 
 
+_SCHED_CODE = {None: -1, "steps": 0, "sweep": 1, "chain": 2}
+_SCHED_NAME = {v: k for k, v in _SCHED_CODE.items()}
+
+
+class Pick:
+    """What a rank's kernel selector decided: kernel id and, for the 2-D
+    blocked path, the schedule ("steps" / "sweep" / "chain") and tile height
+    of the copy it built.  The pick decides how the exchange is arranged
+    (chunked launches, logical shards, overlap), so all ranks of a job must
+    run RANK 0's pick or they would issue different collectives."""
+
+    def __init__(self, kernel, schedule=None, tile_rows=0):
+        self.kernel = int(kernel)
+        self.schedule = schedule
+        self.tile_rows = int(tile_rows or 0)
+
+    def same_build(self, other):
+        """would `other`'s blocked copy do for this pick?  (the sweep
+        schedule sizes its own tiles: only the schedule must match)"""
+        return (self.schedule == other.schedule
+                and (self.schedule == "sweep"
+                     or self.tile_rows == other.tile_rows))
+
+    def __repr__(self):
+        return "Pick(kernel=%d, schedule=%r, tile_rows=%d)" % (
+            self.kernel, self.schedule, self.tile_rows)
+
+
+def agree_on_pick(dist, mine, device=None, group=None):
+    """broadcast rank 0's Pick; every rank returns the same object"""
+    import torch
+    t = torch.tensor([mine.kernel, _SCHED_CODE[mine.schedule], mine.tile_rows],
+                     dtype=torch.int64, device=device)
+    dist.broadcast(t, 0, group=group)
+    k, sc, tr = (int(v) for v in t.tolist())
+    return Pick(k, _SCHED_NAME[sc], tr)
+
+
 class ShardExchange:
     """Exchange of equally sized y fragments between `world` ranks.
 
@@ -322,124 +360,3 @@ class ShardedSpmv:
                 pending.append(self.ex.send_chunk(a, b))
         for w in pending:
             wait_all(w)
-
-
-def extra_measurements(S, torch, mat, args, x, y, Mloc, Nglob, K, kind):
-    """Secondary numbers for the same JSON line (1 GPU only): the column-
-    window sweep of the headline family (W = N is the worst case: every 8 B
-    gather of x pulls a 128 B line through the fabric), both HLL kernels, the
-    CSR sub-wave and stream kernels and the blocked path where the autotuner
-    picks it, BASELINE config 2 (banded CSR, flushed) and the
-    KKT-like stand-in for config 4."""
-    st = torch.cuda.current_stream().cuda_stream
-    out = {}
-
-    def med(v):
-        return float(np.median(v))
-
-    def row(tag, m, ms):
-        b = m.algorithmic_bytes
-        out[tag] = {"kernel_ms": round(ms, 5),
-                    "gflops": round(2.0 * m.NZ / (ms * 1e6), 1),
-                    "gbps": round(b / (ms * 1e6), 1),
-                    "roofline_frac": round(b / (ms * 1e6) / 8000.0, 4)}
-
-    dx, dy = x.data_ptr(), y.data_ptr()
-    if hasattr(mat, "num_blocks") and mat.col_major:
-        for k in (1, 2):
-            row("W=N hll_%s" % S.HLL_KERNEL_NAMES[k], mat,
-                med(mat.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        try:
-            mat.build_panels(0)
-            row("W=N hll_tile_panels", mat,
-                med(mat.time(S.HLL_KERNEL_PANELS, dx, dy, 2, 10, 0, args.waves,
-                             stream=st)))
-        except OSError as e:
-            out["error W=N tile_panels"] = str(e)
-    for wname, W in (("W=2^20", 1 << 20), ("W=2^17", 1 << 17),
-                     ("W=2^14", 1 << 14), ("W=2^11", 1 << 11)):
-        try:
-            dA = S.CsrDevice.generate(kind, Mloc, Nglob, K, W, 0, 42)
-            dH = dA.to_hll(True)
-            for k in (1, 2):
-                row("%s hll_%s" % (wname, S.HLL_KERNEL_NAMES[k]), dH,
-                    med(dH.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-            for k in (2, 4):
-                row("%s csr_%s" % (wname, S.CSR_KERNEL_NAMES[k]), dA,
-                    med(dA.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-            best, _ = dH.autotune(dx, dy, True)
-            if best == S.HLL_KERNEL_PANELS:  # else: one of the rows above
-                row("%s hll_tile_panels (autotuned pick)" % wname, dH,
-                    med(dH.time(best, dx, dy, 2, 10, 0, args.waves, stream=st)))
-            dH.release()
-            dA.release()
-        except OSError as e:  # e.g. out of memory on a smaller card
-            out["error " + wname] = str(e)
-    # 10M x 10M banded, 32/row: gathers fully coalesced (stream-bound case)
-    try:
-        dA = S.CsrDevice.generate(S.SYNTH_BANDED, Mloc, Nglob, K, 0, 0, 42)
-        dH = dA.to_hll(True)
-        row("banded10M hll_threads_col_major", dH,
-            med(dH.time(1, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        row("banded10M csr_subwave_row", dA,
-            med(dA.time(2, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        dH.release()
-        dA.release()
-    except OSError as e:
-        out["error banded10M"] = str(e)
-    # config 2: 1M x 1M banded CSR, 16/row; the 212 MB working set fits the
-    # 256 MiB Infinity Cache, so each timed launch follows a 512 MiB flush
-    try:
-        dB = S.CsrDevice.generate(S.SYNTH_BANDED, 1_000_000, 1_000_000, 16, 0,
-                                  0, 42)
-        for k in (1, 2, 4):
-            row("config2 banded1M csr_%s flushed" % S.CSR_KERNEL_NAMES[k], dB,
-                med(dB.time(k, dx, dy, 2, 20, 512 << 20, args.waves,
-                            stream=st)))
-        row("config2 banded1M csr_subwave_row cached", dB,
-            med(dB.time(2, dx, dy, 2, 20, 0, args.waves, stream=st)))
-        dHb = dB.to_hll(True)
-        row("config2 banded1M hll_threads_col_major flushed", dHb,
-            med(dHb.time(1, dx, dy, 2, 20, 512 << 20, args.waves, stream=st)))
-        best, _ = dB.autotune(dx, dy, True)
-        row("config2 banded1M csr_%s (autotuned pick) flushed"
-            % S.CSR_KERNEL_LABELS[best], dB,
-            med(dB.time(best, dx, dy, 2, 20, 512 << 20, args.waves,
-                        stream=st)))
-        dHb.release()
-        dB.release()
-    except OSError as e:
-        out["error config2"] = str(e)
-    # config 4 stand-ins (nlpkkt160 itself cannot be downloaded here):
-    # (a) its structure class: 27-point operator on a 203^3 grid, 8.37M rows,
-    #     rows of 8..27 entries (ragged at the boundary), ~2.2e8 entries;
-    # (b) a row-length skew stress test: short rows + one 128-entry row in 64
-    try:
-        n3 = 203 ** 3
-        dS = S.CsrDevice.generate(S.SYNTH_STENCIL, n3, n3, 27, 0, 0, 42)
-        for k in (1, 2, 4):
-            row("config4-like stencil27 203^3 csr_%s" % S.CSR_KERNEL_NAMES[k],
-                dS, med(dS.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        dSh = dS.to_hll(True)
-        for k in (1, 2):
-            row("config4-like stencil27 203^3 hll_%s" % S.HLL_KERNEL_NAMES[k],
-                dSh, med(dSh.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        best, _ = dS.autotune(dx, dy, True)
-        if best == S.CSR_KERNEL_PANELS:
-            row("config4-like stencil27 203^3 csr_tile_panels (autotuned pick)",
-                dS, med(dS.time(best, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        dSh.release()
-        dS.release()
-        dK = S.CsrDevice.generate(S.SYNTH_KKT, 8_345_600, Nglob, 16, 1 << 16,
-                                  0, 42)
-        for k in (2, 4):
-            row("skewed-rows kkt8.3M csr_%s" % S.CSR_KERNEL_NAMES[k], dK,
-                med(dK.time(k, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        best, _ = dK.autotune(dx, dy, True)
-        if best == S.CSR_KERNEL_PANELS:
-            row("skewed-rows kkt8.3M csr_tile_panels (autotuned pick)", dK,
-                med(dK.time(best, dx, dy, 2, 10, 0, args.waves, stream=st)))
-        dK.release()
-    except OSError as e:
-        out["error config4"] = str(e)
-    return out

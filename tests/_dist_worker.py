@@ -43,6 +43,38 @@ def main():
         else:
             out.copy_(res)
 
+    if mode == "pick":
+        # bench.py's kernel / schedule / tile-height agreement with a FAKE
+        # compute: every rank "tunes" something different, all must end up
+        # running rank 0's pick and arrange the same exchange for it
+        mine = D.Pick(kernel=4 if rank == 0 else 1 + rank % 2,
+                      schedule=("chain", "sweep", None)[rank % 3],
+                      tile_rows=(8192, 0, 0)[rank % 3])
+        pick = D.agree_on_pick(dist, mine)
+        assert (pick.kernel, pick.schedule, pick.tile_rows) == (4, "chain", 8192)
+        assert pick.same_build(mine) == (rank % 3 == 0)
+        assert D.Pick(4, "sweep", 20448).same_build(D.Pick(4, "sweep", 10208))
+        assert not D.Pick(4, "chain", 8192).same_build(D.Pick(4, "chain", 4096))
+        # the pick decides the arrangement: chain -> `chunks` logical shards
+        # per rank, every rank the same collectives (a rank that kept its own
+        # pick would issue a different number of all-gathers and hang)
+        calls = []
+
+        def fake(a, b, out=None):
+            calls.append((a, b))
+            compute(a, b, out)
+        L = chunks if pick.schedule == "chain" else 1
+        sh = D.ShardedSpmv([object()] * L, pick.kernel, rank, world,
+                           rows_per_rank, x, y, chunks=1, compute=fake)
+        sh.step()
+        fI, fJ, fA = O.synth_csr(kind, M, N, K, W, 42)
+        assert np.array_equal(y.numpy(), O.csr_spmv(fI, fJ, fA, x.numpy()))
+        assert calls == [(rows_per_rank // L * i, rows_per_rank // L * (i + 1))
+                         for i in range(L)]
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank %d ok" % rank)
+        return
     if mode == "halo":
         # `chunks` = halo rows: only rows near another rank's range travel
         H = chunks

@@ -54,6 +54,10 @@ def run_world(world, mode, chunks, rows):
                                                (2, "staged", 3),
                                                (2, "shards", 4),
                                                (2, "shards", 1),
+                                               # rank 0's kernel pick is
+                                               # broadcast and built by all
+                                               (2, "pick", 4),
+                                               (3, "pick", 2),
                                                # halo rows: < a fragment, a
                                                # whole fragment and a half
                                                # the node's real widths
