@@ -32,10 +32,10 @@
 
 static struct {
     const char *matrix, *out_dir, *synthetic;
-    int rows, nnz_row, iters, cpu, gpus;
+    int rows, nnz_row, iters, cpu, gpus, only_mgpu;
     long long window;
     bool debug;
-} opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, false};
+} opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, 0, false};
 
 static sparse_csr *A;
 static sparse_hll *H_row, *H_col;
@@ -349,6 +349,7 @@ int main(int argc, char **argv) {
         {"window", required_argument, NULL, 'W'},
         {"iters", required_argument, NULL, 'i'},
         {"gpus", required_argument, NULL, 'g'},
+        {"only-multi-gpu", no_argument, NULL, 1003},
         {"no-cpu", no_argument, NULL, 'C'},
         {"debug", no_argument, NULL, 'd'},
         {"help", no_argument, NULL, 'h'},
@@ -364,6 +365,7 @@ int main(int argc, char **argv) {
         case 'W': opt.window = atoll(optarg); break;
         case 'i': opt.iters = atoi(optarg); break;
         case 'g': opt.gpus = atoi(optarg); break;
+        case 1003: opt.only_mgpu = 1; break;
         case 'C': opt.cpu = 0; break;
         case 'd': opt.debug = true; break;
         case 'h':
@@ -411,13 +413,17 @@ int main(int argc, char **argv) {
     else
         vec_fill_synth(&x, 7, 0);
 
+    if (opt.only_mgpu) /* a GPU-count sweep re-runs only the -g N step */
+        opt.cpu = 0;
     if (opt.cpu || opt.debug)
         run_serial();
     if (opt.cpu)
         run_omp();
     if (spmv_device_count() > 0) {
-        run_gpu();
-        if (opt.gpus >= 1 && (opt.gpus > 1 || getenv("SPMV_FORCE_MGPU")))
+        if (!opt.only_mgpu)
+            run_gpu();
+        if (opt.gpus >= 1 &&
+            (opt.gpus > 1 || opt.only_mgpu || getenv("SPMV_FORCE_MGPU")))
             run_multi_gpu();
     } else
         LOG_WARN("no GPU visible: GPU benchmarks skipped (no CPU fallback)");

@@ -47,11 +47,21 @@ static int nccl_errno(ncclResult_t r) {
         }                                                                     \
     } while (0)
 
-extern "C" {
+/* Every entry point walks the devices with hipSetDevice; a caller that
+ * shares the process (torch, another library) must find ITS current device
+ * unchanged afterwards. */
+struct device_guard {
+    int saved;
+    bool ok;
+    device_guard() : saved(0), ok(hipGetDevice(&saved) == hipSuccess) {}
+    ~device_guard() {
+        if (ok)
+            (void)hipSetDevice(saved);
+    }
+};
 
-void spmv_mgpu_destroy(spmv_mgpu *g) {
-    if (!g)
-        return;
+/* shards and vectors of a previous load / generate on this handle */
+static void drop_shards(spmv_mgpu *g) {
     for (int r = 0; r < g->n; ++r) {
         (void)hipSetDevice(g->dev[r]);
         if (g->csr[r])
@@ -60,6 +70,22 @@ void spmv_mgpu_destroy(spmv_mgpu *g) {
             spmv_hll_release(g->hll[r]);
         (void)hipFree(g->x[r]);
         (void)hipFree(g->y[r]);
+        g->csr[r] = NULL;
+        g->hll[r] = NULL;
+        g->x[r] = g->y[r] = NULL;
+    }
+    g->rows_per_gpu = g->M = g->N = 0;
+}
+
+extern "C" {
+
+void spmv_mgpu_destroy(spmv_mgpu *g) {
+    if (!g)
+        return;
+    device_guard keep;
+    drop_shards(g);
+    for (int r = 0; r < g->n; ++r) {
+        (void)hipSetDevice(g->dev[r]);
         if (g->comm[r])
             ncclCommDestroy(g->comm[r]);
         if (g->stream[r])
@@ -75,6 +101,7 @@ int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
     if (spmv_device_count() < ngpus)
         return -ENODEV;
     int rc = 0;
+    device_guard keep;
     spmv_mgpu *g = new spmv_mgpu();
     g->n = ngpus;
     g->rows_per_gpu = g->M = g->N = g->is_hll = 0;
@@ -121,6 +148,8 @@ int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
     if (IS_ERR(starts))
         return PTR_ERR(starts);
     int rc = 0;
+    device_guard keep;
+    drop_shards(g); /* a handle can be loaded again: nothing leaks */
     g->M = A->M;
     g->N = A->N;
     g->is_hll = as_hll != 0;
@@ -155,6 +184,8 @@ int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
     if (!g || rows_per_gpu < 0 || rows_per_gpu % HACK_SIZE)
         return -EINVAL;
     int rc = 0;
+    device_guard keep;
+    drop_shards(g);
     g->rows_per_gpu = rows_per_gpu;
     g->M = g->N = rows_per_gpu * g->n;
     g->is_hll = as_hll != 0;
@@ -178,6 +209,7 @@ int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host) {
     if (!g || !x_host)
         return -EINVAL;
     int rc = 0;
+    device_guard keep;
     for (int r = 0; r < g->n; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         HIP_TRY(hipMemcpy(g->x[r], x_host, (size_t)g->N * sizeof(double),
@@ -191,6 +223,7 @@ int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed) {
     if (!g)
         return -EINVAL;
     int rc = 0;
+    device_guard keep;
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         rc = spmv_dev_fill_synth(g->x[r], g->N, seed, 0, g->stream[r]);
@@ -208,6 +241,7 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
     if (!g || !kernel)
         return -EINVAL;
     int rc = 0, pick = -1;
+    device_guard keep;
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
@@ -219,15 +253,24 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
         if (r == 0)
             pick = k;
     }
+    /* device 0's blocked copy is the model: every other shard is rebuilt
+     * with its schedule, tile height and build options unless it already
+     * holds the same (shards of one matrix run one arrangement) */
     for (int r = 1; r < g->n && !rc && pick == blocked; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
-        int steps = 0;
-        int have = g->is_hll
-                       ? spmv_hll_panels_info(g->hll[r], &steps, NULL, NULL, NULL)
-                       : spmv_csr_panels_info(g->csr[r], &steps, NULL, NULL, NULL);
-        if (have == -ENOENT)
-            rc = g->is_hll ? spmv_hll_build_panels(g->hll[r], 0)
-                           : spmv_csr_build_panels(g->csr[r], 0);
+        const bool same =
+            g->is_hll
+                ? (spmv_hll_panels_schedule(g->hll[r]) ==
+                       spmv_hll_panels_schedule(g->hll[0]) &&
+                   spmv_hll_panels_tile_rows(g->hll[r]) ==
+                       spmv_hll_panels_tile_rows(g->hll[0]))
+                : (spmv_csr_panels_schedule(g->csr[r]) ==
+                       spmv_csr_panels_schedule(g->csr[0]) &&
+                   spmv_csr_panels_tile_rows(g->csr[r]) ==
+                       spmv_csr_panels_tile_rows(g->csr[0]));
+        if (!same)
+            rc = g->is_hll ? spmv_hll_build_panels_like(g->hll[r], g->hll[0])
+                           : spmv_csr_build_panels_like(g->csr[r], g->csr[0]);
     }
     if (!rc)
         *kernel = pick;
@@ -251,6 +294,7 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
     if (!g || iters < 0 || warmup < 0 || (iters && !ms_each))
         return -EINVAL;
     int rc = 0;
+    device_guard keep;
     if (kernel < 0)
         kernel = g->is_hll ? 1 : 2;
     for (int it = -warmup; it < iters && !rc; ++it) {
@@ -271,12 +315,22 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
         if (rc)
             break;
         if (g->n > 1) {
+            /* every call inside the group is checked, and the group is
+             * ALWAYS closed before an error leaves this function -- an open
+             * group would swallow the communicators' next operations */
             NCCL_TRY(ncclGroupStart());
-            for (int r = 0; r < g->n; ++r)
-                ncclAllGather(g->y[r] + (size_t)r * g->rows_per_gpu, g->y[r],
-                              (size_t)g->rows_per_gpu, ncclDouble, g->comm[r],
-                              g->stream[r]);
-            NCCL_TRY(ncclGroupEnd());
+            ncclResult_t first_bad = ncclSuccess;
+            for (int r = 0; r < g->n; ++r) {
+                const ncclResult_t e = ncclAllGather(
+                    g->y[r] + (size_t)r * g->rows_per_gpu, g->y[r],
+                    (size_t)g->rows_per_gpu, ncclDouble, g->comm[r],
+                    g->stream[r]);
+                if (e != ncclSuccess && first_bad == ncclSuccess)
+                    first_bad = e;
+            }
+            const ncclResult_t closed = ncclGroupEnd();
+            NCCL_TRY(first_bad);
+            NCCL_TRY(closed);
         }
         for (int r = 0; r < g->n; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
@@ -293,6 +347,7 @@ fail:
 int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host) {
     if (!g || rank < 0 || rank >= g->n || !y_host)
         return -EINVAL;
+    device_guard keep;
     HIP_RET(hipSetDevice(g->dev[rank]));
     HIP_RET(hipMemcpy(y_host, g->y[rank], (size_t)g->M * sizeof(double),
                       hipMemcpyDeviceToHost));

@@ -54,6 +54,7 @@ void log_prog_usage(const char *prog) {
             "  -g, --gpus <n>          row-partition over n GPUs + RCCL all-gather(y)\n"
             "  -i, --iters <n>         timed GPU launches per kernel (default 20)\n"
             "      --no-cpu            skip the serial / OpenMP benchmarks\n"
+            "      --only-multi-gpu    run only the -g <n> step (GPU-count sweeps)\n"
             "  -h, --help              show this message\n",
             prog);
 }

@@ -20,8 +20,10 @@ pytestmark = pytest.mark.gpu
     # GPU, each all-gathered while the next one computes
     ["--shards-per-gpu", "4"],
     ["--shards-per-gpu", "2", "--kernel", "4", "--window", "0"],
-    # the blocked path with an exchange splits the rank's rows in two by itself
-    ["--kernel", "4", "--window", "0", "--expect-shards", "2"],
+    # the blocked path (sweep schedule) with an exchange: the serial
+    # arrangement and two overlapped logical shards on fewer CUs are both
+    # timed and the faster one kept -- either outcome is legitimate
+    ["--kernel", "4", "--window", "0", "--expect-shards", "1or2"],
     # autotuned: the pick (kernel, blocked schedule, tile height) is broadcast
     ["--kernel", "-1", "--window", "65536"],
     # opt-in halo exchange (a world of one has nobody to send to)
@@ -38,7 +40,7 @@ def test_bench_through_torchrun_one_rank(extra):
     expect = None
     if "--expect-shards" in extra:
         i = extra.index("--expect-shards")
-        expect, extra = int(extra[i + 1]), extra[:i] + extra[i + 2:]
+        expect, extra = extra[i + 1], extra[:i] + extra[i + 2:]
     cmd += extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env,
                        timeout=600)
@@ -56,6 +58,10 @@ def test_bench_through_torchrun_one_rank(extra):
         assert j["config"]["exchange"] == "halo"
         assert j["config"]["halo_rows"] == 2048  # half of --window 4096
     if expect:
-        assert j["config"]["logical_shards_per_gpu"] == expect
-        assert j["config"]["rows_per_gpu"] == 320000
-        assert j["config"]["exchange"] == "staged"
+        arr = j["config"]["exchange_arrangement"]
+        assert "exchange after the kernel" in arr and "overlapped" in arr
+        L = j["config"]["logical_shards_per_gpu"]
+        assert L in (1, 2) and j["config"]["rows_per_gpu"] == 320000
+        assert j["config"]["exchange"] == ("staged" if L == 2 else "allgather")
+        assert arr.endswith("-> overlapped" if L == 2
+                            else "-> exchange after the kernel")

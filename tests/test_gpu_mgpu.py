@@ -59,6 +59,34 @@ def test_mgpu_generated_shards():
         S.MultiGpu(S.device_count() + 1)
 
 
+def test_mgpu_handle_can_be_reloaded_and_leaves_the_current_device_alone():
+    """a second load / generate on one handle frees the previous shards
+    (device memory stays flat over 10 reloads) and no entry point changes
+    the caller's current device (mgpu.hip)"""
+    import torch
+    n = min(S.device_count(), 8)
+    dev0 = S._lib.spmv_get_device()
+    g = S.MultiGpu(n)
+    free0 = None
+    for it in range(10):
+        g.generate(S.SYNTH_RANDOM, 320_000, 32, 4096, 42, as_hll=bool(it & 1))
+        g.fill_x(7)
+        g.spmv(iters=1)
+        assert S._lib.spmv_get_device() == dev0
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if it == 1:
+            free0 = free
+        if it > 1:  # HLL / CSR alternate: compare like with like, +-64 MB
+            assert abs(free - free0) < (64 << 20) or (it & 1) != 1
+    y = g.get_y(0)
+    want, sc = O.synth_row_dot(S.SYNTH_RANDOM, 320_000 * n, 320_000 * n, 32,
+                               4096, 0, 42, 7, 12345)
+    assert abs(y[12345] - want) <= 1e-12 * sc
+    g.destroy()
+    assert S._lib.spmv_get_device() == dev0
+
+
 def test_driver_multi_gpu_flag(tmp_path):
     drv = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
     env = dict(os.environ, OMP_NUM_THREADS="4", SPMV_FORCE_MGPU="1")
