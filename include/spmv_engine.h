@@ -55,6 +55,9 @@ int spmv_get_device(void);   /* current device or negative errno */
 int spmv_device_info(int device, char *name, size_t len, int *compute_units,
                      size_t *hbm_bytes);
 
+/* free / total bytes of HBM on the current device (leak checks) */
+int spmv_dev_mem_info(size_t *free_bytes, size_t *total_bytes);
+
 /* ---- raw device memory, for hosts without their own allocator ---- */
 int spmv_dev_malloc(void **dptr, size_t bytes);
 int spmv_dev_free(void *dptr);
@@ -114,7 +117,13 @@ int spmv_csr_upload(const sparse_csr *A, spmv_csr_dev **out);
 /* Build a synthetic matrix (spmv_synth.h) directly in device memory. */
 int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
                       uint64_t seed, spmv_csr_dev **out);
-/* y[0..M) = A * x on `stream`; asynchronous. kernel = 0..4 (hip_csr.h). */
+/* y[0..M) = A * x on `stream`; asynchronous. kernel = 0..4 (hip_csr.h).
+ * Launches of one handle must be stream-ordered (the persistent kernels keep
+ * per-handle device scratch); different handles are independent.
+ * opts.variant (tuning): bit 0 keep the hardware's workgroup->XCD order;
+ * bits 2-3 passes of the sub-wave kernel (4 / 2 instead of 8); kernel 4:
+ * bit 4 the persistent software-pipelined form, bit 5 the one-shot form
+ * (default: whichever spmv_csr_autotune measured faster, else one-shot). */
 int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
                     const spmv_launch_opts *opts, const double *d_x,
                     double *d_y, void *stream);

@@ -185,6 +185,8 @@ _sig("spmv_set_device", C.c_int, C.c_int)
 _sig("spmv_get_device", C.c_int)
 _sig("spmv_device_info", C.c_int, C.c_int, C.c_char_p, C.c_size_t, _ip,
      C.POINTER(C.c_size_t))
+_sig("spmv_dev_mem_info", C.c_int, C.POINTER(C.c_size_t),
+     C.POINTER(C.c_size_t))
 _sig("spmv_dev_malloc", C.c_int, C.POINTER(C.c_void_p), C.c_size_t)
 _sig("spmv_dev_free", C.c_int, C.c_void_p)
 _sig("spmv_dev_memset", C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p)
@@ -335,6 +337,13 @@ def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
     o.reserve_cus = reserve_cus
     o.lds_min = lds_min or _env_int("SPMV_LDS_MIN", 1, 160 * 1024 - 64)
     return o
+
+
+def dev_mem_info():
+    """(free, total) bytes of HBM on the current device"""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(_lib.spmv_dev_mem_info(C.byref(f), C.byref(t)), "spmv_dev_mem_info")
+    return f.value, t.value
 
 
 def device_info(d=0):

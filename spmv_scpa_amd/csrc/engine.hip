@@ -189,6 +189,18 @@ int spmv_device_info(int device, char *name, size_t len, int *compute_units,
     return 0;
 }
 
+int spmv_dev_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    size_t f = 0, t = 0;
+    HIP_RET(hipMemGetInfo(&f, &t));
+    if (free_bytes)
+        *free_bytes = f;
+    if (total_bytes)
+        *total_bytes = t;
+    return 0;
+}
+
 int spmv_dev_malloc(void **dptr, size_t bytes) {
     if (!dptr)
         return -EINVAL;

@@ -63,7 +63,6 @@ def test_mgpu_handle_can_be_reloaded_and_leaves_the_current_device_alone():
     """a second load / generate on one handle frees the previous shards
     (device memory stays flat over 10 reloads) and no entry point changes
     the caller's current device (mgpu.hip)"""
-    import torch
     n = min(S.device_count(), 8)
     dev0 = S._lib.spmv_get_device()
     g = S.MultiGpu(n)
@@ -73,8 +72,8 @@ def test_mgpu_handle_can_be_reloaded_and_leaves_the_current_device_alone():
         g.fill_x(7)
         g.spmv(iters=1)
         assert S._lib.spmv_get_device() == dev0
-        torch.cuda.synchronize()
-        free = torch.cuda.mem_get_info()[0]
+        S.stream_sync()
+        free = S.dev_mem_info()[0]
         if it == 1:
             free0 = free
         if it > 1:  # HLL / CSR alternate: compare like with like, +-64 MB
