@@ -420,6 +420,8 @@ def single_matrix_bench(args, S, torch, dev):
     torch.cuda.synchronize()
     if args.kernel >= 0:
         kernel, tuned = args.kernel, None
+        if kernel == S.CSR_KERNEL_PANELS:  # fixed: default chain layout (the
+            dA.build_panels(0, "chain")    # SPMV_TILE_ROWS knob applies)
     else:
         kernel, tuned = dA.autotune(x.data_ptr(), y.data_ptr())
     kname = "csr_" + S.CSR_KERNEL_LABELS[kernel]

@@ -335,7 +335,7 @@ def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
     o.tile_rows = tile_rows or _env_int("SPMV_TILE_ROWS", 32, 20448)
     o.sweep_wgs_per_cu = sweep_wgs_per_cu or _env_int("SPMV_SWEEP_WGS", 1, 8)
     o.reserve_cus = reserve_cus
-    o.lds_min = lds_min or _env_int("SPMV_LDS_MIN", 1, 160 * 1024 - 64)
+    o.lds_min = lds_min or _env_int("SPMV_LDS_MIN", 1, 160 * 1024 - 256)
     return o
 
 

@@ -319,6 +319,7 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
                       int variant, const double *x, double *y, int b0, int b1,
                       hipStream_t s) {
     const bool remap = !(variant & 1);
+    (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     if (!H || !x || !y || b0 < 0 || b1 > H->nb || b0 > b1)
         return -EINVAL;
     if ((kernel == 0 || kernel == 3) == (H->col_major != 0))

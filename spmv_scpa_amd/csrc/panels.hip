@@ -63,6 +63,7 @@
                                 perf only, see phase_wait */
 #define CNT_STRIDE 32        /* one phase counter per 128-B line */
 #define SWEEP_TAIL 16384     /* zero slots behind the entries: >= 3 chunks */
+#define BIG_LDS_BYTES (160 * 1024 - 256) /* most dynamic LDS a launch asks for */
 
 struct spmv_panels {
     int N;           /* columns */
@@ -326,7 +327,9 @@ extern "C" int spmv_set_panel_schedule(int sched) {
 
 /* rows of y one workgroup can hold when `per_cu` of them share a CU's LDS */
 static int sweep_tile_rows_max(int per_cu) {
-    return (int)((160 * 1024 - 64 * per_cu) / per_cu / 8 / 32 * 32);
+    /* the workgroups of a CU share 160 KiB; each carries a 128-byte static
+     * ring besides its tile */
+    return (int)((160 * 1024 - 128 * per_cu) / per_cu / 8 / 32 * 32);
 }
 
 /* compute units of the current device; -ENODEV unless it is a gfx950 (the
@@ -374,7 +377,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         o = &dflt;
     if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
-        o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > 160 * 1024 - 64 ||
+        o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
         o->reserved[0] || o->reserved[1])
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
@@ -1259,9 +1262,13 @@ template <auto Kernel> static int allow_big_lds(void) {
     HIP_RET(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
+        /* dynamic + static LDS must stay within 160 KiB: the sweep kernels
+         * carry a 128-byte static ring (asking for 160 KiB - 64 made the
+         * call fail with hipErrorInvalidValue once the ring grew from 32 to
+         * 128 bytes).  BIG_LDS_BYTES = the tallest tile, 20448 rows. */
         HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 64));
+                                    BIG_LDS_BYTES));
         done.fetch_or(bit, std::memory_order_release);
     }
     return 0;
@@ -1273,6 +1280,7 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         return -EINVAL;
     if (M == 0)
         return 0;
+    (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     size_t lds = (size_t)P->tile_rows * sizeof(double);
     if (waves <= 0)
         waves = P->waves_hint;

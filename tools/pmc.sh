@@ -6,6 +6,7 @@ tag="$1"; ctr="$2"; shift 2
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$root/gpurun_out/pmc_$tag"
 mkdir -p "$out"
+case "$1" in /*) ;; *) set -- "$root/$1" "${@:2}" ;; esac  # script path: absolute
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out" -- python3 "$@" > "$out/stdout.txt" 2> "$out/stderr.txt"
 echo "rc=$?"

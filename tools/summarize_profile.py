@@ -46,7 +46,8 @@ def last_dispatch(path):
 
 # bench.py kernel label -> device function(s) that run it
 KERNEL_FUNCS = {
-    "tile_panels": ("k_tiles_sweep", "k_tiles_step", "k_tiles_chain"),
+    "tile_panels": ("k_tiles_flow", "k_tiles_sweep", "k_tiles_step",
+                    "k_tiles_chain"),
     "hll_threads_row_major": ("k_hll_row_major",),
     "hll_threads_col_major": ("k_hll_col_lds",),
     "hll_wave_block": ("k_hll_col_direct",),
@@ -55,7 +56,7 @@ KERNEL_FUNCS = {
     "csr_wave_row": ("k_csr_wave_row",),
     "csr_subwave_row": ("k_csr_subwave_row",),
     "csr_block_row": ("k_csr_block_row",),
-    "csr_stream": ("k_csr_stream",),
+    "csr_stream": ("k_csr_stream_pipe", "k_csr_stream"),
 }
 
 
