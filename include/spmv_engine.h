@@ -118,12 +118,11 @@ int spmv_csr_upload(const sparse_csr *A, spmv_csr_dev **out);
 int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
                       uint64_t seed, spmv_csr_dev **out);
 /* y[0..M) = A * x on `stream`; asynchronous. kernel = 0..4 (hip_csr.h).
- * Launches of one handle must be stream-ordered (the persistent kernels keep
- * per-handle device scratch); different handles are independent.
+ * Launches of one handle must be stream-ordered (the sweep schedule of the
+ * blocked path keeps per-handle phase counters); different handles are
+ * independent.
  * opts.variant (tuning): bit 0 keep the hardware's workgroup->XCD order;
- * bits 2-3 passes of the sub-wave kernel (4 / 2 instead of 8); kernel 4:
- * bit 4 the persistent software-pipelined form, bit 5 the one-shot form
- * (default: whichever spmv_csr_autotune measured faster, else one-shot). */
+ * bits 2-3 passes of the sub-wave kernel (4 / 2 instead of 8). */
 int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
                     const spmv_launch_opts *opts, const double *d_x,
                     double *d_y, void *stream);

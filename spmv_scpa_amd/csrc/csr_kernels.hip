@@ -359,192 +359,6 @@ __global__ void __launch_bounds__(STREAM_THREADS)
 }
 
 /* ------------------------------------------------------------------ */
-/*
- * stream, persistent and software-pipelined (same table, same LDS forms,
- * same results as k_csr_stream).  The one-shot kernel walks a range through
- * three dependent memory phases (table -> JA/AS -> x) and only the workgroups
- * that happen to be in the second one keep stream bytes in flight: short
- * launches (1M rows: 45 us against 34 us of pure streaming) are latency-bound.
- * Here a workgroup takes ranges from a global ticket counter (dynamic, so the
- * chip drains evenly whatever the grid) and runs them as a pipeline:
- *
- *   the JA/AS (and IRP) loads of range k+1 are issued as soon as range k's
- *   registers have gone to LDS -- they fly under k's x gathers and row sums;
- *   the table entry and ticket of range k+2 are fetched one step earlier.
- *
- * ticket[0] hands out ranges; the workgroup that draws the last failing
- * ticket (value n + grid - 1) puts the counter back to 0, so the next launch
- * on the stream finds it ready (launches sharing a handle are stream-ordered,
- * as for y itself).
- */
-/* workgroup barrier that orders LDS only: __syncthreads() also drains the
- * vector-memory queue (s_waitcnt vmcnt(0)), which would make every
- * prefetched load of the next range land before the barrier -- the first
- * build of this kernel did exactly that and ran 2.5x SLOWER than the
- * one-shot form (0.117 vs 0.047 ms on 1M x 16). */
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__global__ void __launch_bounds__(STREAM_THREADS)
-    k_csr_stream_pipe(int n_rowblk, unsigned *ticket,
-                      const int2 *__restrict__ rowblk,
-                      const unsigned char *__restrict__ mode,
-                      const int *__restrict__ irp, const int *__restrict__ ja,
-                      const double *__restrict__ as,
-                      const double *__restrict__ x, double *__restrict__ y) {
-    __shared__ double s_val[STREAM_LDS];
-    __shared__ int s_ja[STREAM_LDS];
-    __shared__ double part[STREAM_THREADS / WAVE];
-    __shared__ int rowptr[STREAM_THREADS + 1];
-    __shared__ unsigned s_ticket[2];
-    constexpr int E = STREAM_NNZ / STREAM_THREADS;
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
-    const unsigned last_ticket = (unsigned)n_rowblk + gridDim.x - 1u;
-
-    /* tickets: slot k & 1 holds the range of pipeline step k */
-    auto draw = [&](int slot) {
-        if (tid == 0) {
-            const unsigned t = atomicAdd(ticket, 1u);
-            if (t == last_ticket) /* everybody has drawn a failing ticket */
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            s_ticket[slot] = t;
-        }
-    };
-    /* a workgroup draws until it fails once: exactly grid failing draws */
-    draw(0);
-    __syncthreads();
-    unsigned rb = s_ticket[0];
-    if (rb >= (unsigned)n_rowblk)
-        return;
-    draw(1);
-    __syncthreads();
-    unsigned rb_next = s_ticket[1];
-    bool has_next = rb_next < (unsigned)n_rowblk;
-
-    int c[E], rp = 0;
-    double a[E];
-    int2 t_a = rowblk[rb], t_z = rowblk[rb + 1];
-    int md = mode[rb];
-    int2 n_a = has_next ? rowblk[rb_next] : t_a;
-    int2 n_z = has_next ? rowblk[rb_next + 1] : t_a;
-    int n_md = has_next ? mode[rb_next] : 0;
-
-    /* coalesced fetch of a range's entries and of its row offsets */
-    auto issue = [&](int2 ta, int2 tz) {
-        const int beg = ta.y, cnt = tz.y - ta.y, rows = tz.x - ta.x;
-        if (cnt > STREAM_NNZ)
-            return; /* one long row: read in place */
-        if (tid < rows)
-            rp = irp[ta.x + tid] - beg;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int k = tid + e * STREAM_THREADS;
-            const bool has = k < cnt;
-            c[e] = has ? ld_stream(ja + beg + k) : -1;
-            a[e] = has ? ld_stream(as + beg + k) : 0.0;
-        }
-    };
-    issue(t_a, t_z);
-
-    for (int step = 0;; ++step) {
-        const int row_a = t_a.x, rows = t_z.x - t_a.x;
-        const int beg = t_a.y, cnt = t_z.y - t_a.y;
-        /* the ticket after next, drawn a whole step ahead of its use */
-        if (has_next)
-            draw(step & 1);
-
-        if (cnt > STREAM_NNZ) {
-            double acc = 0.0;
-            for (int k = beg + tid; k < t_z.y; k += STREAM_THREADS)
-                acc += ld_stream(as + k) * x[ld_stream(ja + k)];
-            acc = group_sum<WAVE>(acc);
-            if (lane == 0)
-                part[tid / WAVE] = acc;
-            lds_barrier();
-            if (tid == 0) {
-                double t = 0.0;
-                for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
-                    t += part[w];
-                y[row_a] = t;
-            }
-            if (has_next)
-                issue(n_a, n_z);
-        } else {
-            /* registers -> LDS, then the next range's loads take their place */
-            if (tid < rows)
-                rowptr[tid] = rp;
-            if (tid == 0)
-                rowptr[rows] = cnt;
-            if (md == 0) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int k = tid + e * STREAM_THREADS;
-                    if (c[e] >= 0) {
-                        s_ja[TSKEW(k)] = c[e];
-                        s_val[TSKEW(k)] = a[e];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if (c[e] >= 0)
-                        s_val[tid + e * STREAM_THREADS] = a[e] * x[c[e]];
-            }
-            if (has_next)
-                issue(n_a, n_z);
-            lds_barrier();
-            if (md == 0) {
-                if (rows * 4 <= STREAM_THREADS)
-                    stream_rows<4>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
-                else if (rows * 2 <= STREAM_THREADS)
-                    stream_rows<2>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
-                else
-                    stream_rows<1>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
-            } else {
-                int g = 1;
-                while (g < WAVE && g * rows * 2 <= cnt)
-                    g <<= 1;
-                const int sub = tid & (g - 1);
-                const int per_pass = STREAM_THREADS / g;
-                for (int r = tid / g;
-                     r < rows + (per_pass - rows % per_pass) % per_pass;
-                     r += per_pass) {
-                    double acc = 0.0;
-                    const bool live = r < rows;
-                    if (live) {
-                        const int ra = rowptr[r], rz = rowptr[r + 1];
-                        for (int k = ra + sub; k < rz; k += g)
-                            acc += s_val[k];
-                    }
-                    for (int d = g >> 1; d > 0; d >>= 1)
-                        acc += __shfl_down(acc, d, WAVE);
-                    if (live && sub == 0)
-                        y[row_a + r] = acc;
-                }
-            }
-        }
-        if (!has_next)
-            return;
-        lds_barrier(); /* LDS (and the drawn ticket) are free again */
-        /* advance: next becomes current, the drawn ticket becomes next */
-        rb = rb_next;
-        t_a = n_a;
-        t_z = n_z;
-        md = n_md;
-        rb_next = s_ticket[step & 1];
-        has_next = rb_next < (unsigned)n_rowblk;
-        if (has_next) {
-            n_a = rowblk[rb_next];
-            n_z = rowblk[rb_next + 1];
-            n_md = mode[rb_next];
-        }
-    }
-}
-
-/* ------------------------------------------------------------------ */
 static int pick_group(const spmv_csr_dev *A, int group) {
     if (group >= 2 && group <= 32 && (group & (group - 1)) == 0)
         return group;
@@ -645,26 +459,18 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
         break;
     }
     case 4: {
-        if (A->n_rowblk <= 0)
-            break;
-        /* variant bit 4: the persistent pipelined form; bit 5: the one-shot
-         * form whatever the handle's tuned hint says */
-        const bool pipe = (variant & 16) || (A->stream_pipe && !(variant & 32));
-        if (pipe && A->stream_ticket) {
-            /* 6 workgroups of 26 KiB of LDS share a CU */
-            int grid = A->cus * 6;
-            if (grid > A->n_rowblk)
-                grid = A->n_rowblk;
-            hipLaunchKernelGGL(k_csr_stream_pipe, dim3(grid),
-                               dim3(STREAM_THREADS), 0, s, A->n_rowblk,
-                               A->stream_ticket, (const int2 *)A->rowblk,
-                               A->rowblk_mode, A->irp, A->ja, A->as, x, y);
-        } else {
+        /* Tried in round 2 and dropped on measurement: a persistent,
+         * ticket-scheduled, software-pipelined form (next range's JA/AS
+         * loads issued under the current range's gathers).  2.5x slower
+         * (1M x 16: 0.116 vs 0.046 ms; 10M x 32: 1.87 vs 0.65 ms), with
+         * __syncthreads and with LDS-only barriers alike: vector-memory
+         * results return in order, so the gathers wait behind the prefetched
+         * stream loads they were meant to overlap. */
+        if (A->n_rowblk > 0)
             hipLaunchKernelGGL(k_csr_stream, dim3(A->n_rowblk),
                                dim3(STREAM_THREADS), 0, s,
                                (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
                                A->ja, A->as, x, y);
-        }
         break;
     }
     default:

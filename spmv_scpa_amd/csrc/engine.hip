@@ -374,13 +374,6 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
     HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
                       hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&d->stream_ticket, 64));
-    HIP_TRY(hipMemset(d->stream_ticket, 0, 64));
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, d->device));
-        d->cus = prop.multiProcessorCount;
-    }
 fail:
     return rc;
 }
@@ -408,7 +401,6 @@ void spmv_csr_release(spmv_csr_dev *d) {
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
     (void)hipFree(d->rowblk_mode);
-    (void)hipFree(d->stream_ticket);
     panels_free(d->panels);
     free(d);
 }
@@ -1110,22 +1102,6 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
         if (m < bms) {
             bms = m;
             best = cand[k];
-        }
-        if (cand[k] == 4) {
-            /* kernel 4 in its persistent pipelined form (variant bit 4);
-             * the faster form becomes the handle's default for kernel 4 */
-            spmv_launch_opts o;
-            memset(&o, 0, sizeof o);
-            o.variant = 16;
-            rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush, ms.data(), NULL);
-            if (rc)
-                return rc;
-            const double mp = median_of(ms);
-            A->stream_pipe = mp < m;
-            if (mp < bms) {
-                bms = mp;
-                best = 4;
-            }
         }
     }
     if (allow_panels) {

@@ -75,10 +75,6 @@ struct spmv_csr_dev {
     int *rowblk;
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
-    unsigned *stream_ticket; /* [1] range counter of the persistent stream
-                                kernel; zero between launches */
-    int stream_pipe; /* tuned hint: kernel 4 runs persistent + pipelined */
-    int cus;         /* compute units of the handle's device */
     int max_row_len;
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };

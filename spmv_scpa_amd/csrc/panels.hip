@@ -659,6 +659,18 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
  * serialises gathers and stream (measured 2.2 ms vs the sum of both).
  * The poll for the NEXT panel's entry condition thus returns with the
  * gathers and costs no drain; only a miss falls into the (bounded) spin.
+ *
+ * Tried in round 2 and dropped on measurement (gpurun r2c6, same run): a
+ * wavefront-granular form -- each wavefront walks 256-slot blocks of the
+ * tile's entry list straight across bucket boundaries, all bookkeeping in
+ * SGPRs -- which removes the masked tail chunk of every bucket (the third
+ * chunk of a ~8500-entry bucket is 7 % full).  Config 3, W = N: 1.57 vs
+ * 1.56 ms at 512 lanes, 1.49 vs 1.63 at 256 (noise-level gain); one shard of
+ * the 80M-column problem (610 panels, ~1000-entry buckets): 5.42 vs 3.01 ms
+ * -- the per-panel scalar work of every wavefront costs more than the tail
+ * chunks did.  Also dropped: one phase arrival per WAVEFRONT instead of per
+ * workgroup (256 same-address atomics per phase and XCD; the selector fell
+ * back to the chain schedule).
  */
 
 template <int Q> struct sweep_chunk {
@@ -834,189 +846,6 @@ __global__ void __launch_bounds__(NT)
             if (A.p >= panels)
                 break;
         }
-        __syncthreads();
-        const int64_t row0 = (int64_t)t * tile_rows;
-        for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
-            __builtin_nontemporal_store(ytile[i], y + row0 + i);
-        __syncthreads();
-    }
-}
-
-/* ------------------------------------------------------------------ */
-/* schedule "sweep", wavefront-granular form ("flow")                    */
-/* ------------------------------------------------------------------ */
-/*
- * Same layout, same tile/panel geometry, same phase counters as
- * k_tiles_sweep, but the unit of work is ONE WAVEFRONT BLOCK of 256 slots
- * instead of a workgroup-wide chunk of NT x Q x 4 slots.  A tile's buckets
- * lie back to back (each padded to whole blocks), so the tile is simply a
- * list of blocks; wavefront w of W takes blocks w, w + W, w + 2W, ... of
- * that list, Q per pipeline step, straight across bucket boundaries.
- *
- * Why: with workgroup chunks a bucket of ~8500 entries (config 3) costs three
- * chunks of 4096, the last one 7 % full -- its lanes are masked but its three
- * stream loads per group are still issued (they fetch the NEXT bucket's
- * slots, which are then fetched again): ~45 % more stream instructions and
- * ~1 GB of the 6.3 GB the counters show.  Blocks leave only the padding to
- * 256 slots (1.5 %).
- *
- * Everything that steers a wavefront is wave-uniform and lives in SGPRs
- * (the wave index goes through readfirstlane), so bucket bookkeeping is
- * scalar code with scalar loads and every vector-memory instruction of the
- * loop body stays unconditional (see k_tiles_sweep).
- *
- * Phase protocol: a wavefront leaves panel q when its read position passes
- * it (also panels it holds no block of); the last wavefront of the workgroup
- * to leave arrives at counter q (wg_arrive).  Before a wavefront gathers its
- * first block of panel p it wants counter p - lag complete (n_x = the XCD's
- * workgroups).  The poll is issued with the block's loads, two steps ahead;
- * only a miss spins, bounded.
- */
-template <int Q> struct flow_chunk {
-    u32x4 en[Q];
-    f64x2 va[Q], vb[Q];
-    int live[Q];   /* lane: entry u of the block exists iff live > 64 u */
-    int pa[Q];     /* uniform: panel of the block; < 0: past the tile's end */
-    int polled[Q]; /* uniform: counter (pa - lag) as seen at load time */
-    bool first[Q]; /* uniform: the wavefront's first block in that panel */
-};
-
-template <int NT, int Q>
-__global__ void __launch_bounds__(NT)
-    k_tiles_flow(int M, int tile_rows, int tiles, int panels, int shift,
-                 int lag, int spin, unsigned total,
-                 const int64_t *__restrict__ bptr,
-                 const int *__restrict__ blen,
-                 const unsigned *__restrict__ tent,
-                 const double *__restrict__ tval,
-                 const double *__restrict__ x, double *__restrict__ y,
-                 int *phase_cnt) {
-    extern __shared__ double ytile[];
-    __shared__ int wave_done[WAVE_RING];
-    constexpr int WAVES = NT / WAVE;
-    const int tid = threadIdx.x;
-    const unsigned lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = gridDim.x;
-    const int xcd = blockIdx.x % NUM_XCD;
-    const int n_x = grid / NUM_XCD + (xcd < (grid % NUM_XCD) ? 1 : 0);
-    const int rounds = (tiles + grid - 1) / grid;
-    int *cnt = phase_cnt + (size_t)xcd * rounds * panels * CNT_STRIDE;
-    const unsigned lowmask = (1u << shift) - 1u;
-    bool synced = true;
-    if (tid < WAVE_RING)
-        wave_done[tid] = 0;
-
-    for (int r = 0; r < rounds; ++r) {
-        const int t = r * grid + blockIdx.x;
-        const int q0 = r * panels;
-        if (t >= tiles) { /* no tile this round: arrive at all its phases */
-            if (tid == 0)
-                for (int p = 0; p < panels; ++p)
-                    phase_arrive(cnt + (size_t)(q0 + p) * CNT_STRIDE);
-            continue;
-        }
-        for (int i = tid; i < tile_rows; i += NT)
-            ytile[i] = 0.0;
-        __syncthreads();
-
-        const int64_t *bp = bptr + (int64_t)t * panels;
-        const int *bl = blen + (int64_t)t * panels;
-        /* read position of this wavefront: next block, the bucket it lies
-         * in [b0, e0) of panel fpa, and where the next bucket starts */
-        const unsigned tile_end = (unsigned)bp[panels]; /* next tile's start */
-        unsigned fblk = (unsigned)bp[0] + (unsigned)wv * 256u;
-        int fpa = 0, seen = -1; /* seen: last panel a block was taken from */
-        unsigned fe = (unsigned)bp[0] + (unsigned)bl[0];
-        unsigned fnext = (unsigned)bp[1]; /* panels >= 1: bp[1] exists */
-
-        auto fill = [&](flow_chunk<Q> &c) {
-#pragma unroll
-            for (int g = 0; g < Q; ++g) {
-                const bool in_tile = fblk < tile_end;
-                /* leave finished panels behind (arrive), find the block's */
-                while (in_tile && fblk >= fnext) {
-                    if (lane == 0)
-                        wg_arrive(wave_done, q0 + fpa, WAVES,
-                                  cnt + (size_t)(q0 + fpa) * CNT_STRIDE);
-                    ++fpa;
-                    fe = fnext + (unsigned)bl[fpa];
-                    fnext = (unsigned)bp[fpa + 1];
-                }
-                c.pa[g] = in_tile ? fpa : -1;
-                c.first[g] = in_tile && fpa != seen;
-                if (in_tile)
-                    seen = fpa;
-                const unsigned blk = in_tile ? fblk : total; /* tail: zeros */
-                c.live[g] = in_tile ? (int)(fe - blk) - (int)lane : 0;
-                const int qw = q0 + fpa - lag;
-                c.polled[g] = __hip_atomic_load(
-                    cnt + (size_t)(in_tile && lag > 0 && qw >= 0 ? qw : 0) *
-                              CNT_STRIDE,
-                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                c.en[g] = __builtin_nontemporal_load(
-                    (const u32x4 *)(tent + blk + lane * 4u));
-                c.va[g] = __builtin_nontemporal_load(
-                    (const f64x2 *)(tval + blk + lane * 2u));
-                c.vb[g] = __builtin_nontemporal_load(
-                    (const f64x2 *)(tval + blk + 128u + lane * 2u));
-                if (in_tile)
-                    fblk += (unsigned)WAVES * 256u;
-            }
-        };
-
-        auto step = [&](flow_chunk<Q> &c, flow_chunk<Q> &f) {
-            double pr[Q][4], w[Q][4];
-            unsigned rr[Q][4];
-            int on[Q];
-#pragma unroll
-            for (int g = 0; g < Q; ++g) {
-                const int pa = c.pa[g] < 0 ? 0 : c.pa[g];
-                const int qw = q0 + pa - lag;
-                if (c.first[g] && lag > 0 && qw >= 0 && synced &&
-                    __builtin_amdgcn_readfirstlane(c.polled[g]) < n_x)
-                    synced = phase_wait(cnt + (size_t)qw * CNT_STRIDE, n_x, spin);
-                const double *xp = x + ((int64_t)pa << shift);
-                on[g] = c.live[g];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned col = 64 * u < on[g] ? (c.en[g][u] & lowmask) : 0u;
-                    pr[g][u] = xp[col];
-                    rr[g][u] = c.en[g][u] >> shift;
-                }
-                w[g][0] = c.va[g][0];
-                w[g][1] = c.va[g][1];
-                w[g][2] = c.vb[g][0];
-                w[g][3] = c.vb[g][1];
-            }
-            fill(f);
-#pragma unroll
-            for (int g = 0; g < Q; ++g)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (64 * u < on[g])
-                        unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
-        };
-
-        flow_chunk<Q> A, B, C;
-        fill(A);
-        fill(B);
-        for (;;) {
-            if (A.pa[0] < 0)
-                break;
-            step(A, C);
-            if (B.pa[0] < 0)
-                break;
-            step(B, A);
-            if (C.pa[0] < 0)
-                break;
-            step(C, B);
-        }
-        /* panels behind the wavefront's last block: nothing left to read */
-        if (lane == 0)
-            for (int p = fpa; p < panels; ++p)
-                wg_arrive(wave_done, q0 + p, WAVES,
-                          cnt + (size_t)(q0 + p) * CNT_STRIDE);
         __syncthreads();
         const int64_t row0 = (int64_t)t * tile_rows;
         for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
@@ -1310,26 +1139,6 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     } while (0)
         const int abl = (variant >> 8) & 7;
         const int two = !((variant >> 11) & 1); /* 2 groups of 4 per lane */
-        if (!(variant & 8192) && abl == 0) {
-            /* wavefront-granular form (default); bit 13 runs the
-             * workgroup-chunk kernel below for comparison */
-#define FL(NTHR, QQ)                                                           \
-    do {                                                                       \
-        if (int rc_ = allow_big_lds<&k_tiles_flow<NTHR, QQ>>())                \
-            return rc_;                                                        \
-        hipLaunchKernelGGL((k_tiles_flow<NTHR, QQ>), dim3(P->grid),           \
-                           dim3(NTHR), lds, s, M, P->tile_rows, P->tiles,      \
-                           P->panels, P->shift, lag, SWEEP_SPIN_MAX,           \
-                           (unsigned)P->total, P->bptr, P->blen, P->ent,       \
-                           P->val, x, y, P->phase_cnt);                        \
-    } while (0)
-            const bool q1 = (variant & 2048) != 0; /* one block per step */
-            if (waves > 8) { if (q1) FL(1024, 1); else FL(1024, 2); }
-            else if (waves > 0 && waves < 8) { if (q1) FL(256, 1); else FL(256, 2); }
-            else { if (q1) FL(512, 1); else FL(512, 2); }
-#undef FL
-            return hip_errno(hipGetLastError());
-        }
         if (abl == 1) { SW(256, 1, 1); }
         else if (abl == 2) { SW(256, 1, 2); }
         else if (abl == 3) { SW(256, 1, 3); }

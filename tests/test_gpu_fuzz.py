@@ -56,11 +56,6 @@ def test_blocked_path_random_shapes(case, monkeypatch):
             S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
             dA.launch(k, d_x.ptr, d_y.ptr)
             check(("csr", k))
-        for rep in range(3):  # persistent pipelined stream kernel; launched
-            # repeatedly: its range counter must come back to zero by itself
-            S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
-            dA.launch(4, d_x.ptr, d_y.ptr, variant=16)
-            check(("csr stream pipelined", rep))
         for sched in ("chain", "steps", "sweep"):
             S.set_panel_schedule(sched)
             if sched != "sweep":

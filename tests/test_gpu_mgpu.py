@@ -66,18 +66,18 @@ def test_mgpu_handle_can_be_reloaded_and_leaves_the_current_device_alone():
     n = min(S.device_count(), 8)
     dev0 = S._lib.spmv_get_device()
     g = S.MultiGpu(n)
-    free0 = None
+    free = []
     for it in range(10):
         g.generate(S.SYNTH_RANDOM, 320_000, 32, 4096, 42, as_hll=bool(it & 1))
         g.fill_x(7)
         g.spmv(iters=1)
         assert S._lib.spmv_get_device() == dev0
         S.stream_sync()
-        free = S.dev_mem_info()[0]
-        if it == 1:
-            free0 = free
-        if it > 1:  # HLL / CSR alternate: compare like with like, +-64 MB
-            assert abs(free - free0) < (64 << 20) or (it & 1) != 1
+        free.append(S.dev_mem_info()[0])
+    # a shard is 123 MB: leaking one per reload would cost 740 MB between
+    # reloads 3 and 9 (same format: both odd); the allocator's own caching
+    # moves free memory by ~100 MB either way
+    assert free[9] > free[3] - (256 << 20), free
     y = g.get_y(0)
     want, sc = O.synth_row_dot(S.SYNTH_RANDOM, 320_000 * n, 320_000 * n, 32,
                                4096, 0, 42, 7, 12345)
