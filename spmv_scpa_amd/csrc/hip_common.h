@@ -63,6 +63,16 @@ static inline int hip_errno(hipError_t e) {
 
 struct spmv_panels; /* panels.hip */
 
+/* contiguous ranges of a launch's work items, one per XCD, holding about
+ * equal numbers of ENTRIES: workgroup b (dealt round-robin to the XCDs) runs
+ * item first[b % NUM_XCD] + b / NUM_XCD, or nothing when that lies beyond
+ * its XCD's range; the launch has NUM_XCD * (longest range) workgroups.
+ * Neighbouring items share their window of x, so they meet in one L2 --
+ * and no XCD idles when the rows are denser in one part of the matrix. */
+struct xcd_ranges {
+    int first[NUM_XCD + 1];
+};
+
 struct spmv_csr_dev {
     int M, N;
     int64_t NZ;
@@ -75,6 +85,8 @@ struct spmv_csr_dev {
     int *rowblk;
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
+    xcd_ranges rowblk_xcd;      /* stream kernel: ranges of ranges per XCD */
+    int rowblk_xcd_max;
     int max_row_len;
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };

@@ -54,6 +54,7 @@
 #include <atomic>
 #include <hipcub/hipcub.hpp>
 #include <string.h>
+#include <vector>
 
 #include "hip_common.h"
 
@@ -92,6 +93,16 @@ struct spmv_panels {
     int *cpanel;     /* DEVICE [tiles*panels] panel of that bucket */
     int *nbk;        /* DEVICE [tiles] non-empty buckets per tile */
     int max_nbk;     /* launches needed = max over tiles */
+    /* steps / chain: XCD k runs the CONTIGUOUS tile range
+     * [xcd_first[k], xcd_first[k+1]) -- neighbouring tiles share their x
+     * window, so they should meet in one L2 -- and the ranges hold about
+     * equal numbers of ENTRIES, not of tiles: with equal tile counts a
+     * matrix whose rows are dense in one half (the nlpkkt160-shaped KKT
+     * matrix: 42 entries per state row, 15 per constraint row) leaves half
+     * of the XCDs idle while the others finish (0.62 ms; balanced: see
+     * DESIGN.md) */
+    int xcd_first[NUM_XCD + 1];
+    int xcd_max;     /* longest range: the launch has NUM_XCD * xcd_max groups */
     int *phase_cnt;  /* DEVICE sweep: [NUM_XCD][rounds*panels] arrival counters */
     size_t phase_cnt_bytes;
 };
@@ -356,6 +367,56 @@ static long long sweep_tile_rows(int M, int grid, int tile_max) {
     return tr < 32 ? 32 : tr;
 }
 
+/* start slot of every tile (and the end of the last one) */
+__global__ void k_tile_starts(int tiles, int panels,
+                              const int64_t *__restrict__ bptr, int64_t *out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= tiles)
+        out[t] = bptr[(int64_t)t * panels];
+}
+
+/* contiguous tile ranges of about equal entry counts, one per XCD */
+static int balance_xcd_ranges(spmv_panels *P) {
+    int rc = 0;
+    int64_t *d_st = NULL;
+    const int tiles = P->tiles;
+    std::vector<int64_t> st((size_t)tiles + 1, 0);
+    if (tiles > 0) {
+        HIP_TRY(hipMalloc((void **)&d_st, ((size_t)tiles + 1) * sizeof(int64_t)));
+        hipLaunchKernelGGL(k_tile_starts, dim3((tiles + 256) / 256), dim3(256),
+                           0, 0, tiles, P->panels, P->bptr, d_st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(st.data(), d_st, ((size_t)tiles + 1) * sizeof(int64_t),
+                          hipMemcpyDeviceToHost));
+    }
+    {
+        const int64_t total = st[tiles] - st[0];
+        P->xcd_first[0] = 0;
+        for (int k = 1; k < NUM_XCD; ++k) {
+            /* first tile whose start reaches k/8 of the entries; every tile
+             * also counts one slot so that empty tiles spread evenly */
+            const double want = (double)(total + tiles) * k / NUM_XCD;
+            int lo = P->xcd_first[k - 1], hi = tiles;
+            while (lo < hi) {
+                const int mid = lo + (hi - lo) / 2;
+                if ((double)(st[mid] - st[0] + mid) < want)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            P->xcd_first[k] = lo;
+        }
+        P->xcd_first[NUM_XCD] = tiles;
+        P->xcd_max = 0;
+        for (int k = 0; k < NUM_XCD; ++k)
+            if (P->xcd_first[k + 1] - P->xcd_first[k] > P->xcd_max)
+                P->xcd_max = P->xcd_first[k + 1] - P->xcd_first[k];
+    }
+fail:
+    (void)hipFree(d_st);
+    return rc;
+}
+
 static int bits_for(long long n) { /* smallest b with 2^b >= n */
     int b = 0;
     while ((1ll << b) < n)
@@ -573,6 +634,11 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                                P->val);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
+    }
+    if (!sweep) {
+        rc = balance_xcd_ranges(P);
+        if (rc)
+            goto fail;
     }
     if (sweep) {
         const size_t rounds = ((size_t)tiles + P->grid - 1) / P->grid;
@@ -870,6 +936,7 @@ __global__ void __launch_bounds__(NT)
 template <int NT, int Q>
 __global__ void __launch_bounds__(NT)
     k_tiles_step(int M, int tile_rows, int panels, int shift, int step,
+                 xcd_ranges xr,
                  const int64_t *__restrict__ cb, const int *__restrict__ cpanel,
                  const int *__restrict__ nbk, const unsigned *__restrict__ tent,
                  const double *__restrict__ tval, const double *__restrict__ x,
@@ -877,14 +944,12 @@ __global__ void __launch_bounds__(NT)
     extern __shared__ double ytile[];
     constexpr unsigned CH = NT * Q * 4;
     const int tid = threadIdx.x;
-    /* XCD-contiguous tile ranges: the tiles an XCD runs at one time are
-     * neighbours, so their step-th panels coincide or are adjacent */
-    int t;
-    {
-        const int nx = 8, nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk / nx, r = nblk % nx, xx = bid % nx, kk = bid / nx;
-        t = xx * q + (xx < r ? xx : r) + kk;
-    }
+    /* XCD-contiguous tile ranges of equal work (xcd_ranges): the tiles an
+     * XCD runs at one time are neighbours, so their step-th panels coincide
+     * or are adjacent */
+    const int t = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
+    if (t >= xr.first[blockIdx.x % NUM_XCD + 1])
+        return; /* this XCD's range is shorter than the longest one */
     const int64_t row0 = (int64_t)t * tile_rows;
     if (step >= nbk[t]) {
         if (step == 0) /* a tile without entries: its rows are zero */
@@ -983,6 +1048,7 @@ __global__ void __launch_bounds__(NT)
 template <int NT, int Q>
 __global__ void __launch_bounds__(NT)
     k_tiles_chain(int M, int tile_rows, int panels, int shift, unsigned total,
+                  xcd_ranges xr,
                   const int64_t *__restrict__ cb, const int *__restrict__ cpanel,
                   const int *__restrict__ nbk, const unsigned *__restrict__ tent,
                   const double *__restrict__ tval, const double *__restrict__ x,
@@ -990,12 +1056,9 @@ __global__ void __launch_bounds__(NT)
     extern __shared__ double ytile[];
     constexpr unsigned CH = NT * Q * 4;
     const int tid = threadIdx.x;
-    int t;
-    {
-        const int nx = 8, nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk / nx, r = nblk % nx, xx = bid % nx, kk = bid / nx;
-        t = xx * q + (xx < r ? xx : r) + kk;
-    }
+    const int t = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
+    if (t >= xr.first[blockIdx.x % NUM_XCD + 1])
+        return; /* this XCD's range is shorter than the longest one */
     const int64_t row0 = (int64_t)t * tile_rows;
     const int nb = nbk[t];
     const int64_t *tcb = cb + (int64_t)t * panels * 2;
@@ -1166,6 +1229,10 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
 #undef SW
         return hip_errno(hipGetLastError());
     }
+    if (P->tiles <= 0 || P->xcd_max <= 0)
+        return 0;
+    xcd_ranges xr;
+    memcpy(xr.first, P->xcd_first, sizeof xr.first);
     if (P->chain != !!(variant & 1)) { /* variant bit 0 flips the stored mode */
         const double per_bucket_c =
             (double)P->nnz / ((double)P->tiles *
@@ -1173,10 +1240,11 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
 #define CHN(NTHR, QQ)                                                          \
     do {                                                                       \
         if (int rc_ = allow_big_lds<&k_tiles_chain<NTHR, QQ>>()) return rc_;   \
-        hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>), dim3(P->tiles),         \
-                           dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
-                           P->shift, (unsigned)P->total, P->cb, P->cpanel,     \
-                           P->nbk, P->ent, P->val, x, y);                      \
+        hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>),                         \
+                           dim3(NUM_XCD * P->xcd_max), dim3(NTHR), lds, s, M,  \
+                           P->tile_rows, P->panels, P->shift,                  \
+                           (unsigned)P->total, xr, P->cb, P->cpanel, P->nbk,   \
+                           P->ent, P->val, x, y);                              \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
             if (waves > 0 && waves < 8) CHN(256, 2);
@@ -1199,10 +1267,10 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
 #define ST(NTHR, QQ)                                                           \
     do {                                                                       \
         if (int rc_ = allow_big_lds<&k_tiles_step<NTHR, QQ>>()) return rc_;    \
-        hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>), dim3(P->tiles),          \
-                           dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
-                           P->shift, p, P->cb, P->cpanel, P->nbk, P->ent,      \
-                           P->val, x, y);                                      \
+        hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>),                          \
+                           dim3(NUM_XCD * P->xcd_max), dim3(NTHR), lds, s, M,  \
+                           P->tile_rows, P->panels, P->shift, p, xr, P->cb,    \
+                           P->cpanel, P->nbk, P->ent, P->val, x, y);           \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
             if (waves > 0 && waves < 8) ST(256, 2);
