@@ -254,9 +254,8 @@ __device__ __forceinline__ void stream_rows(int tid, int rows, const int *rowptr
         y_range[r] = acc;
 }
 
-template <bool REMAP>
 __global__ void __launch_bounds__(STREAM_THREADS)
-    k_csr_stream(xcd_ranges xr, const int2 *__restrict__ rowblk,
+    k_csr_stream(const int2 *__restrict__ rowblk,
                  const unsigned char *__restrict__ mode,
                  const int *__restrict__ irp, const int *__restrict__ ja,
                  const double *__restrict__ as, const double *__restrict__ x,
@@ -267,12 +266,14 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     __shared__ int rowptr[STREAM_THREADS + 1]; /* this range's slice of IRP */
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
-    int rb = blockIdx.x;
-    if (REMAP) { /* XCD-contiguous runs of equal work (xcd_ranges) */
-        rb = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
-        if (rb >= xr.first[blockIdx.x % NUM_XCD + 1])
-            return;
-    }
+    /* ranges are dealt to the XCDs round-robin (hardware order).  XCD-
+     * contiguous runs of equal work -- what the blocked schedules use -- were
+     * measured SLOWER here (banded 10M x 32: 0.738 vs 0.704 ms, 27-point
+     * stencil 0.621 vs 0.605, 1M x 16: 0.049 vs 0.046): neighbouring ranges
+     * share next to nothing of x, and eight XCDs streaming eight distant
+     * regions of JA/AS suit the HBM channels less than all of them
+     * advancing through one */
+    const int rb = blockIdx.x;
     const int2 t_a = rowblk[rb], t_z = rowblk[rb + 1]; /* (row, entry) */
     const int row_a = t_a.x, row_b = t_z.x;
     const int beg = t_a.y, end = t_z.y;
@@ -472,17 +473,9 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * __syncthreads and with LDS-only barriers alike: vector-memory
          * results return in order, so the gathers wait behind the prefetched
          * stream loads they were meant to overlap. */
-        if (A->n_rowblk <= 0)
-            break;
-        if (remap)
-            hipLaunchKernelGGL(k_csr_stream<true>,
-                               dim3(NUM_XCD * A->rowblk_xcd_max),
-                               dim3(STREAM_THREADS), 0, s, A->rowblk_xcd,
-                               (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
-                               A->ja, A->as, x, y);
-        else /* variant bit 0: the hardware's round-robin order */
-            hipLaunchKernelGGL(k_csr_stream<false>, dim3(A->n_rowblk),
-                               dim3(STREAM_THREADS), 0, s, A->rowblk_xcd,
+        if (A->n_rowblk > 0)
+            hipLaunchKernelGGL(k_csr_stream, dim3(A->n_rowblk),
+                               dim3(STREAM_THREADS), 0, s,
                                (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
                                A->ja, A->as, x, y);
         break;

@@ -370,30 +370,6 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     build_rowblk(host_irp, d->M, tab, mode, &d->max_row_len);
     d->n_rowblk = (int)tab.size() - 1;
     {
-        /* per XCD a contiguous run of ranges with ~1/8 of the entries */
-        const int n = d->n_rowblk;
-        const double total = n > 0 ? (double)host_irp[tab[n]] + n : 0.0;
-        d->rowblk_xcd.first[0] = 0;
-        for (int k = 1; k < NUM_XCD; ++k) {
-            int lo = d->rowblk_xcd.first[k - 1], hi = n;
-            const double want = total * k / NUM_XCD;
-            while (lo < hi) {
-                const int mid = lo + (hi - lo) / 2;
-                if ((double)host_irp[tab[mid]] + mid < want)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            d->rowblk_xcd.first[k] = lo;
-        }
-        d->rowblk_xcd.first[NUM_XCD] = n;
-        d->rowblk_xcd_max = 0;
-        for (int k = 0; k < NUM_XCD; ++k)
-            d->rowblk_xcd_max =
-                std::max(d->rowblk_xcd_max,
-                         d->rowblk_xcd.first[k + 1] - d->rowblk_xcd.first[k]);
-    }
-    {
         /* (first row, first entry) per range: the kernel learns both with one
          * load instead of a load of the row and a dependent load of IRP */
         std::vector<int> tab2(tab.size() * 2);

@@ -85,8 +85,6 @@ struct spmv_csr_dev {
     int *rowblk;
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
-    xcd_ranges rowblk_xcd;      /* stream kernel: ranges of ranges per XCD */
-    int rowblk_xcd_max;
     int max_row_len;
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };

@@ -105,6 +105,74 @@ __global__ void k_vector_walk(const char *__restrict__ buf, size_t bytes, int *s
         *sink = (int)acc;
 }
 
+/*
+ * Does a 4-byte scalar load pull the WHOLE 128-byte line into the XCD's L2?
+ * Every wave owns a private 32 KiB region (256 lines) of a cold buffer:
+ *   mode 0  nothing             (vector read then misses to HBM)
+ *   mode 1  s_load_dword per 128-B line
+ *   mode 2  s_load_dword per 64 B
+ *   mode 3  one vector dword per 128-B line (known to fill the line)
+ * then the wave reads its region with 16 B/lane vector loads and reports the
+ * cycles (s_memtime) that read took.  mode 1 == mode 3 << mode 0 would mean
+ * scalar touches are a usable L2 prefetch.
+ */
+template <int MODE>
+__global__ void k_touch_then_read(const char *__restrict__ buf, size_t region,
+                                  unsigned long long *cycles, int *sink) {
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const char *p = buf + wave * region;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned acc = 0;
+    if (MODE == 1 || MODE == 2) {
+        const int stride = MODE == 1 ? 128 : 64;
+        for (size_t o = 0; o < region; o += 8 * (size_t)stride) {
+            const char *q = p + o;
+            const unsigned a_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)q);
+            const unsigned a_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)q >> 32));
+            const uint64_t a = (uint64_t)a_lo | ((uint64_t)a_hi << 32);
+            unsigned r0, r1, r2, r3, r4, r5, r6, r7;
+            asm volatile("s_load_dword %0, %8, 0x0\n\t"
+                         "s_load_dword %1, %9, 0x0\n\t"
+                         "s_load_dword %2, %10, 0x0\n\t"
+                         "s_load_dword %3, %11, 0x0\n\t"
+                         "s_load_dword %4, %12, 0x0\n\t"
+                         "s_load_dword %5, %13, 0x0\n\t"
+                         "s_load_dword %6, %14, 0x0\n\t"
+                         "s_load_dword %7, %15, 0x0\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4),
+                           "=&s"(r5), "=&s"(r6), "=&s"(r7)
+                         : "s"(a), "s"(a + stride), "s"(a + 2 * (uint64_t)stride),
+                           "s"(a + 3 * (uint64_t)stride), "s"(a + 4 * (uint64_t)stride),
+                           "s"(a + 5 * (uint64_t)stride), "s"(a + 6 * (uint64_t)stride),
+                           "s"(a + 7 * (uint64_t)stride)
+                         : "memory");
+            acc += r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+        }
+    } else if (MODE == 3) {
+        for (size_t o = 0; o < region; o += 64 * 128)
+            acc += *(const unsigned *)(p + o + lane * 128);
+    }
+    /* make sure the touches have landed (and give HBM time in mode 0 too) */
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (size_t o = 0; o < region; o += 4096) {
+        u32x4 a = *(const u32x4 *)(p + o + lane * 16);
+        u32x4 b = *(const u32x4 *)(p + o + 1024 + lane * 16);
+        u32x4 c = *(const u32x4 *)(p + o + 2048 + lane * 16);
+        u32x4 d = *(const u32x4 *)(p + o + 3072 + lane * 16);
+        acc += a[0] ^ b[1] ^ c[2] ^ d[3];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0)
+        cycles[wave] = t1 - t0;
+    if (acc == 0x12345678u)
+        *sink = (int)acc;
+}
+
 template <class F> static double time_ms(F f, int iters) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -160,6 +228,30 @@ int main() {
                        wide ? "s_load_dwordx16" : "s_load_dword", stride, wpc, ms,
                        touched / ms / 1e6, bytes / ms / 1e6);
             }
+    {
+        printf("== scalar touch, then vector read of the same 32 KiB (cycles of the read, "
+               "mean over 2048 waves, cold regions)\n");
+        const size_t region = 32 << 10;
+        const int waves = 2048;
+        unsigned long long *cyc, h[2048];
+        CK(hipMalloc(&cyc, waves * sizeof *cyc));
+        const char *names[4] = {"nothing (HBM)", "s_load_dword / 128 B", "s_load_dword / 64 B",
+                                "vector dword / 128 B"};
+        for (int mode = 0; mode < 4; ++mode) {
+            /* a fresh 64 MiB slice of the 2 GiB buffer per mode, far apart */
+            const char *base = buf + (size_t)(mode + 1) * (256u << 20);
+            if (mode == 0) hipLaunchKernelGGL(k_touch_then_read<0>, dim3(waves / 4), dim3(256), 0, 0, base, region, cyc, sink);
+            if (mode == 1) hipLaunchKernelGGL(k_touch_then_read<1>, dim3(waves / 4), dim3(256), 0, 0, base, region, cyc, sink);
+            if (mode == 2) hipLaunchKernelGGL(k_touch_then_read<2>, dim3(waves / 4), dim3(256), 0, 0, base, region, cyc, sink);
+            if (mode == 3) hipLaunchKernelGGL(k_touch_then_read<3>, dim3(waves / 4), dim3(256), 0, 0, base, region, cyc, sink);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
+            double sum = 0;
+            for (int i = 0; i < waves; ++i) sum += (double)h[i];
+            printf("%-24s : %10.0f cycles per 32 KiB read\n", names[mode], sum / waves);
+        }
+        CK(hipFree(cyc));
+    }
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     printf("done\n");
