@@ -130,9 +130,13 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
     const double m1 = last_m;
     if (!err && t2)
         try_one(0, t2);
-    /* taller still (160 KiB of LDS, one workgroup per CU) when height paid */
+    /* taller still (160 KiB of LDS, one workgroup per CU) when height paid,
+     * shorter still when it cost (nlpkkt160-shaped KKT matrix: 0.525 ms at
+     * 8192 rows, 0.596 at 16384) */
     if (!err && t2 == 16384 && last_m < m1)
         try_one(0, 20448);
+    else if (!err && t2 == 16384 && m1 < last_m)
+        try_one(0, 4096);
     if (err) {
         panels_free(keep);
         *slot = original;
