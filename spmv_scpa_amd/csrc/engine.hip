@@ -333,7 +333,8 @@ __global__ void k_flush(double *buf, size_t n) {
 /* ------------------------------------------------------------------ */
 /* row-block table of the CSR stream kernel (host, O(M))                */
 /* ------------------------------------------------------------------ */
-static void build_rowblk(const int *irp, int M, std::vector<int> &tab,
+static void build_rowblk(const int *irp, int M, int nnz_budget, int row_budget,
+                         std::vector<int> &tab,
                          std::vector<unsigned char> &mode, int *max_len) {
     tab.clear();
     mode.clear();
@@ -343,7 +344,7 @@ static void build_rowblk(const int *irp, int M, std::vector<int> &tab,
         int len = irp[r + 1] - irp[r];
         longest = std::max(longest, len);
         int have = irp[r] - irp[start];
-        bool full = (have + len > STREAM_NNZ) || (r - start >= STREAM_THREADS);
+        bool full = (have + len > nnz_budget) || (r - start >= row_budget);
         if (full && r > start) {
             tab.push_back(r); /* close [start, r) */
             mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
@@ -371,9 +372,13 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
                           hipMemcpyDeviceToHost));
         host_irp = tmp.data();
     }
-    build_rowblk(host_irp, d->M, tab, mode, &d->max_row_len);
-    d->n_rowblk = (int)tab.size() - 1;
-    {
+    /* two tables: workgroup granularity (<= 2048 entries, <= 256 rows) and
+     * wavefront granularity (<= 512 entries, <= 64 rows) */
+    for (int pass = 0; pass < 2; ++pass) {
+        int longest = 0;
+        build_rowblk(host_irp, d->M, pass ? WSTREAM_NNZ : STREAM_NNZ,
+                     pass ? WAVE : STREAM_THREADS, tab, mode, &longest);
+        d->max_row_len = longest;
         /* (first row, first entry) per range: the kernel learns both with one
          * load instead of a load of the row and a dependent load of IRP */
         std::vector<int> tab2(tab.size() * 2);
@@ -381,13 +386,16 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
             tab2[2 * k] = tab[k];
             tab2[2 * k + 1] = host_irp[tab[k]];
         }
-        HIP_TRY(hipMalloc((void **)&d->rowblk, tab2.size() * sizeof(int)));
-        HIP_TRY(hipMemcpy(d->rowblk, tab2.data(), tab2.size() * sizeof(int),
+        int **dtab = pass ? &d->wrowblk : &d->rowblk;
+        unsigned char **dmode = pass ? &d->wrowblk_mode : &d->rowblk_mode;
+        (pass ? d->n_wrowblk : d->n_rowblk) = (int)tab.size() - 1;
+        HIP_TRY(hipMalloc((void **)dtab, tab2.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(*dtab, tab2.data(), tab2.size() * sizeof(int),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)dmode, mode.size()));
+        HIP_TRY(hipMemcpy(*dmode, mode.data(), mode.size(),
                           hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
-    HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
-                      hipMemcpyHostToDevice));
 fail:
     return rc;
 }
@@ -415,6 +423,8 @@ void spmv_csr_release(spmv_csr_dev *d) {
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
     (void)hipFree(d->rowblk_mode);
+    (void)hipFree(d->wrowblk);
+    (void)hipFree(d->wrowblk_mode);
     panels_free(d->panels);
     free(d);
 }
@@ -1113,6 +1123,25 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
         if (rc)
             return rc;
         double m = median_of(ms);
+        if (cand[k] == 4) {
+            /* kernel 4 has two granularities (workgroup / wavefront ranges);
+             * launch variant bit 4 / bit 5 force one, the faster becomes the
+             * handle's default for kernel 4 */
+            spmv_launch_opts o;
+            memset(&o, 0, sizeof o);
+            o.variant = 32; /* workgroup ranges */
+            rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush, ms.data(), NULL);
+            if (rc)
+                return rc;
+            const double mg = median_of(ms);
+            o.variant = 16; /* wavefront ranges */
+            rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush, ms.data(), NULL);
+            if (rc)
+                return rc;
+            const double mw = median_of(ms);
+            A->stream_wave = mw < mg;
+            m = mw < mg ? mw : mg;
+        }
         if (m < bms) {
             bms = m;
             best = cand[k];
