@@ -90,6 +90,13 @@ def parse_args(argv=None):
                     help="initialise RCCL and run the y exchange even with "
                          "one rank (exercises the multi-GPU path on a "
                          "1-GPU box)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend.  nccl (= RCCL) is the "
+                         "product path.  gloo is a REHEARSAL of the multi-rank "
+                         "control flow on a box with fewer GPUs than ranks: "
+                         "ranks share the visible GPUs (rank %% device count) "
+                         "and y fragments are staged through host memory -- "
+                         "its timings mean nothing")
     ap.add_argument("--mtx", default="",
                     help="--config 4: Matrix Market file (default: "
                          "$SPMV_MTX_DIR/nlpkkt160.mtx, else the generated "
@@ -524,6 +531,8 @@ def main():
     if not torch.cuda.is_available() or S.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no GPU visible "
                          "(there is no CPU fallback)")
+    if args.backend == "gloo":  # rehearsal: ranks may share a card
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     S.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -537,7 +546,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     L = args.shards_per_gpu
     if args.strong:
@@ -835,6 +847,10 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
+            "backend": ("gloo REHEARSAL (ranks share GPUs, host-staged "
+                        "exchange: timings are not measurements)"
+                        if args.backend == "gloo" else "nccl (RCCL)")
+            if use_dist else None,
             "workload": workload,
             "kernel": kname,
             "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format

@@ -366,115 +366,6 @@ __global__ void __launch_bounds__(STREAM_THREADS)
 }
 
 /* ------------------------------------------------------------------ */
-/*
- * stream, wavefront-granular: the same idea and the same two LDS forms as
- * k_csr_stream, but a WAVEFRONT owns a range (<= WSTREAM_NNZ entries, <= 64
- * rows; table built at upload) and nothing in the kernel synchronises across
- * wavefronts: no workgroup barrier between the coalesced fetch, the LDS
- * transposition and the row sums, only wave-level ordering.  The four
- * wavefronts of a workgroup run decoupled, like the thread-per-row HLL kernel
- * whose 256-lane launch is the fastest thing measured on 1M x 16 (0.0397 ms
- * vs 0.045 for the workgroup-granular form).
- */
-#define WSTREAM_LDS (WSTREAM_NNZ + WSTREAM_NNZ / 32 + 1)
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__global__ void __launch_bounds__(WSTREAM_WAVES *WAVE)
-    k_csr_stream_wave(int n_ranges, const int2 *__restrict__ rowblk,
-                      const unsigned char *__restrict__ mode,
-                      const int *__restrict__ irp, const int *__restrict__ ja,
-                      const double *__restrict__ as,
-                      const double *__restrict__ x, double *__restrict__ y) {
-    __shared__ double s_val_all[WSTREAM_WAVES][WSTREAM_LDS];
-    __shared__ int s_ja_all[WSTREAM_WAVES][WSTREAM_LDS];
-    __shared__ int rowptr_all[WSTREAM_WAVES][WAVE + 1];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = threadIdx.x / WAVE;
-    const int rb = blockIdx.x * WSTREAM_WAVES + wv; /* wave-uniform */
-    if (rb >= n_ranges)
-        return;
-    double *s_val = s_val_all[wv];
-    int *s_ja = s_ja_all[wv];
-    int *rowptr = rowptr_all[wv];
-    const int2 t_a = rowblk[rb], t_z = rowblk[rb + 1]; /* (row, entry) */
-    const int row_a = t_a.x, rows = t_z.x - t_a.x;
-    const int beg = t_a.y, end = t_z.y;
-    const int cnt = end - beg;
-
-    if (cnt > WSTREAM_NNZ) { /* one long row: the wavefront strides it */
-        double acc = 0.0;
-        for (int k = beg + lane; k < end; k += WAVE)
-            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
-        acc = group_sum<WAVE>(acc);
-        if (lane == 0)
-            y[row_a] = acc;
-        return;
-    }
-    constexpr int E = WSTREAM_NNZ / WAVE;
-    int c[E];
-    double a[E];
-    if (lane < rows) /* at most 64 rows per range */
-        rowptr[lane] = irp[row_a + lane] - beg;
-    if (lane == 0)
-        rowptr[rows] = cnt;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int k = lane + e * WAVE;
-        const bool has = k < cnt;
-        c[e] = has ? ld_stream(ja + beg + k) : -1;
-        a[e] = has ? ld_stream(as + beg + k) : 0.0;
-    }
-    if (mode[rb] == 0) { /* ---- transposed ---- */
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int k = lane + e * WAVE;
-            if (c[e] >= 0) {
-                s_ja[TSKEW(k)] = c[e];
-                s_val[TSKEW(k)] = a[e];
-            }
-        }
-        wave_lds_sync();
-        if (rows * 4 <= WAVE)
-            stream_rows<4>(lane, rows, rowptr, s_ja, s_val, x, y + row_a);
-        else if (rows * 2 <= WAVE)
-            stream_rows<2>(lane, rows, rowptr, s_ja, s_val, x, y + row_a);
-        else
-            stream_rows<1>(lane, rows, rowptr, s_ja, s_val, x, y + row_a);
-        return;
-    }
-    /* ---- cooperative: products in load order, lane team per row ---- */
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (c[e] >= 0)
-            s_val[lane + e * WAVE] = a[e] * x[c[e]];
-    wave_lds_sync();
-    int g = 1;
-    while (g < WAVE && g * rows * 2 <= cnt)
-        g <<= 1;
-    const int sub = lane & (g - 1);
-    const int per_pass = WAVE / g;
-    for (int r = lane / g; r < rows + (per_pass - rows % per_pass) % per_pass;
-         r += per_pass) {
-        double acc = 0.0;
-        const bool live = r < rows;
-        if (live) {
-            const int ra = rowptr[r], rz = rowptr[r + 1];
-            for (int k = ra + sub; k < rz; k += g)
-                acc += s_val[k];
-        }
-        for (int d = g >> 1; d > 0; d >>= 1)
-            acc += __shfl_down(acc, d, WAVE);
-        if (live && sub == 0)
-            y[row_a + r] = acc;
-    }
-}
-
-/* ------------------------------------------------------------------ */
 static int pick_group(const spmv_csr_dev *A, int group) {
     if (group >= 2 && group <= 32 && (group & (group - 1)) == 0)
         return group;
@@ -582,20 +473,12 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * __syncthreads and with LDS-only barriers alike: vector-memory
          * results return in order, so the gathers wait behind the prefetched
          * stream loads they were meant to overlap. */
-        /* two granularities: variant bit 4 forces wavefront ranges, bit 5
-         * workgroup ranges; default = what spmv_csr_autotune measured
-         * faster on this handle (else workgroup ranges) */
-        if (A->n_rowblk <= 0)
-            break;
-        if (((variant & 16) || (A->stream_wave && !(variant & 32))) &&
-            A->n_wrowblk > 0)
-            hipLaunchKernelGGL(
-                k_csr_stream_wave,
-                dim3((A->n_wrowblk + WSTREAM_WAVES - 1) / WSTREAM_WAVES),
-                dim3(WSTREAM_WAVES * WAVE), 0, s, A->n_wrowblk,
-                (const int2 *)A->wrowblk, A->wrowblk_mode, A->irp, A->ja,
-                A->as, x, y);
-        else
+        /* ... and at WAVEFRONT granularity (a wavefront owns <= 512 entries,
+         * four decoupled wavefronts per workgroup, wave-level ordering only,
+         * like the thread-per-row HLL kernel): slower everywhere -- 1M x 16
+         * 0.0454 vs 0.0438 ms, banded 10M x 32 0.766 vs 0.725, 27-point
+         * stencil 0.687 vs 0.608, random W = 2048 0.865 vs 0.798. */
+        if (A->n_rowblk > 0)
             hipLaunchKernelGGL(k_csr_stream, dim3(A->n_rowblk),
                                dim3(STREAM_THREADS), 0, s,
                                (const int2 *)A->rowblk, A->rowblk_mode, A->irp,

@@ -372,13 +372,10 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
                           hipMemcpyDeviceToHost));
         host_irp = tmp.data();
     }
-    /* two tables: workgroup granularity (<= 2048 entries, <= 256 rows) and
-     * wavefront granularity (<= 512 entries, <= 64 rows) */
-    for (int pass = 0; pass < 2; ++pass) {
-        int longest = 0;
-        build_rowblk(host_irp, d->M, pass ? WSTREAM_NNZ : STREAM_NNZ,
-                     pass ? WAVE : STREAM_THREADS, tab, mode, &longest);
-        d->max_row_len = longest;
+    build_rowblk(host_irp, d->M, STREAM_NNZ, STREAM_THREADS, tab, mode,
+                 &d->max_row_len);
+    d->n_rowblk = (int)tab.size() - 1;
+    {
         /* (first row, first entry) per range: the kernel learns both with one
          * load instead of a load of the row and a dependent load of IRP */
         std::vector<int> tab2(tab.size() * 2);
@@ -386,16 +383,13 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
             tab2[2 * k] = tab[k];
             tab2[2 * k + 1] = host_irp[tab[k]];
         }
-        int **dtab = pass ? &d->wrowblk : &d->rowblk;
-        unsigned char **dmode = pass ? &d->wrowblk_mode : &d->rowblk_mode;
-        (pass ? d->n_wrowblk : d->n_rowblk) = (int)tab.size() - 1;
-        HIP_TRY(hipMalloc((void **)dtab, tab2.size() * sizeof(int)));
-        HIP_TRY(hipMemcpy(*dtab, tab2.data(), tab2.size() * sizeof(int),
-                          hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)dmode, mode.size()));
-        HIP_TRY(hipMemcpy(*dmode, mode.data(), mode.size(),
+        HIP_TRY(hipMalloc((void **)&d->rowblk, tab2.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(d->rowblk, tab2.data(), tab2.size() * sizeof(int),
                           hipMemcpyHostToDevice));
     }
+    HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
+    HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
+                      hipMemcpyHostToDevice));
 fail:
     return rc;
 }
@@ -423,8 +417,6 @@ void spmv_csr_release(spmv_csr_dev *d) {
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
     (void)hipFree(d->rowblk_mode);
-    (void)hipFree(d->wrowblk);
-    (void)hipFree(d->wrowblk_mode);
     panels_free(d->panels);
     free(d);
 }
@@ -1123,25 +1115,6 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
         if (rc)
             return rc;
         double m = median_of(ms);
-        if (cand[k] == 4) {
-            /* kernel 4 has two granularities (workgroup / wavefront ranges);
-             * launch variant bit 4 / bit 5 force one, the faster becomes the
-             * handle's default for kernel 4 */
-            spmv_launch_opts o;
-            memset(&o, 0, sizeof o);
-            o.variant = 32; /* workgroup ranges */
-            rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush, ms.data(), NULL);
-            if (rc)
-                return rc;
-            const double mg = median_of(ms);
-            o.variant = 16; /* wavefront ranges */
-            rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush, ms.data(), NULL);
-            if (rc)
-                return rc;
-            const double mw = median_of(ms);
-            A->stream_wave = mw < mg;
-            m = mw < mg ? mw : mg;
-        }
         if (m < bms) {
             bms = m;
             best = cand[k];

@@ -60,11 +60,6 @@ static inline int hip_errno(hipError_t e) {
 #define STREAM_THREADS 256
 /* ranges whose longest row is at most this use the transposed form */
 #define STREAM_ROW_T 48
-/* wave-granular form of the stream kernel: a WAVEFRONT owns consecutive rows
- * holding <= WSTREAM_NNZ entries (and at most 64 rows); 4 independent
- * wavefronts per workgroup */
-#define WSTREAM_NNZ 512
-#define WSTREAM_WAVES 4
 
 struct spmv_panels; /* panels.hip */
 
@@ -90,10 +85,6 @@ struct spmv_csr_dev {
     int *rowblk;
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
-    int *wrowblk;               /* the same table at wavefront granularity */
-    int n_wrowblk;
-    unsigned char *wrowblk_mode;
-    int stream_wave;            /* tuned hint: kernel 4 runs wave-granular */
     int max_row_len;
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };

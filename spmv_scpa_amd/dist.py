@@ -95,6 +95,35 @@ def agree_on_pick(dist, mine, device=None, group=None):
     return Pick(k, _SCHED_NAME[sc], tr)
 
 
+class _Done:
+    """a collective that has already completed (rehearsal path)"""
+
+    def wait(self):
+        return True
+
+
+def all_gather_fragments(dist, out, mine, group=None):
+    """in-place all-gather of equally sized fragments, asynchronous.
+
+    Product path: RCCL (`nccl` backend), one ncclAllGather on the
+    communicator's stream.  REHEARSAL path (`gloo` backend with tensors on a
+    GPU -- several ranks sharing the one card of a test box, where RCCL
+    refuses duplicate devices): gloo has no GPU all-gather, so the fragment is
+    staged through host memory, synchronously.  Slow by construction; it
+    exists so that every line of the multi-rank control flow (pick agreement,
+    arrangement selection, logical shards, cross-rank result check) can run
+    before a real node does."""
+    if dist.get_backend(group) == "gloo" and mine.is_cuda:
+        import torch
+        torch.cuda.current_stream().synchronize()
+        host = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(host, mine.cpu().contiguous().view(-1),
+                                    group=group)
+        out.view(-1).copy_(host)
+        return _Done()
+    return dist.all_gather_into_tensor(out, mine, group=group, async_op=True)
+
+
 class ShardExchange:
     """Exchange of equally sized y fragments between `world` ranks.
 
@@ -118,9 +147,8 @@ class ShardExchange:
         if self.world == 1 and not force:
             return None
         if self.mode == "allgather":
-            return self.dist.all_gather_into_tensor(self.y, self.mine,
-                                                    group=self.group,
-                                                    async_op=True)
+            return all_gather_fragments(self.dist, self.y, self.mine,
+                                        self.group)
         return self.send_chunk(0, self.rows)
 
     def send_chunk(self, a, b):
@@ -170,9 +198,8 @@ class StagedExchange:
         return self.stage[c, self.rank]
 
     def gather(self, c):
-        return self.dist.all_gather_into_tensor(
-            self.stage[c].view(-1), self.stage[c, self.rank],
-            group=self.group, async_op=True)
+        return all_gather_fragments(self.dist, self.stage[c].view(-1),
+                                    self.stage[c, self.rank], self.group)
 
     def finish(self):
         """stage[c][r][:] -> y[r*rows + c*ch : ...] (row order)"""

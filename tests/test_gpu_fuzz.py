@@ -56,9 +56,6 @@ def test_blocked_path_random_shapes(case, monkeypatch):
             S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
             dA.launch(k, d_x.ptr, d_y.ptr)
             check(("csr", k))
-        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
-        dA.launch(4, d_x.ptr, d_y.ptr, variant=16)  # wavefront-granular form
-        check(("csr stream, wavefront ranges",))
         for sched in ("chain", "steps", "sweep"):
             S.set_panel_schedule(sched)
             if sched != "sweep":
