@@ -1,0 +1,65 @@
+"""The N > 1 control flow of bench.py EXECUTED on a 1-GPU box: two ranks
+share the card (`--backend gloo`: RCCL refuses duplicate devices, so the y
+fragments are staged through host memory by dist.all_gather_fragments).  The
+timings of such a run mean nothing; what it proves is that every line the
+driver's 2 / 4 / 8-GPU scaling run will execute has run once: rank 0's pick
+broadcast and rebuilt by the other rank, the measured choice between the two
+exchange arrangements of the sweep schedule, logical shards, the fixed
+80M-style problem of `config.strong`, the cross-rank result check (each rank
+verifies rows the OTHER rank computed), nnz summed over ranks.  It also runs
+two persistent sweep launches on one GPU at the same time -- their grids
+cannot both be resident, the phase waits must expire and the kernels still
+finish (bounded waits: slower, never hung)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import spmv_scpa_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [
+    # blocked path, sweep schedule: both exchange arrangements are built and
+    # timed, the faster kept; config.strong = 4 logical shards per rank
+    ["--kernel", "4", "--window", "0"],
+    # autotuned pick on a banded matrix (direct kernel): row chunks, staged
+    ["--kernel", "-1", "--window", "4096"],
+    # ragged rows: nnz differs between ranks and is summed, every family's
+    # rows are checked through the host generator
+    ["--kernel", "-1", "--family", "ragged", "--window", "4096"],
+])
+def test_two_ranks_share_one_gpu(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", os.path.join(S.ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--rows-per-gpu", "320000", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd + extra, capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    c = j["config"]
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert c["backend"].startswith("gloo REHEARSAL")
+    assert j["rows_checked"] >= 258 + 3  # own rows + the other rank's
+    assert c["rows_per_gpu"] == 320000
+    if "ragged" in extra:
+        assert c["nnz_global"] != 2 * 320000 * 32  # summed, not assumed equal
+    else:
+        assert c["nnz_global"] == 2 * 320000 * 32
+    if extra[:2] == ["--kernel", "4"]:
+        arr = c["exchange_arrangement"]
+        assert "exchange after the kernel" in arr and "overlapped" in arr
+        assert c["logical_shards_per_gpu"] in (1, 2)
+        st = c["strong"]
+        assert "error" not in st, st
+        assert st["ms_per_step"] > 0 and st["speedup_vs_1gpu"] > 0
+        assert "4 logical shards" in st["problem"]
+    else:
+        assert c["exchange"] in ("staged", "allgather")
