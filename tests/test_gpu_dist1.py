@@ -65,3 +65,30 @@ def test_bench_through_torchrun_one_rank(extra):
         assert j["config"]["exchange"] == ("staged" if L == 2 else "allgather")
         assert arr.endswith("-> overlapped" if L == 2
                             else "-> exchange after the kernel")
+
+
+@pytest.mark.parametrize("args,kernel_prefix", [
+    (["--config", "4", "--kkt-n", "24", "--steps", "3", "--warmup", "1"], "csr_"),
+    (["--config", "2", "--steps", "5", "--warmup", "1"], "csr_"),
+])
+def test_bench_lines_of_the_other_configs(args, kernel_prefix, tmp_path):
+    """`bench.py --config 4` (generated nlpkkt160-shaped .mtx, here on a 24^3
+    grid, through io_load_csr_cached) and `--config 2` (1M banded CSR,
+    flushed) print the same kind of line as the headline."""
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(S.ROOT, "bench.py"),
+                        "--no-cpu-baseline"] + args, capture_output=True,
+                       text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["dtype"] == "f64"
+    assert j["config"]["kernel"].startswith(kernel_prefix)
+    assert j["rows_checked"] == 258
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-3
+    assert set(j["extras"]) == {"csr_wave_row", "csr_subwave_row", "csr_stream"}
+    if "--kkt-n" in args:
+        assert "24^3 grid" in j["config"]["workload"]
+        assert j["config"]["loaded_from"].startswith(".mtx text")
+        assert j["config"]["nnz"] == 734664  # gen_kkt_mtx 24: after mirroring

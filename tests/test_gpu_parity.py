@@ -672,3 +672,46 @@ def test_stream_kernel_on_long_empty_and_ragged_rows():
     assert np.array_equal(d_y.to_numpy(np.float64, M), ys[0])
     dA.release()
     S.csr_free(A)
+
+
+def test_config3_ragged_variant_full_size():
+    """SURVEY 8d, secondary variant of config 3: row lengths uniform in
+    [24, 40] (mean 32) so that the HLL form carries pads (S > nnz).  10M x 10M,
+    columns anywhere, generated and converted on the device; the thread-per-
+    row HLL kernels, the CSR stream kernel and the autotuned pick against
+    20k rows regenerated by the oracle."""
+    M = N = 10_000_000
+    K, W = 32, 1 << 30
+    dA = S.CsrDevice.generate(S.SYNTH_RAGGED, M, N, K, W, 0, 42)
+    dH = dA.to_hll(True)
+    assert dH.slots > dA.NZ  # pads are stored (and are real traffic)
+    assert dH.algorithmic_bytes > 12 * dA.NZ
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    rng = np.random.default_rng(6)
+    rows = np.unique(np.concatenate([[0, 31, 32, M - 1],
+                                     rng.integers(0, M, 20_000)]))
+    want = np.array([O.synth_row_dot(S.SYNTH_RAGGED, M, N, K, W, 0, 42, 7,
+                                     int(g)) for g in rows])
+    best, _ = dH.autotune(d_x.ptr, d_y.ptr)
+    if best == S.HLL_KERNEL_PANELS:  # the copy drops the pads, only them
+        assert dH.panels_info()["entries"] == dA.NZ
+    ys = {}
+    for tag, fn in (("hll1", lambda: dH.launch(1, d_x.ptr, d_y.ptr)),
+                    ("hll2", lambda: dH.launch(2, d_x.ptr, d_y.ptr)),
+                    ("csr4", lambda: dA.launch(4, d_x.ptr, d_y.ptr)),
+                    ("auto", lambda: dH.launch(best, d_x.ptr, d_y.ptr))):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        fn()
+        S.stream_sync()
+        y = d_y.to_numpy(np.float64, M)
+        assert np.all(np.isfinite(y)), tag
+        got = y[rows]
+        assert np.max(np.abs(got - want[:, 0]) / want[:, 1]) <= TIGHT, tag
+        den = np.maximum(np.abs(want[:, 0]), 1e-3 * want[:, 1])
+        assert np.max(np.abs(got - want[:, 0]) / den) <= REL_TOL, tag
+        ys[tag] = y
+    assert np.max(np.abs(ys["hll1"] - ys["csr4"])) < 1e-11
+    assert np.max(np.abs(ys["hll1"] - ys["auto"])) < 1e-11
+    dH.release()
+    dA.release()
