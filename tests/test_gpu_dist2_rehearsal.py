@@ -31,6 +31,8 @@ pytestmark = pytest.mark.gpu
     # ragged rows: nnz differs between ranks and is summed, every family's
     # rows are checked through the host generator
     ["--kernel", "-1", "--family", "ragged", "--window", "4096"],
+    # the fixed-problem form as the main line: 8 logical shards, 4 per rank
+    ["--strong", "--kernel", "4", "--window", "0"],
 ])
 def test_two_ranks_share_one_gpu(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -45,10 +47,16 @@ def test_two_ranks_share_one_gpu(extra):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     c = j["config"]
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    strong = "--strong" in extra
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    assert j["scaling"] == ("strong" if strong else "weak")
     assert c["backend"].startswith("gloo REHEARSAL")
     assert j["rows_checked"] >= 258 + 3  # own rows + the other rank's
-    assert c["rows_per_gpu"] == 320000
+    assert c["rows_per_gpu"] == 320000 * (4 if strong else 1)
+    if strong:
+        assert c["logical_shards_per_gpu"] == 4 and c["strong"] is None
+        assert c["nnz_global"] == 8 * 320000 * 32 and c["exchange"] == "staged"
+        return
     if "ragged" in extra:
         assert c["nnz_global"] != 2 * 320000 * 32  # summed, not assumed equal
     else:
