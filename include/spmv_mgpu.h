@@ -7,7 +7,13 @@
  * the same with one process per GPU through torch.distributed.)
  *
  * All functions return 0 or a negative errno (-ENODEV: fewer GPUs than
- * asked for).
+ * asked for).  Every entry point restores the caller's current HIP device; a
+ * handle may be loaded / generated again (the previous shards are freed).
+ *
+ * STATUS: UNMEASURED with more than one device -- the boxes this was built
+ * on have one GPU (tests run it with n = 1 and through `-g 1`); the grouped
+ * all-gather, its error handling and the n > 1 timings have not run on
+ * hardware yet.
  */
 #ifndef SPMV_MGPU_H
 #define SPMV_MGPU_H
