@@ -794,6 +794,25 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
     d->nb = nb;
     d->col_major = col_major ? 1 : 0;
     d->slots = host_off[nb];
+    /* per XCD a contiguous run of hack blocks holding about 1/8 of the slots
+     * (each block also counts 32 slots, so empty blocks spread evenly) */
+    d->xcd_blk.first[0] = 0;
+    for (int k = 1; k < NUM_XCD; ++k) {
+        const double want =
+            ((double)host_off[nb] + 32.0 * nb) * k / NUM_XCD;
+        int lo = d->xcd_blk.first[k - 1], hi = nb;
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if ((double)host_off[mid] + 32.0 * mid < want)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        d->xcd_blk.first[k] = (lo + 1) & ~1; /* block pairs stay together */
+        if (d->xcd_blk.first[k] > nb)
+            d->xcd_blk.first[k] = nb;
+    }
+    d->xcd_blk.first[NUM_XCD] = nb;
     HIP_TRY(hipGetDevice(&d->device));
     /* +64 slots of slack: vector loads of the last chunk stay in bounds */
     HIP_TRY(hipMalloc((void **)&d->ja, ((size_t)d->slots + 64) * sizeof(int)));

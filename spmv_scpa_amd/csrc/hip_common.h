@@ -100,6 +100,8 @@ struct spmv_hll_dev {
     int *ja;       /* [S] pads already rewritten */
     double *as;    /* [S] */
     int64_t *off;  /* [nb+1] slot offset of each block */
+    xcd_ranges xcd_blk; /* hack-block ranges per XCD holding ~1/8 of the SLOTS
+                           each (even boundaries: a wavefront owns a pair) */
     unsigned *padmask; /* [(S+31)/32] bit t set: slot t was a pad (JA == -1)
                           before the rewrite; read only when the blocked copy
                           is built */

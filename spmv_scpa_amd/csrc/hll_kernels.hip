@@ -108,26 +108,36 @@ __global__ void k_hll_row_major(int M, int b0, int b1,
 /*    in flight the JA/AS loads of [j+U, j+2U) are already issued, so    */
 /*    the stream never waits behind a gather round trip.                 */
 /* ------------------------------------------------------------------ */
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    /* workgroups are dealt round-robin over the 8 XCDs; give each XCD a
-     * contiguous range of the grid so neighbouring row tiles (which share
-     * their x window) meet in the same L2.  Bijective for any nblk. */
-    const int nx = 8;
-    int q = nblk / nx, r = nblk % nx;
-    int x = bid % nx, k = bid / nx;
-    return x * q + (x < r ? x : r) + k;
-}
-
+/*
+ * Workgroup -> hack blocks.  REMAP: workgroups are dealt round-robin over the
+ * 8 XCDs; XCD k runs the CONTIGUOUS block range [xr.first[k], xr.first[k+1])
+ * so that neighbouring row tiles (which share their x window) meet in one L2
+ * (+18 % on a band of 2048 columns), and the ranges hold about equal numbers
+ * of SLOTS, not of blocks: a matrix whose rows are wider in one half
+ * otherwise leaves XCDs idle (the finding of round 2 on the blocked path,
+ * DESIGN.md section 4).  The launch has 8 x (longest range) workgroups; the
+ * surplus ones of shorter ranges exit.
+ */
 template <int U, bool REMAP, int ABL = 0> /* ABL 1: all gathers read x[0] */
-__global__ void k_hll_col_direct(int M, int b0, int b1,
+__global__ void k_hll_col_direct(int M, int b0, int b1, xcd_ranges xr,
                                  const int64_t *__restrict__ off,
                                  const int *__restrict__ ja,
                                  const double *__restrict__ as,
                                  const double *__restrict__ x,
                                  double *__restrict__ y) {
-    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    long long t = (long long)bid * blockDim.x + threadIdx.x;
-    int b = b0 + (int)(t / HACK), i = (int)(t % HACK);
+    int b, i;
+    if (REMAP) {
+        const int xx = blockIdx.x % NUM_XCD, kk = blockIdx.x / NUM_XCD;
+        const long long t = (long long)kk * blockDim.x + threadIdx.x;
+        b = xr.first[xx] + (int)(t / HACK);
+        i = (int)(t % HACK);
+        if (b >= xr.first[xx + 1])
+            return;
+    } else {
+        const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        b = b0 + (int)(t / HACK);
+        i = (int)(t % HACK);
+    }
     if (b >= b1)
         return;
     int rows = min(HACK, M - b * HACK);
@@ -208,7 +218,8 @@ __device__ __forceinline__ void hll_chunk_load(hll_chunk &c, int s0, int lane,
 }
 
 template <bool REMAP>
-__global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
+__global__ void k_hll_col_lds(int b0, int b1, xcd_ranges xr,
+                              const int64_t *__restrict__ off,
                               const int *__restrict__ ja,
                               const double *__restrict__ as,
                               const double *__restrict__ x,
@@ -222,8 +233,15 @@ __global__ void k_hll_col_lds(int b0, int b1, const int64_t *__restrict__ off,
     int *s_ja = (int *)((double *)lds_raw + (size_t)waves * 2 * CH_SLOTS) +
                 (size_t)wave * 2 * CH_SLOTS;
 
-    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int bA = b0 + 2 * (bid * waves + wave); /* wave-uniform */
+    int bA; /* wave-uniform */
+    if (REMAP) {
+        const int xx = blockIdx.x % NUM_XCD, kk = blockIdx.x / NUM_XCD;
+        bA = xr.first[xx] + 2 * (kk * waves + wave);
+        if (xr.first[xx + 1] < b1)
+            b1 = xr.first[xx + 1]; /* the pair stays inside the XCD's range */
+    } else {
+        bA = b0 + 2 * ((int)blockIdx.x * waves + wave);
+    }
     if (bA >= b1)
         return;
     const bool hasB = bA + 1 < b1;
@@ -328,6 +346,18 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         return 0;
     const int threads = waves * WAVE;
     const long long lanes = (long long)(b1 - b0) * HACK;
+    /* XCD ranges of this launch: the handle's slot-balanced table for the
+     * whole matrix, an even split for a block sub-range (multi-GPU chunks) */
+    xcd_ranges xr = H->xcd_blk;
+    if (b0 != 0 || b1 != H->nb)
+        for (int k = 0; k <= NUM_XCD; ++k) {
+            long long c = b0 + ((long long)(b1 - b0) * k / NUM_XCD + 1) / 2 * 2;
+            xr.first[k] = k == NUM_XCD || c > b1 ? b1 : (int)c;
+        }
+    int xmax = 0; /* longest range, in blocks */
+    for (int k = 0; k < NUM_XCD; ++k)
+        xmax = xr.first[k + 1] - xr.first[k] > xmax
+                   ? xr.first[k + 1] - xr.first[k] : xmax;
     switch (kernel) {
     case 0:
         hipLaunchKernelGGL(k_hll_row_major,
@@ -345,53 +375,54 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
             size_t lds = (size_t)waves * 2 * CH_SLOTS * (sizeof(double) + sizeof(int));
             if (remap)
                 hipLaunchKernelGGL(k_hll_col_lds<true>,
-                                   dim3((pairs + waves - 1) / waves),
-                                   dim3(threads), lds, s, b0, full_end, H->off,
-                                   H->ja, H->as, x, y);
+                                   dim3(NUM_XCD * (((xmax + 1) / 2 + waves - 1) /
+                                                   waves)),
+                                   dim3(threads), lds, s, b0, full_end, xr,
+                                   H->off, H->ja, H->as, x, y);
             else
                 hipLaunchKernelGGL(k_hll_col_lds<false>,
                                    dim3((pairs + waves - 1) / waves),
-                                   dim3(threads), lds, s, b0, full_end, H->off,
-                                   H->ja, H->as, x, y);
+                                   dim3(threads), lds, s, b0, full_end, xr,
+                                   H->off, H->ja, H->as, x, y);
         }
         if (full_end < b1)
             hipLaunchKernelGGL((k_hll_col_direct<8, false>), dim3(1), dim3(WAVE), 0, s,
-                               H->M, full_end, b1, H->off, H->ja, H->as, x, y);
+                               H->M, full_end, b1, xr, H->off, H->ja, H->as, x, y);
         break;
     }
-    case 2:
+    case 2: {
+        /* REMAP grid: 8 x (workgroups of the longest XCD range) */
+        const unsigned xgrid =
+            NUM_XCD * (unsigned)(((long long)xmax * HACK + threads - 1) / threads);
         if (variant & 32) { /* tuning: 4 columns per pipeline stage */
-            hipLaunchKernelGGL((k_hll_col_direct<4, true>),
-                               dim3((unsigned)((lanes + threads - 1) / threads)),
-                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+            hipLaunchKernelGGL((k_hll_col_direct<4, true>), dim3(xgrid),
+                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (variant & 64) { /* tuning: 16 columns per pipeline stage */
-            hipLaunchKernelGGL((k_hll_col_direct<16, true>),
-                               dim3((unsigned)((lanes + threads - 1) / threads)),
-                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+            hipLaunchKernelGGL((k_hll_col_direct<16, true>), dim3(xgrid),
+                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (variant & 16) {
-            hipLaunchKernelGGL((k_hll_col_direct<8, true, 1>),
-                               dim3((unsigned)((lanes + threads - 1) / threads)),
-                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+            hipLaunchKernelGGL((k_hll_col_direct<8, true, 1>), dim3(xgrid),
+                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (remap)
-            hipLaunchKernelGGL((k_hll_col_direct<8, true>),
-                               dim3((unsigned)((lanes + threads - 1) / threads)),
-                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+            hipLaunchKernelGGL((k_hll_col_direct<8, true>), dim3(xgrid),
+                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
         else
             hipLaunchKernelGGL((k_hll_col_direct<8, false>),
                                dim3((unsigned)((lanes + threads - 1) / threads)),
-                               dim3(threads), 0, s, H->M, b0, b1, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
         break;
+    }
     case 3:
         hipLaunchKernelGGL(
             k_hll_subwave_row,
