@@ -41,9 +41,13 @@ extern "C" {
 typedef struct spmv_launch_opts {
     int waves_per_block; /* 1..16; 0 = process default (set_*_waves_per_block) */
     int group;           /* lanes per row of the sub-wave kernels; 0 = auto */
-    int variant;         /* tuning bit-field, 0 = default; bit 0: keep the
-                            hardware's round-robin workgroup->XCD order
-                            instead of the XCD-contiguous remap */
+    int variant;         /* tuning bit-field, 0 = default; bit 0: hardware
+                            (round-robin) workgroup->XCD order, bit 1: XCD-
+                            contiguous ranges of equal work; neither: the
+                            handle's order (what spmv_*_autotune measured
+                            faster; before tuning: hardware order for HLL,
+                            contiguous for the CSR sub-wave kernel and the
+                            blocked chain / steps schedules) */
     int reserved[5];     /* must be 0 */
 } spmv_launch_opts;
 
@@ -107,7 +111,14 @@ typedef struct spmv_panel_opts {
                              the previous shard) runs beside it; 0: none */
     int lds_min;          /* launch with at least this many bytes of dynamic
                              LDS (caps workgroups per CU); 0: the tile */
-    int reserved[2];      /* must be 0 */
+    int tile_order;       /* steps / chain: 0 = XCD-contiguous tile ranges of
+                             equal work (neighbouring tiles share an L2: wins
+                             when rows reach over many tiles' columns), 1 =
+                             hardware order (tile = workgroup index: wins by
+                             3-8 % on narrow bands, where all XCDs then stream
+                             through one region of the matrix).
+                             spmv_*_autotune measures both */
+    int reserved[1];      /* must be 0 */
 } spmv_panel_opts;
 
 /* ---- CSR handle ---- */

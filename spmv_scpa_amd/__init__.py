@@ -95,7 +95,7 @@ class PanelOpts(C.Structure):
     _fields_ = [("sched", C.c_int), ("panel_cols", C.c_int),
                 ("tile_rows", C.c_int), ("sweep_wgs_per_cu", C.c_int),
                 ("reserve_cus", C.c_int), ("lds_min", C.c_int),
-                ("reserved", C.c_int * 2)]
+                ("tile_order", C.c_int), ("reserved", C.c_int * 1)]
 
 
 _CSRp = C.POINTER(SparseCSR)

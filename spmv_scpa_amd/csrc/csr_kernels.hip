@@ -416,11 +416,13 @@ static void launch_subwave(int passes, int r0, int r1, int threads, bool remap,
 int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                       int variant, const double *x, double *y, int r0, int r1,
                       hipStream_t s) {
-    const bool remap = !(variant & 1);
     const int passes = (variant & 4) ? 4 : (variant & 8) ? 2 : 8;
     (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
         return -EINVAL;
+    /* variant bit 0: hardware order, bit 1: XCD ranges, else the handle's */
+    const bool remap = (variant & 1) ? false : (variant & 2) ? true
+                                                            : !A->hw_order;
     if (r0 == r1)
         return 0;
     const int threads = waves * WAVE;

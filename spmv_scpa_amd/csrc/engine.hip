@@ -89,6 +89,20 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
         }
         panels_set_waves(cand, best_waves);
         panels_set_chain(cand, best_chain);
+        if (!err && sched == 0) {
+            /* the best launch mode once more with the tiles in hardware order
+             * (narrow bands: +3..8 %; wide windows: the XCD-contiguous ranges
+             * win by up to 2x) */
+            panels_set_hw_order(cand, 1);
+            double m = 0.0;
+            rc = time_it(&m);
+            if (rc)
+                err = rc;
+            else if (m < 0.98 * best_m)
+                best_m = m;
+            else
+                panels_set_hw_order(cand, 0);
+        }
         *slot = original;
         last_m = err ? 1e300 : best_m;
         /* a later blocked candidate has to beat the kept one by 3 %: two
@@ -794,6 +808,7 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
     d->nb = nb;
     d->col_major = col_major ? 1 : 0;
     d->slots = host_off[nb];
+    d->hw_order = 1;
     /* per XCD a contiguous run of hack blocks holding about 1/8 of the slots
      * (each block also counts 32 slots, so empty blocks spread evenly) */
     d->xcd_blk.first[0] = 0;
@@ -1081,17 +1096,26 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
     double bms = 1e300;
     std::vector<double> ms(5);
     const size_t flush = tune_flush_bytes(spmv_hll_algorithmic_bytes(H));
-    for (int k = 0; k < 2; ++k) {
-        int rc = spmv_hll_time(H, cand[k], NULL, d_x, d_y, 1, 5, flush,
-                               ms.data(), NULL);
-        if (rc)
-            return rc;
-        double m = median_of(ms);
-        if (m < bms) {
-            bms = m;
-            best = cand[k];
+    int best_hw = H->hw_order;
+    for (int k = 0; k < 2; ++k)
+        for (int hw = 1; hw >= 0; --hw) { /* both workgroup orders */
+            if (!H->col_major && hw == 0)
+                continue; /* the row-major kernels have one order */
+            spmv_launch_opts o;
+            memset(&o, 0, sizeof o);
+            o.variant = hw ? 1 : 2;
+            int rc = spmv_hll_time(H, cand[k], &o, d_x, d_y, 1, 5, flush,
+                                   ms.data(), NULL);
+            if (rc)
+                return rc;
+            double m = median_of(ms);
+            if (m < bms) {
+                bms = m;
+                best = cand[k];
+                best_hw = hw;
+            }
         }
-    }
+    H->hw_order = best_hw;
     if (allow_panels) {
         const double stream_ms =
             (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
@@ -1126,14 +1150,32 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
     double bms = 1e300;
     std::vector<double> ms(5);
     const size_t flush = tune_flush_bytes(spmv_csr_algorithmic_bytes(A));
+    A->hw_order = 0;
     for (int k = 0; k < 3; ++k) {
         if (cand[k] == 1 && A->M > 0 && (double)A->NZ / A->M < 48.0)
             continue; /* a wavefront per row wastes lanes on short rows */
-        int rc = spmv_csr_time(A, cand[k], NULL, d_x, d_y, 1, 5, flush,
-                               ms.data(), NULL);
-        if (rc)
-            return rc;
-        double m = median_of(ms);
+        double m;
+        if (cand[k] == 2) { /* the sub-wave kernel in both workgroup orders */
+            double mo[2];
+            for (int hw = 0; hw < 2; ++hw) {
+                spmv_launch_opts o;
+                memset(&o, 0, sizeof o);
+                o.variant = hw ? 1 : 2;
+                int rc = spmv_csr_time(A, 2, &o, d_x, d_y, 1, 5, flush,
+                                       ms.data(), NULL);
+                if (rc)
+                    return rc;
+                mo[hw] = median_of(ms);
+            }
+            A->hw_order = mo[1] < 0.98 * mo[0];
+            m = A->hw_order ? mo[1] : mo[0];
+        } else {
+            int rc = spmv_csr_time(A, cand[k], NULL, d_x, d_y, 1, 5, flush,
+                                   ms.data(), NULL);
+            if (rc)
+                return rc;
+            m = median_of(ms);
+        }
         if (m < bms) {
             bms = m;
             best = cand[k];

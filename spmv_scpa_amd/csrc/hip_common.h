@@ -86,6 +86,8 @@ struct spmv_csr_dev {
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
     int max_row_len;
+    int hw_order; /* sub-wave kernel: 1 = hardware workgroup order measured
+                     faster than XCD-contiguous ranges (spmv_csr_autotune) */
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };
 
@@ -100,6 +102,11 @@ struct spmv_hll_dev {
     int *ja;       /* [S] pads already rewritten */
     double *as;    /* [S] */
     int64_t *off;  /* [nb+1] slot offset of each block */
+    int hw_order; /* kernels 1 / 2: 1 = hardware workgroup order (default:
+                     eight XCDs advancing through ONE region of the slabs
+                     measured 3-8 % faster on banded matrices than eight
+                     contiguous regions), 0 = the XCD ranges below
+                     (spmv_hll_autotune measures both) */
     xcd_ranges xcd_blk; /* hack-block ranges per XCD holding ~1/8 of the SLOTS
                            each (even boundaries: a wavefront owns a pair) */
     unsigned *padmask; /* [(S+31)/32] bit t set: slot t was a pad (JA == -1)
@@ -142,6 +149,7 @@ int panels_tile_rows(const spmv_panels *P);
 int panels_is_chain(const spmv_panels *P);
 void panels_set_chain(spmv_panels *P, int chain);
 void panels_set_waves(spmv_panels *P, int waves);
+void panels_set_hw_order(spmv_panels *P, int hw);
 int panels_waves(const spmv_panels *P);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s);

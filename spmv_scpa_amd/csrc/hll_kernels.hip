@@ -336,7 +336,6 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1,
 int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
                       int variant, const double *x, double *y, int b0, int b1,
                       hipStream_t s) {
-    const bool remap = !(variant & 1);
     (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     if (!H || !x || !y || b0 < 0 || b1 > H->nb || b0 > b1)
         return -EINVAL;
@@ -344,6 +343,9 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         return -EINVAL; /* layout of the handle does not fit the kernel */
     if (b0 == b1)
         return 0;
+    /* variant bit 0: hardware order, bit 1: XCD ranges, else the handle's */
+    const bool remap = (variant & 1) ? false : (variant & 2) ? true
+                                                            : !H->hw_order;
     const int threads = waves * WAVE;
     const long long lanes = (long long)(b1 - b0) * HACK;
     /* XCD ranges of this launch: the handle's slot-balanced table for the

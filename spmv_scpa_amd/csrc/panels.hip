@@ -103,6 +103,8 @@ struct spmv_panels {
      * DESIGN.md) */
     int xcd_first[NUM_XCD + 1];
     int xcd_max;     /* longest range: the launch has NUM_XCD * xcd_max groups */
+    int hw_order;    /* steps / chain: tile = workgroup index instead
+                        (spmv_panel_opts.tile_order; set by the selector) */
     int *phase_cnt;  /* DEVICE sweep: [NUM_XCD][rounds*panels] arrival counters */
     size_t phase_cnt_bytes;
 };
@@ -433,13 +435,13 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, {0, 0}};
+    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, 0, {0}};
     if (!o)
         o = &dflt;
     if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
-        o->reserved[0] || o->reserved[1])
+        o->tile_order < 0 || o->tile_order > 1 || o->reserved[0])
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
     int sched = o->sched;
@@ -514,6 +516,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P->wgs_per_cu = per_cu;
     P->reserve_cus = sweep ? o->reserve_cus : 0;
     P->lds_min = o->lds_min;
+    P->hw_order = sweep ? 0 : o->tile_order;
     uint64_t *key[2] = {NULL, NULL};
     unsigned *idx[2] = {NULL, NULL};
     uint64_t *skey = NULL;
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(NT)
 template <int NT, int Q>
 __global__ void __launch_bounds__(NT)
     k_tiles_step(int M, int tile_rows, int panels, int shift, int step,
-                 xcd_ranges xr,
+                 int tiles_hw, xcd_ranges xr,
                  const int64_t *__restrict__ cb, const int *__restrict__ cpanel,
                  const int *__restrict__ nbk, const unsigned *__restrict__ tent,
                  const double *__restrict__ tval, const double *__restrict__ x,
@@ -947,8 +950,11 @@ __global__ void __launch_bounds__(NT)
     /* XCD-contiguous tile ranges of equal work (xcd_ranges): the tiles an
      * XCD runs at one time are neighbours, so their step-th panels coincide
      * or are adjacent */
-    const int t = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
-    if (t >= xr.first[blockIdx.x % NUM_XCD + 1])
+    /* tiles_hw > 0: hardware order instead (tile = workgroup index) */
+    const int t = tiles_hw > 0 ? (int)blockIdx.x
+                               : xr.first[blockIdx.x % NUM_XCD] +
+                                     (int)(blockIdx.x / NUM_XCD);
+    if (t >= (tiles_hw > 0 ? tiles_hw : xr.first[blockIdx.x % NUM_XCD + 1]))
         return; /* this XCD's range is shorter than the longest one */
     const int64_t row0 = (int64_t)t * tile_rows;
     if (step >= nbk[t]) {
@@ -1048,7 +1054,7 @@ __global__ void __launch_bounds__(NT)
 template <int NT, int Q>
 __global__ void __launch_bounds__(NT)
     k_tiles_chain(int M, int tile_rows, int panels, int shift, unsigned total,
-                  xcd_ranges xr,
+                  int tiles_hw, xcd_ranges xr,
                   const int64_t *__restrict__ cb, const int *__restrict__ cpanel,
                   const int *__restrict__ nbk, const unsigned *__restrict__ tent,
                   const double *__restrict__ tval, const double *__restrict__ x,
@@ -1056,8 +1062,11 @@ __global__ void __launch_bounds__(NT)
     extern __shared__ double ytile[];
     constexpr unsigned CH = NT * Q * 4;
     const int tid = threadIdx.x;
-    const int t = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
-    if (t >= xr.first[blockIdx.x % NUM_XCD + 1])
+    /* tiles_hw > 0: hardware order instead (tile = workgroup index) */
+    const int t = tiles_hw > 0 ? (int)blockIdx.x
+                               : xr.first[blockIdx.x % NUM_XCD] +
+                                     (int)(blockIdx.x / NUM_XCD);
+    if (t >= (tiles_hw > 0 ? tiles_hw : xr.first[blockIdx.x % NUM_XCD + 1]))
         return; /* this XCD's range is shorter than the longest one */
     const int64_t row0 = (int64_t)t * tile_rows;
     const int nb = nbk[t];
@@ -1233,6 +1242,10 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         return 0;
     xcd_ranges xr;
     memcpy(xr.first, P->xcd_first, sizeof xr.first);
+    /* variant bit 1: tiles in hardware order, bit 2: the XCD-contiguous
+     * work-balanced ranges, neither: what the copy was built / tuned with */
+    const bool hw = (variant & 2) ? true : (variant & 4) ? false
+                                                         : P->hw_order != 0;
     if (P->chain != !!(variant & 1)) { /* variant bit 0 flips the stored mode */
         const double per_bucket_c =
             (double)P->nnz / ((double)P->tiles *
@@ -1241,10 +1254,11 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     do {                                                                       \
         if (int rc_ = allow_big_lds<&k_tiles_chain<NTHR, QQ>>()) return rc_;   \
         hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>),                         \
-                           dim3(NUM_XCD * P->xcd_max), dim3(NTHR), lds, s, M,  \
-                           P->tile_rows, P->panels, P->shift,                  \
-                           (unsigned)P->total, xr, P->cb, P->cpanel, P->nbk,   \
-                           P->ent, P->val, x, y);                              \
+                           dim3(hw ? P->tiles : NUM_XCD * P->xcd_max),         \
+                           dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
+                           P->shift, (unsigned)P->total, hw ? P->tiles : 0,    \
+                           xr, P->cb, P->cpanel, P->nbk, P->ent, P->val, x,    \
+                           y);                                                 \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
             if (waves > 0 && waves < 8) CHN(256, 2);
@@ -1268,8 +1282,9 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     do {                                                                       \
         if (int rc_ = allow_big_lds<&k_tiles_step<NTHR, QQ>>()) return rc_;    \
         hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>),                          \
-                           dim3(NUM_XCD * P->xcd_max), dim3(NTHR), lds, s, M,  \
-                           P->tile_rows, P->panels, P->shift, p, xr, P->cb,    \
+                           dim3(hw ? P->tiles : NUM_XCD * P->xcd_max),         \
+                           dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
+                           P->shift, p, hw ? P->tiles : 0, xr, P->cb,          \
                            P->cpanel, P->nbk, P->ent, P->val, x, y);           \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
@@ -1306,13 +1321,13 @@ int panels_from_hll_opts(const spmv_hll_dev *H, const spmv_panel_opts *o,
 
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, {0, 0}};
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, {0}};
     return panels_from_csr_opts(A, &o, out);
 }
 
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, {0, 0}};
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, {0}};
     return panels_from_hll_opts(H, &o, out);
 }
 
@@ -1325,6 +1340,7 @@ void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     o->sweep_wgs_per_cu = P->sweep ? P->wgs_per_cu : 0;
     o->reserve_cus = P->reserve_cus;
     o->lds_min = P->lds_min;
+    o->tile_order = P->hw_order;
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }
@@ -1334,6 +1350,10 @@ void panels_set_chain(spmv_panels *P, int chain) {
         P->chain = chain != 0;
 }
 int panels_waves(const spmv_panels *P) { return P ? P->waves_hint : 0; }
+void panels_set_hw_order(spmv_panels *P, int hw) {
+    if (P && !P->sweep)
+        P->hw_order = hw != 0;
+}
 void panels_set_waves(spmv_panels *P, int waves) {
     if (P)
         P->waves_hint = waves > 0 ? waves : 0;

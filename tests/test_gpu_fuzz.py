@@ -56,6 +56,17 @@ def test_blocked_path_random_shapes(case, monkeypatch):
             S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
             dA.launch(k, d_x.ptr, d_y.ptr)
             check(("csr", k))
+        # both workgroup orders of the direct kernels (variant bit 0: hardware
+        # order, bit 1: XCD-contiguous ranges of equal work)
+        for k, variant in ((2, 1), (2, 2)):
+            S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+            dA.launch(k, d_x.ptr, d_y.ptr, variant=variant)
+            check(("csr", k, "variant", variant))
+        for k in (1, 2):
+            for variant in (0, 1, 2):
+                S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                dH.launch(k, d_x.ptr, d_y.ptr, variant=variant)
+                check(("hll", k, "variant", variant))
         for sched in ("chain", "steps", "sweep"):
             S.set_panel_schedule(sched)
             if sched != "sweep":
