@@ -46,8 +46,9 @@ typedef struct spmv_launch_opts {
                             contiguous ranges of equal work; neither: the
                             handle's order (what spmv_*_autotune measured
                             faster; before tuning: hardware order for HLL,
-                            contiguous for the CSR sub-wave kernel and the
-                            blocked chain / steps schedules) */
+                            contiguous for the CSR sub-wave kernel; the
+                            blocked chain / steps schedules have three orders,
+                            spmv_panel_opts.tile_order) */
     int reserved[5];     /* must be 0 */
 } spmv_launch_opts;
 
@@ -111,13 +112,13 @@ typedef struct spmv_panel_opts {
                              the previous shard) runs beside it; 0: none */
     int lds_min;          /* launch with at least this many bytes of dynamic
                              LDS (caps workgroups per CU); 0: the tile */
-    int tile_order;       /* steps / chain: 0 = XCD-contiguous tile ranges of
-                             equal work (neighbouring tiles share an L2: wins
-                             when rows reach over many tiles' columns), 1 =
-                             hardware order (tile = workgroup index: wins by
-                             3-8 % on narrow bands, where all XCDs then stream
-                             through one region of the matrix).
-                             spmv_*_autotune measures both */
+    int tile_order;       /* steps / chain, which tile a workgroup runs:
+                             0 = grouped (default: groups of 32 consecutive
+                             tiles per XCD, groups dealt round-robin --
+                             neighbours share an L2 and the chip advances
+                             through one region), 1 = hardware order (tile =
+                             workgroup index), 2 = XCD-contiguous ranges of
+                             equal work.  spmv_*_autotune measures all three */
     int reserved[1];      /* must be 0 */
 } spmv_panel_opts;
 

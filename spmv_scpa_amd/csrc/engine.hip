@@ -90,18 +90,21 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
         panels_set_waves(cand, best_waves);
         panels_set_chain(cand, best_chain);
         if (!err && sched == 0) {
-            /* the best launch mode once more with the tiles in hardware order
-             * (narrow bands: +3..8 %; wide windows: the XCD-contiguous ranges
-             * win by up to 2x) */
-            panels_set_hw_order(cand, 1);
-            double m = 0.0;
-            rc = time_it(&m);
-            if (rc)
-                err = rc;
-            else if (m < 0.98 * best_m)
-                best_m = m;
-            else
-                panels_set_hw_order(cand, 0);
+            /* the best launch mode in the other two tile orders (the copy is
+             * built with order 0, grouped); another order has to win by 2 % */
+            int best_order = 0;
+            for (int order = 1; order <= 2 && !err; ++order) {
+                panels_set_order(cand, order);
+                double m = 0.0;
+                rc = time_it(&m);
+                if (rc)
+                    err = rc;
+                else if (m < 0.98 * best_m) {
+                    best_m = m;
+                    best_order = order;
+                }
+            }
+            panels_set_order(cand, best_order);
         }
         *slot = original;
         last_m = err ? 1e300 : best_m;

@@ -149,7 +149,7 @@ int panels_tile_rows(const spmv_panels *P);
 int panels_is_chain(const spmv_panels *P);
 void panels_set_chain(spmv_panels *P, int chain);
 void panels_set_waves(spmv_panels *P, int waves);
-void panels_set_hw_order(spmv_panels *P, int hw);
+void panels_set_order(spmv_panels *P, int order);
 int panels_waves(const spmv_panels *P);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s);

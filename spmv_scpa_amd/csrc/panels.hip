@@ -103,8 +103,9 @@ struct spmv_panels {
      * DESIGN.md) */
     int xcd_first[NUM_XCD + 1];
     int xcd_max;     /* longest range: the launch has NUM_XCD * xcd_max groups */
-    int hw_order;    /* steps / chain: tile = workgroup index instead
-                        (spmv_panel_opts.tile_order; set by the selector) */
+    int order;       /* steps / chain, which tile a workgroup runs
+                        (spmv_panel_opts.tile_order; the selector measures):
+                        0 grouped, 1 hardware order, 2 XCD-contiguous ranges */
     int *phase_cnt;  /* DEVICE sweep: [NUM_XCD][rounds*panels] arrival counters */
     size_t phase_cnt_bytes;
 };
@@ -441,7 +442,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
-        o->tile_order < 0 || o->tile_order > 1 || o->reserved[0])
+        o->tile_order < 0 || o->tile_order > 2 || o->reserved[0])
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
     int sched = o->sched;
@@ -516,7 +517,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P->wgs_per_cu = per_cu;
     P->reserve_cus = sweep ? o->reserve_cus : 0;
     P->lds_min = o->lds_min;
-    P->hw_order = sweep ? 0 : o->tile_order;
+    P->order = sweep ? 0 : o->tile_order;
     uint64_t *key[2] = {NULL, NULL};
     unsigned *idx[2] = {NULL, NULL};
     uint64_t *skey = NULL;
@@ -950,12 +951,24 @@ __global__ void __launch_bounds__(NT)
     /* XCD-contiguous tile ranges of equal work (xcd_ranges): the tiles an
      * XCD runs at one time are neighbours, so their step-th panels coincide
      * or are adjacent */
-    /* tiles_hw > 0: hardware order instead (tile = workgroup index) */
-    const int t = tiles_hw > 0 ? (int)blockIdx.x
-                               : xr.first[blockIdx.x % NUM_XCD] +
-                                     (int)(blockIdx.x / NUM_XCD);
-    if (t >= (tiles_hw > 0 ? tiles_hw : xr.first[blockIdx.x % NUM_XCD + 1]))
-        return; /* this XCD's range is shorter than the longest one */
+    /* tiles_hw > 0: hardware order (tile = workgroup index); < 0: groups of
+     * G = -tiles_hw >> 24 consecutive tiles per XCD, the groups dealt to the
+     * XCDs round-robin (tiles = -tiles_hw & 0xffffff): neighbouring tiles
+     * share an L2 AND the chip as a whole advances through one region */
+    int t, t_end;
+    if (tiles_hw > 0) {
+        t = (int)blockIdx.x;
+        t_end = tiles_hw;
+    } else if (tiles_hw < 0) {
+        const int G = (-tiles_hw) >> 24, k = blockIdx.x / NUM_XCD;
+        t = ((k / G) * NUM_XCD + (int)(blockIdx.x % NUM_XCD)) * G + k % G;
+        t_end = (-tiles_hw) & 0xffffff;
+    } else {
+        t = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
+        t_end = xr.first[blockIdx.x % NUM_XCD + 1];
+    }
+    if (t >= t_end)
+        return; /* beyond the tiles / this XCD's range */
     const int64_t row0 = (int64_t)t * tile_rows;
     if (step >= nbk[t]) {
         if (step == 0) /* a tile without entries: its rows are zero */
@@ -1062,12 +1075,24 @@ __global__ void __launch_bounds__(NT)
     extern __shared__ double ytile[];
     constexpr unsigned CH = NT * Q * 4;
     const int tid = threadIdx.x;
-    /* tiles_hw > 0: hardware order instead (tile = workgroup index) */
-    const int t = tiles_hw > 0 ? (int)blockIdx.x
-                               : xr.first[blockIdx.x % NUM_XCD] +
-                                     (int)(blockIdx.x / NUM_XCD);
-    if (t >= (tiles_hw > 0 ? tiles_hw : xr.first[blockIdx.x % NUM_XCD + 1]))
-        return; /* this XCD's range is shorter than the longest one */
+    /* tiles_hw > 0: hardware order (tile = workgroup index); < 0: groups of
+     * G = -tiles_hw >> 24 consecutive tiles per XCD, the groups dealt to the
+     * XCDs round-robin (tiles = -tiles_hw & 0xffffff): neighbouring tiles
+     * share an L2 AND the chip as a whole advances through one region */
+    int t, t_end;
+    if (tiles_hw > 0) {
+        t = (int)blockIdx.x;
+        t_end = tiles_hw;
+    } else if (tiles_hw < 0) {
+        const int G = (-tiles_hw) >> 24, k = blockIdx.x / NUM_XCD;
+        t = ((k / G) * NUM_XCD + (int)(blockIdx.x % NUM_XCD)) * G + k % G;
+        t_end = (-tiles_hw) & 0xffffff;
+    } else {
+        t = xr.first[blockIdx.x % NUM_XCD] + (int)(blockIdx.x / NUM_XCD);
+        t_end = xr.first[blockIdx.x % NUM_XCD + 1];
+    }
+    if (t >= t_end)
+        return; /* beyond the tiles / this XCD's range */
     const int64_t row0 = (int64_t)t * tile_rows;
     const int nb = nbk[t];
     const int64_t *tcb = cb + (int64_t)t * panels * 2;
@@ -1242,10 +1267,34 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         return 0;
     xcd_ranges xr;
     memcpy(xr.first, P->xcd_first, sizeof xr.first);
-    /* variant bit 1: tiles in hardware order, bit 2: the XCD-contiguous
-     * work-balanced ranges, neither: what the copy was built / tuned with */
-    const bool hw = (variant & 2) ? true : (variant & 4) ? false
-                                                         : P->hw_order != 0;
+    /* Which tile a workgroup runs (workgroups are dealt to the XCDs
+     * round-robin).  0 GROUPED (default): groups of 32 consecutive tiles --
+     * one per CU of an XCD -- per XCD, the groups dealt round-robin, so
+     * neighbouring tiles share an L2 AND the eight XCDs together advance
+     * through one region of the matrix (and through rows of any density
+     * together: no XCD idles on a matrix that is denser in one half).
+     * 1 HARDWARE order: tile = workgroup index.  2 XCD-CONTIGUOUS ranges of
+     * equal work.  Measured (round 2, tile 8192 unless noted; ms):
+     *                      grouped  hardware  contiguous
+     *   banded 10M x 32     0.615     0.619     0.642
+     *   random W = 2^11     0.646     0.642     0.665
+     *   random W = 2^17     0.672     0.755     0.654
+     *   random W = 2^20     0.925     1.686     0.922   (20448 rows: 0.79 / 1.12 / 0.78)
+     *   27-point stencil    0.473     0.485     0.499
+     *   skewed rows 8.3M    0.171     0.176     0.174
+     * variant bit 1 forces hardware order, bit 2 the contiguous ranges,
+     * bits 14-15 a group size of 32 / 64 / 16 (experiments). */
+    const int gsel = (variant >> 14) & 3;
+    int ord = gsel ? 0 : (variant & 2) ? 1 : (variant & 4) ? 2 : P->order;
+    if (ord == 0 && P->tiles >= (1 << 24))
+        ord = 2; /* the packed (group, tiles) argument holds 24 bits of tiles */
+    const int G = gsel == 2 ? 64 : gsel == 3 ? 16 : 32; /* < 128: 7 bits */
+    const int order_arg = ord == 0 ? -((G << 24) | P->tiles)
+                          : ord == 1 ? P->tiles : 0;
+    const unsigned order_grid =
+        ord == 0 ? (unsigned)((P->tiles + NUM_XCD * G - 1) / (NUM_XCD * G)) *
+                       NUM_XCD * G
+        : ord == 1 ? (unsigned)P->tiles : (unsigned)(NUM_XCD * P->xcd_max);
     if (P->chain != !!(variant & 1)) { /* variant bit 0 flips the stored mode */
         const double per_bucket_c =
             (double)P->nnz / ((double)P->tiles *
@@ -1254,9 +1303,9 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     do {                                                                       \
         if (int rc_ = allow_big_lds<&k_tiles_chain<NTHR, QQ>>()) return rc_;   \
         hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>),                         \
-                           dim3(hw ? P->tiles : NUM_XCD * P->xcd_max),         \
+                           dim3(order_grid),                                   \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
-                           P->shift, (unsigned)P->total, hw ? P->tiles : 0,    \
+                           P->shift, (unsigned)P->total, order_arg,            \
                            xr, P->cb, P->cpanel, P->nbk, P->ent, P->val, x,    \
                            y);                                                 \
     } while (0)
@@ -1282,9 +1331,9 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     do {                                                                       \
         if (int rc_ = allow_big_lds<&k_tiles_step<NTHR, QQ>>()) return rc_;    \
         hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>),                          \
-                           dim3(hw ? P->tiles : NUM_XCD * P->xcd_max),         \
+                           dim3(order_grid),                                   \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
-                           P->shift, p, hw ? P->tiles : 0, xr, P->cb,          \
+                           P->shift, p, order_arg, xr, P->cb,                  \
                            P->cpanel, P->nbk, P->ent, P->val, x, y);           \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
@@ -1340,7 +1389,7 @@ void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     o->sweep_wgs_per_cu = P->sweep ? P->wgs_per_cu : 0;
     o->reserve_cus = P->reserve_cus;
     o->lds_min = P->lds_min;
-    o->tile_order = P->hw_order;
+    o->tile_order = P->order;
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }
@@ -1350,9 +1399,9 @@ void panels_set_chain(spmv_panels *P, int chain) {
         P->chain = chain != 0;
 }
 int panels_waves(const spmv_panels *P) { return P ? P->waves_hint : 0; }
-void panels_set_hw_order(spmv_panels *P, int hw) {
-    if (P && !P->sweep)
-        P->hw_order = hw != 0;
+void panels_set_order(spmv_panels *P, int order) {
+    if (P && !P->sweep && order >= 0 && order <= 2)
+        P->order = order;
 }
 void panels_set_waves(spmv_panels *P, int waves) {
     if (P)

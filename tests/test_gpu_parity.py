@@ -395,8 +395,10 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
     for variant, waves in (((0, 8), (0, 4), (16, 8), (128, 4), (2048, 8))
                            if sweep else
                            # bit 1: tiles in hardware order, bit 2: XCD ranges
+                           # bits 14-15: group size of the grouped order
                            ((0, 8), (0, 4), (1, 0), (1, 16), (2048, 8), (2, 8),
-                            (4, 0), (3, 4))):
+                            (4, 0), (3, 4), (16384, 8), (32768 + 1, 4),
+                            (49152, 0))):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         for _ in range(2):  # repeated launches must not accumulate
             dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant,
