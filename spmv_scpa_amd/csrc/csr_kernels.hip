@@ -254,6 +254,16 @@ __device__ __forceinline__ void stream_rows(int tid, int rows, const int *rowptr
         y_range[r] = acc;
 }
 
+typedef int s_v4i __attribute__((ext_vector_type(4)));
+typedef double s_v2d __attribute__((ext_vector_type(2)));
+
+/* WIDE: ranges in transposed mode fetch JA / AS with 16-byte loads from the
+ * 16-byte boundary below the range's first entry (a wavefront instruction
+ * covers 1 KiB of whole lines: 6 load instructions per lane instead of 16);
+ * the LDS transposition absorbs the shift and the fact that a lane's JA and
+ * AS elements are different entries.  The device arrays carry 2056 entries
+ * of slack so the last range may read past NZ. */
+template <bool WIDE>
 __global__ void __launch_bounds__(STREAM_THREADS)
     k_csr_stream(const int2 *__restrict__ rowblk,
                  const unsigned char *__restrict__ mode,
@@ -298,6 +308,49 @@ __global__ void __launch_bounds__(STREAM_THREADS)
         return;
     }
 
+    const int md = mode[rb];
+    if (WIDE && md == 0 && cnt + (beg & 3) <= STREAM_NNZ) {
+        const int d = beg & 3; /* entries between the 16-B boundary and beg */
+        const int *ja_al = ja + (beg - d);
+        const double *as_al = as + (beg - d);
+        s_v4i cj[2];
+        s_v2d ca[4];
+        if (tid < rows)
+            rowptr[tid] = irp[row_a + tid] - beg;
+        if (tid == 0)
+            rowptr[rows] = cnt;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            cj[i] = ld_stream((const s_v4i *)(ja_al + (i * STREAM_THREADS + tid) * 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ca[i] = ld_stream((const s_v2d *)(as_al + (i * STREAM_THREADS + tid) * 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (i * STREAM_THREADS + tid) * 4 + j - d;
+                if (k >= 0 && k < cnt)
+                    s_ja[TSKEW(k)] = cj[i][j];
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = (i * STREAM_THREADS + tid) * 2 + j - d;
+                if (k >= 0 && k < cnt)
+                    s_val[TSKEW(k)] = ca[i][j];
+            }
+        __syncthreads();
+        if (rows * 4 <= STREAM_THREADS)
+            stream_rows<4>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
+        else if (rows * 2 <= STREAM_THREADS)
+            stream_rows<2>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
+        else
+            stream_rows<1>(tid, rows, rowptr, s_ja, s_val, x, y + row_a);
+        return;
+    }
+
     /* coalesced fetch of the range's entries (all loads of a lane issued
      * together) and of its row offsets */
     constexpr int E = STREAM_NNZ / STREAM_THREADS;
@@ -315,7 +368,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
         a[e] = has ? ld_stream(as + beg + k) : 0.0;
     }
 
-    if (mode[rb] == 0) { /* ---- transposed ---- */
+    if (md == 0) { /* ---- transposed ---- */
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int k = tid + e * STREAM_THREADS;
@@ -480,8 +533,15 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * like the thread-per-row HLL kernel): slower everywhere -- 1M x 16
          * 0.0454 vs 0.0438 ms, banded 10M x 32 0.766 vs 0.725, 27-point
          * stencil 0.687 vs 0.608, random W = 2048 0.865 vs 0.798. */
-        if (A->n_rowblk > 0)
-            hipLaunchKernelGGL(k_csr_stream, dim3(A->n_rowblk),
+        if (A->n_rowblk <= 0)
+            break;
+        if (variant & 16) /* tuning: 4- / 8-byte loads only */
+            hipLaunchKernelGGL(k_csr_stream<false>, dim3(A->n_rowblk),
+                               dim3(STREAM_THREADS), 0, s,
+                               (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
+                               A->ja, A->as, x, y);
+        else
+            hipLaunchKernelGGL(k_csr_stream<true>, dim3(A->n_rowblk),
                                dim3(STREAM_THREADS), 0, s,
                                (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
                                A->ja, A->as, x, y);

@@ -448,8 +448,10 @@ static int csr_alloc_dev(int M, int N, int64_t NZ, spmv_csr_dev **out) {
     d->NZ = NZ;
     HIP_TRY(hipGetDevice(&d->device));
     HIP_TRY(hipMalloc((void **)&d->irp, ((size_t)M + 1) * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&d->ja, std::max<size_t>(NZ, 4) * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&d->as, std::max<size_t>(NZ, 2) * sizeof(double)));
+    /* + slack: the stream kernel's 16-byte loads of the last range may read
+     * up to 2048 + 3 entries past NZ (never used) */
+    HIP_TRY(hipMalloc((void **)&d->ja, ((size_t)NZ + 2056) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->as, ((size_t)NZ + 2056) * sizeof(double)));
     *out = d;
     return 0;
 fail:
