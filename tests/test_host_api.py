@@ -455,3 +455,35 @@ def test_corrupt_sidecar_never_reaches_the_kernels(tmp_path, what):
     B = S.csr_load_bin(b)
     assert np.array_equal(S.csr_arrays(B)[1], J)
     S.csr_free(B)
+
+
+def test_fast_decimal_path_is_bit_identical_to_the_reference_scanf(tmp_path):
+    """The parallel tokeniser converts plain decimals itself (Clinger's fast
+    path: <= 15 significant digits over 10^k, one correctly rounded division)
+    and leaves everything else to strtod.  Every kind of token, cycled over a
+    file big enough for the parallel path, against the oracle's fscanf
+    restatement bit for bit."""
+    toks = ["0.1", "-0.3", "123456789012345", "0.000123", "1.000",
+            "999999999999999", "0.30000000000000004", "5.", "+.5", "-0.0",
+            "00012.5000", "1e-3", "-2.5E+2", "0.1234567890123456",
+            "1234567890123456", "0.0000000000000000000001",
+            "0.00000000000000000000001", "3", "-7", "0x1.8p1", "inf"]
+    M = N = 400
+    n = 120_000
+    rng = np.random.default_rng(3)
+    i = rng.integers(1, M + 1, n)
+    j = rng.integers(1, N + 1, n)
+    p = str(tmp_path / "tok.mtx")
+    with open(p, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n"
+                % (M, N, n))
+        f.write("".join("%d %d %s\n" % (a, b, toks[k % len(toks)])
+                        for k, (a, b) in enumerate(zip(i, j))))
+    rc, oM, oN, oNZ, IRP, JA, AS = O.load_mtx(p)
+    assert rc == 0 and oNZ == n
+    A = S.io_load_csr(p)
+    gI, gJ, gA = S.csr_arrays(A)
+    assert np.array_equal(gI, IRP) and np.array_equal(gJ, JA)
+    assert np.array_equal(bits(gA), bits(AS))
+    assert np.isinf(gA).any() and (gA == 0.1).any() and (gA == 3.0).any()
+    S.csr_free(A)
