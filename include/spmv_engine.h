@@ -41,14 +41,16 @@ extern "C" {
 typedef struct spmv_launch_opts {
     int waves_per_block; /* 1..16; 0 = process default (set_*_waves_per_block) */
     int group;           /* lanes per row of the sub-wave kernels; 0 = auto */
-    int variant;         /* tuning bit-field, 0 = default; bit 0: hardware
-                            (round-robin) workgroup->XCD order, bit 1: XCD-
-                            contiguous ranges of equal work; neither: the
+    int variant;         /* tuning bit-field, 0 = default.  Workgroup -> XCD
+                            order of the direct kernels: bit 0 hardware
+                            (round-robin) order, bit 1 XCD-contiguous ranges
+                            of equal work, bit 2 (HLL kernels 1 / 2) grouped
+                            runs of 32 workgroups per XCD; none of them: the
                             handle's order (what spmv_*_autotune measured
                             faster; before tuning: hardware order for HLL,
-                            contiguous for the CSR sub-wave kernel; the
-                            blocked chain / steps schedules have three orders,
-                            spmv_panel_opts.tile_order) */
+                            contiguous for the CSR sub-wave kernel).  The
+                            blocked schedules read their own bits
+                            (panels.hip) and spmv_panel_opts.tile_order */
     int reserved[5];     /* must be 0 */
 } spmv_launch_opts;
 

@@ -102,11 +102,13 @@ struct spmv_hll_dev {
     int *ja;       /* [S] pads already rewritten */
     double *as;    /* [S] */
     int64_t *off;  /* [nb+1] slot offset of each block */
-    int hw_order; /* kernels 1 / 2: 1 = hardware workgroup order (default:
-                     eight XCDs advancing through ONE region of the slabs
-                     measured 3-8 % faster on banded matrices than eight
-                     contiguous regions), 0 = the XCD ranges below
-                     (spmv_hll_autotune measures both) */
+    int order; /* kernels 1 / 2, which blocks a workgroup runs: 0 = hardware
+                  order (eight XCDs advancing through ONE region of the
+                  slabs: 3-8 % faster on banded matrices than eight contiguous
+                  regions), 1 = the XCD ranges below, 2 = grouped (runs of 32
+                  workgroups per XCD, runs round-robin: region locality AND
+                  neighbours in one L2 -- banded 10M x 32: 85 % of 8 TB/s);
+                  spmv_hll_autotune measures all three */
     xcd_ranges xcd_blk; /* hack-block ranges per XCD holding ~1/8 of the SLOTS
                            each (even boundaries: a wavefront owns a pair) */
     unsigned *padmask; /* [(S+31)/32] bit t set: slot t was a pad (JA == -1)

@@ -27,6 +27,9 @@
 #include "hip_common.h"
 
 #define HACK 32
+/* grouped order: runs of this many consecutive workgroups per XCD, the runs
+ * dealt to the XCDs round-robin (see panels.hip, the blocked schedules) */
+#define HLL_GROUP 32
 
 template <typename T> __device__ __forceinline__ T ld_stream(const T *p) {
     return __builtin_nontemporal_load(p);
@@ -118,7 +121,7 @@ __global__ void k_hll_row_major(int M, int b0, int b1,
  * DESIGN.md section 4).  The launch has 8 x (longest range) workgroups; the
  * surplus ones of shorter ranges exit.
  */
-template <int U, bool REMAP, int ABL = 0> /* ABL 1: all gathers read x[0] */
+template <int U, int ORDER, int ABL = 0> /* ABL 1: all gathers read x[0] */
 __global__ void k_hll_col_direct(int M, int b0, int b1, xcd_ranges xr,
                                  const int64_t *__restrict__ off,
                                  const int *__restrict__ ja,
@@ -126,13 +129,20 @@ __global__ void k_hll_col_direct(int M, int b0, int b1, xcd_ranges xr,
                                  const double *__restrict__ x,
                                  double *__restrict__ y) {
     int b, i;
-    if (REMAP) {
+    if (ORDER == 1) {
         const int xx = blockIdx.x % NUM_XCD, kk = blockIdx.x / NUM_XCD;
         const long long t = (long long)kk * blockDim.x + threadIdx.x;
         b = xr.first[xx] + (int)(t / HACK);
         i = (int)(t % HACK);
         if (b >= xr.first[xx + 1])
             return;
+    } else if (ORDER == 2) { /* groups of HLL_GROUP workgroups per XCD */
+        const int xx = blockIdx.x % NUM_XCD, kk = blockIdx.x / NUM_XCD;
+        const long long w =
+            ((long long)(kk / HLL_GROUP) * NUM_XCD + xx) * HLL_GROUP + kk % HLL_GROUP;
+        const long long t = w * blockDim.x + threadIdx.x;
+        b = b0 + (int)(t / HACK);
+        i = (int)(t % HACK);
     } else {
         const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         b = b0 + (int)(t / HACK);
@@ -217,7 +227,7 @@ __device__ __forceinline__ void hll_chunk_load(hll_chunk &c, int s0, int lane,
     c.aB1 = sa + 128 < nB ? ld_stream((const v2d *)(gaB + sa + 128)) : zd;
 }
 
-template <bool REMAP>
+template <int ORDER>
 __global__ void k_hll_col_lds(int b0, int b1, xcd_ranges xr,
                               const int64_t *__restrict__ off,
                               const int *__restrict__ ja,
@@ -234,11 +244,15 @@ __global__ void k_hll_col_lds(int b0, int b1, xcd_ranges xr,
                 (size_t)wave * 2 * CH_SLOTS;
 
     int bA; /* wave-uniform */
-    if (REMAP) {
+    if (ORDER == 1) {
         const int xx = blockIdx.x % NUM_XCD, kk = blockIdx.x / NUM_XCD;
         bA = xr.first[xx] + 2 * (kk * waves + wave);
         if (xr.first[xx + 1] < b1)
             b1 = xr.first[xx + 1]; /* the pair stays inside the XCD's range */
+    } else if (ORDER == 2) { /* groups of HLL_GROUP workgroups per XCD */
+        const int xx = blockIdx.x % NUM_XCD, kk = blockIdx.x / NUM_XCD;
+        const int w = ((kk / HLL_GROUP) * NUM_XCD + xx) * HLL_GROUP + kk % HLL_GROUP;
+        bA = b0 + 2 * (w * waves + wave);
     } else {
         bA = b0 + 2 * ((int)blockIdx.x * waves + wave);
     }
@@ -343,9 +357,10 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         return -EINVAL; /* layout of the handle does not fit the kernel */
     if (b0 == b1)
         return 0;
-    /* variant bit 0: hardware order, bit 1: XCD ranges, else the handle's */
-    const bool remap = (variant & 1) ? false : (variant & 2) ? true
-                                                            : !H->hw_order;
+    /* workgroup order: variant bit 0 hardware, bit 1 XCD ranges, bit 2
+     * grouped; none: the handle's (0 hardware / 1 ranges / 2 grouped) */
+    const int order = (variant & 1) ? 0 : (variant & 2) ? 1 : (variant & 4) ? 2
+                                                        : H->order;
     const int threads = waves * WAVE;
     const long long lanes = (long long)(b1 - b0) * HACK;
     /* XCD ranges of this launch: the handle's slot-balanced table for the
@@ -375,20 +390,26 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         if (full_end > b0) {
             int pairs = (full_end - b0 + 1) / 2;
             size_t lds = (size_t)waves * 2 * CH_SLOTS * (sizeof(double) + sizeof(int));
-            if (remap)
-                hipLaunchKernelGGL(k_hll_col_lds<true>,
+            const int nwg = (pairs + waves - 1) / waves;
+            if (order == 1)
+                hipLaunchKernelGGL(k_hll_col_lds<1>,
                                    dim3(NUM_XCD * (((xmax + 1) / 2 + waves - 1) /
                                                    waves)),
                                    dim3(threads), lds, s, b0, full_end, xr,
                                    H->off, H->ja, H->as, x, y);
-            else
-                hipLaunchKernelGGL(k_hll_col_lds<false>,
-                                   dim3((pairs + waves - 1) / waves),
+            else if (order == 2)
+                hipLaunchKernelGGL(k_hll_col_lds<2>,
+                                   dim3((nwg + NUM_XCD * HLL_GROUP - 1) /
+                                        (NUM_XCD * HLL_GROUP) * NUM_XCD * HLL_GROUP),
                                    dim3(threads), lds, s, b0, full_end, xr,
                                    H->off, H->ja, H->as, x, y);
+            else
+                hipLaunchKernelGGL(k_hll_col_lds<0>, dim3(nwg), dim3(threads),
+                                   lds, s, b0, full_end, xr, H->off, H->ja,
+                                   H->as, x, y);
         }
         if (full_end < b1)
-            hipLaunchKernelGGL((k_hll_col_direct<8, false>), dim3(1), dim3(WAVE), 0, s,
+            hipLaunchKernelGGL((k_hll_col_direct<8, 0>), dim3(1), dim3(WAVE), 0, s,
                                H->M, full_end, b1, xr, H->off, H->ja, H->as, x, y);
         break;
     }
@@ -397,30 +418,36 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         const unsigned xgrid =
             NUM_XCD * (unsigned)(((long long)xmax * HACK + threads - 1) / threads);
         if (variant & 32) { /* tuning: 4 columns per pipeline stage */
-            hipLaunchKernelGGL((k_hll_col_direct<4, true>), dim3(xgrid),
+            hipLaunchKernelGGL((k_hll_col_direct<4, 1>), dim3(xgrid),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (variant & 64) { /* tuning: 16 columns per pipeline stage */
-            hipLaunchKernelGGL((k_hll_col_direct<16, true>), dim3(xgrid),
+            hipLaunchKernelGGL((k_hll_col_direct<16, 1>), dim3(xgrid),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (variant & 16) {
-            hipLaunchKernelGGL((k_hll_col_direct<8, true, 1>), dim3(xgrid),
+            hipLaunchKernelGGL((k_hll_col_direct<8, 1, 1>), dim3(xgrid),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
-        if (remap)
-            hipLaunchKernelGGL((k_hll_col_direct<8, true>), dim3(xgrid),
+        const unsigned hwgrid = (unsigned)((lanes + threads - 1) / threads);
+        if (order == 1)
+            hipLaunchKernelGGL((k_hll_col_direct<8, 1>), dim3(xgrid),
+                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               H->ja, H->as, x, y);
+        else if (order == 2)
+            hipLaunchKernelGGL((k_hll_col_direct<8, 2>),
+                               dim3((hwgrid + NUM_XCD * HLL_GROUP - 1) /
+                                    (NUM_XCD * HLL_GROUP) * NUM_XCD * HLL_GROUP),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
         else
-            hipLaunchKernelGGL((k_hll_col_direct<8, false>),
-                               dim3((unsigned)((lanes + threads - 1) / threads)),
+            hipLaunchKernelGGL((k_hll_col_direct<8, 0>), dim3(hwgrid),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
         break;

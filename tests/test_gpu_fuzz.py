@@ -63,7 +63,7 @@ def test_blocked_path_random_shapes(case, monkeypatch):
             dA.launch(k, d_x.ptr, d_y.ptr, variant=variant)
             check(("csr", k, "variant", variant))
         for k in (1, 2):
-            for variant in (0, 1, 2):
+            for variant in (0, 1, 2, 4):
                 S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
                 dH.launch(k, d_x.ptr, d_y.ptr, variant=variant)
                 check(("hll", k, "variant", variant))
