@@ -44,11 +44,13 @@ typedef struct spmv_launch_opts {
     int variant;         /* tuning bit-field, 0 = default.  Workgroup -> XCD
                             order of the direct kernels: bit 0 hardware
                             (round-robin) order, bit 1 XCD-contiguous ranges
-                            of equal work, bit 2 (HLL kernels 1 / 2) grouped
-                            runs of 32 workgroups per XCD; none of them: the
-                            handle's order (what spmv_*_autotune measured
-                            faster; before tuning: hardware order for HLL,
-                            contiguous for the CSR sub-wave kernel).  The
+                            of equal work, grouped runs of 32 workgroups per
+                            XCD: bit 2 (HLL kernels 1 / 2) / bit 5 (CSR
+                            sub-wave and stream kernels; bit 6: stream kernel
+                            in hardware order); none of them: the handle's
+                            order (what spmv_*_autotune measured faster;
+                            before tuning: grouped from 2M rows up).  CSR
+                            stream kernel: bit 4 = 4- / 8-byte loads only.  The
                             blocked schedules read their own bits
                             (panels.hip) and spmv_panel_opts.tile_order */
     int reserved[5];     /* must be 0 */

@@ -117,7 +117,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
  * instead of 768 B): the kernel is latency-bound otherwise (1 pass 1.30 ms,
  * 4 passes 0.83 ms, 8 passes 0.79 ms on banded 10M x 32).
  */
-template <int G, int P, bool REMAP>
+#define CSR_GROUP 32 /* grouped order: runs of 32 workgroups per XCD */
+__device__ __forceinline__ int xcd_grouped(int bid) {
+    const int xx = bid % 8, kk = bid / 8;
+    return ((kk / CSR_GROUP) * 8 + xx) * CSR_GROUP + kk % CSR_GROUP;
+}
+
+template <int G, int P, int ORDER>
 __global__ void k_csr_subwave_row(int r0, int r1,
                                   const int *__restrict__ irp,
                                   const int *__restrict__ ja,
@@ -127,7 +133,11 @@ __global__ void k_csr_subwave_row(int r0, int r1,
     constexpr int RPP = WAVE / G; /* rows per pass */
     const int lane = threadIdx.x & (WAVE - 1);
     const int sub = lane & (G - 1);
-    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    /* ORDER 0: hardware order, 1: XCD-contiguous equal ranges, 2: grouped
+     * (the grid is then padded to a multiple of 8 x CSR_GROUP; rows beyond
+     * r1 are masked below) */
+    const int bid = ORDER == 1 ? xcd_remap(blockIdx.x, gridDim.x)
+                    : ORDER == 2 ? xcd_grouped(blockIdx.x) : (int)blockIdx.x;
     const long long wave_global =
         ((long long)bid * blockDim.x + threadIdx.x) / WAVE;
     const long long rbase = (long long)r0 + wave_global * (P * RPP) + lane / G;
@@ -265,7 +275,7 @@ typedef double s_v2d __attribute__((ext_vector_type(2)));
  * of slack so the last range may read past NZ. */
 template <bool WIDE>
 __global__ void __launch_bounds__(STREAM_THREADS)
-    k_csr_stream(const int2 *__restrict__ rowblk,
+    k_csr_stream(int n_rowblk, int grouped, const int2 *__restrict__ rowblk,
                  const unsigned char *__restrict__ mode,
                  const int *__restrict__ irp, const int *__restrict__ ja,
                  const double *__restrict__ as, const double *__restrict__ x,
@@ -276,14 +286,17 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     __shared__ int rowptr[STREAM_THREADS + 1]; /* this range's slice of IRP */
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
-    /* ranges are dealt to the XCDs round-robin (hardware order).  XCD-
-     * contiguous runs of equal work -- what the blocked schedules use -- were
-     * measured SLOWER here (banded 10M x 32: 0.738 vs 0.704 ms, 27-point
-     * stencil 0.621 vs 0.605, 1M x 16: 0.049 vs 0.046): neighbouring ranges
-     * share next to nothing of x, and eight XCDs streaming eight distant
-     * regions of JA/AS suit the HBM channels less than all of them
-     * advancing through one */
-    const int rb = blockIdx.x;
+    /* Which range a workgroup runs (workgroups are dealt to the XCDs
+     * round-robin): its own index (hardware order) or grouped runs of 32
+     * consecutive ranges per XCD, the runs dealt round-robin (+2.5..4.7 % on
+     * 10M-row matrices: banded 0.652 vs 0.683 ms, W = 2^11 0.803 vs 0.830,
+     * 27-point stencil 0.570 vs 0.584; 1M x 16: 0.0471 vs 0.0462).  XCD-
+     * contiguous runs of equal work -- eight distant regions of JA/AS
+     * streamed at once -- were measured SLOWER than hardware order (banded
+     * 0.738 vs 0.704, stencil 0.621 vs 0.605, 1M x 16 0.049 vs 0.046). */
+    const int rb = grouped ? xcd_grouped(blockIdx.x) : (int)blockIdx.x;
+    if (rb >= n_rowblk)
+        return;
     const int2 t_a = rowblk[rb], t_z = rowblk[rb + 1]; /* (row, entry) */
     const int row_a = t_a.x, row_b = t_z.x;
     const int beg = t_a.y, end = t_z.y;
@@ -430,19 +443,25 @@ static int pick_group(const spmv_csr_dev *A, int group) {
 }
 
 template <int G, int P>
-static void launch_subwave_p(int r0, int r1, int threads, bool remap,
+static void launch_subwave_p(int r0, int r1, int threads, int order,
                              const spmv_csr_dev *A, const double *x, double *y,
                              hipStream_t s) {
     const int rows_per_wave = P * (WAVE / G);
     long long waves = ((long long)(r1 - r0) + rows_per_wave - 1) / rows_per_wave;
     long long wpb = threads / WAVE;
     unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-    if (remap)
-        hipLaunchKernelGGL((k_csr_subwave_row<G, P, true>), dim3(grid),
+    if (order == 1)
+        hipLaunchKernelGGL((k_csr_subwave_row<G, P, 1>), dim3(grid),
+                           dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
+                           x, y);
+    else if (order == 2)
+        hipLaunchKernelGGL((k_csr_subwave_row<G, P, 2>),
+                           dim3((grid + 8 * CSR_GROUP - 1) / (8 * CSR_GROUP) *
+                                8 * CSR_GROUP),
                            dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
                            x, y);
     else
-        hipLaunchKernelGGL((k_csr_subwave_row<G, P, false>), dim3(grid),
+        hipLaunchKernelGGL((k_csr_subwave_row<G, P, 0>), dim3(grid),
                            dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
                            x, y);
 }
@@ -450,7 +469,7 @@ static void launch_subwave_p(int r0, int r1, int threads, bool remap,
 /* passes: independent row groups per wavefront (tuning, variant bits 2-3;
  * carried per launch -- the launch path keeps no process-global state) */
 template <int G>
-static void launch_subwave(int passes, int r0, int r1, int threads, bool remap,
+static void launch_subwave(int passes, int r0, int r1, int threads, int remap,
                            const spmv_csr_dev *A, const double *x, double *y,
                            hipStream_t s) {
     switch (passes) {
@@ -473,9 +492,11 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
         return -EINVAL;
-    /* variant bit 0: hardware order, bit 1: XCD ranges, else the handle's */
-    const bool remap = (variant & 1) ? false : (variant & 2) ? true
-                                                            : !A->hw_order;
+    /* workgroup order of the sub-wave kernel: variant bit 0 hardware, bit 1
+     * XCD-contiguous ranges, bit 5 grouped runs; none: the handle's
+     * (0 / 1 / 2, spmv_csr_autotune) */
+    const int remap = (variant & 1) ? 0 : (variant & 2) ? 1 : (variant & 32) ? 2
+                                                        : A->order;
     if (r0 == r1)
         return 0;
     const int threads = waves * WAVE;
@@ -535,16 +556,26 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * stencil 0.687 vs 0.608, random W = 2048 0.865 vs 0.798. */
         if (A->n_rowblk <= 0)
             break;
-        if (variant & 16) /* tuning: 4- / 8-byte loads only */
-            hipLaunchKernelGGL(k_csr_stream<false>, dim3(A->n_rowblk),
-                               dim3(STREAM_THREADS), 0, s,
-                               (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
-                               A->ja, A->as, x, y);
-        else
-            hipLaunchKernelGGL(k_csr_stream<true>, dim3(A->n_rowblk),
-                               dim3(STREAM_THREADS), 0, s,
-                               (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
-                               A->ja, A->as, x, y);
+        {
+            /* ranges in grouped runs of 32 per XCD (variant bit 5) or in
+             * hardware order (bit 6); none: the handle's */
+            const int grp = (variant & 32) ? 1 : (variant & 64) ? 0
+                                                               : A->stream_grouped;
+            const unsigned grid =
+                grp ? (unsigned)((A->n_rowblk + 8 * CSR_GROUP - 1) /
+                                 (8 * CSR_GROUP) * 8 * CSR_GROUP)
+                    : (unsigned)A->n_rowblk;
+            if (variant & 16) /* tuning: 4- / 8-byte loads only */
+                hipLaunchKernelGGL(k_csr_stream<false>, dim3(grid),
+                                   dim3(STREAM_THREADS), 0, s, A->n_rowblk, grp,
+                                   (const int2 *)A->rowblk, A->rowblk_mode,
+                                   A->irp, A->ja, A->as, x, y);
+            else
+                hipLaunchKernelGGL(k_csr_stream<true>, dim3(grid),
+                                   dim3(STREAM_THREADS), 0, s, A->n_rowblk, grp,
+                                   (const int2 *)A->rowblk, A->rowblk_mode,
+                                   A->irp, A->ja, A->as, x, y);
+        }
         break;
     }
     default:

@@ -446,6 +446,13 @@ static int csr_alloc_dev(int M, int N, int64_t NZ, spmv_csr_dev **out) {
     d->M = M;
     d->N = N;
     d->NZ = NZ;
+    /* workgroup orders before tuning (csr_kernels.hip): grouped runs for
+     * matrices of >= 2M rows (banded 10M x 32: stream kernel 0.652 ms
+     * grouped / 0.683 hardware, sub-wave 0.843 / 0.905 / 0.885 contiguous),
+     * below: hardware order for the stream kernel (1M x 16: 0.0462 vs
+     * 0.0471), contiguous ranges for the sub-wave kernel (0.0536 vs 0.0548) */
+    d->order = M >= 2000000 ? 2 : 1;
+    d->stream_grouped = M >= 2000000;
     HIP_TRY(hipGetDevice(&d->device));
     HIP_TRY(hipMalloc((void **)&d->irp, ((size_t)M + 1) * sizeof(int)));
     /* + slack: the stream kernel's 16-byte loads of the last range may read
@@ -1159,25 +1166,43 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
     double bms = 1e300;
     std::vector<double> ms(5);
     const size_t flush = tune_flush_bytes(spmv_csr_algorithmic_bytes(A));
-    A->hw_order = 0;
     for (int k = 0; k < 3; ++k) {
         if (cand[k] == 1 && A->M > 0 && (double)A->NZ / A->M < 48.0)
             continue; /* a wavefront per row wastes lanes on short rows */
         double m;
-        if (cand[k] == 2) { /* the sub-wave kernel in both workgroup orders */
-            double mo[2];
-            for (int hw = 0; hw < 2; ++hw) {
+        if (cand[k] == 2) { /* the sub-wave kernel in its three orders */
+            static const int bit[3] = {1, 2, 32};
+            double mo[3];
+            for (int order = 0; order < 3; ++order) {
                 spmv_launch_opts o;
                 memset(&o, 0, sizeof o);
-                o.variant = hw ? 1 : 2;
+                o.variant = bit[order];
                 int rc = spmv_csr_time(A, 2, &o, d_x, d_y, 1, 5, flush,
                                        ms.data(), NULL);
                 if (rc)
                     return rc;
-                mo[hw] = median_of(ms);
+                mo[order] = median_of(ms);
             }
-            A->hw_order = mo[1] < 0.98 * mo[0];
-            m = A->hw_order ? mo[1] : mo[0];
+            int pick = 0;
+            for (int order = 1; order < 3; ++order)
+                if (mo[order] < mo[pick])
+                    pick = order;
+            A->order = pick;
+            m = mo[pick];
+        } else if (cand[k] == 4) { /* the stream kernel in its two orders */
+            double mo[2];
+            for (int grp = 0; grp < 2; ++grp) {
+                spmv_launch_opts o;
+                memset(&o, 0, sizeof o);
+                o.variant = grp ? 32 : 64;
+                int rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush,
+                                       ms.data(), NULL);
+                if (rc)
+                    return rc;
+                mo[grp] = median_of(ms);
+            }
+            A->stream_grouped = mo[1] < mo[0];
+            m = mo[A->stream_grouped];
         } else {
             int rc = spmv_csr_time(A, cand[k], NULL, d_x, d_y, 1, 5, flush,
                                    ms.data(), NULL);

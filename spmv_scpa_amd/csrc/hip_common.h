@@ -86,8 +86,11 @@ struct spmv_csr_dev {
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
     int max_row_len;
-    int hw_order; /* sub-wave kernel: 1 = hardware workgroup order measured
-                     faster than XCD-contiguous ranges (spmv_csr_autotune) */
+    int order; /* sub-wave kernel, workgroup order: 0 hardware, 1 XCD-contiguous
+                  equal ranges, 2 grouped runs of 32 workgroups per XCD
+                  (spmv_csr_autotune measures all three) */
+    int stream_grouped; /* stream kernel: ranges in grouped runs instead of
+                           hardware order (spmv_csr_autotune measures both) */
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
 };
 

@@ -56,9 +56,11 @@ def test_blocked_path_random_shapes(case, monkeypatch):
             S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
             dA.launch(k, d_x.ptr, d_y.ptr)
             check(("csr", k))
-        # both workgroup orders of the direct kernels (variant bit 0: hardware
-        # order, bit 1: XCD-contiguous ranges of equal work)
-        for k, variant in ((2, 1), (2, 2)):
+        # the workgroup orders of the direct kernels (variant bit 0: hardware
+        # order, bit 1: XCD-contiguous ranges, bit 5 (CSR) / bit 2 (HLL):
+        # grouped runs; stream kernel: bit 6 hardware order, bit 4 narrow loads)
+        for k, variant in ((2, 1), (2, 2), (2, 32), (4, 32), (4, 64),
+                           (4, 16 | 32)):
             S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
             dA.launch(k, d_x.ptr, d_y.ptr, variant=variant)
             check(("csr", k, "variant", variant))
