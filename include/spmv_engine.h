@@ -102,7 +102,7 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
  * no environment variable and, apart from the process default schedule of
  * spmv_set_panel_schedule(), keeps no mutable global: two host threads may
  * build and launch different handles concurrently.  Zero-initialise; 0 means
- * "default" in every field except `sched`.
+ * "default" in every field except `sched` and `sweep_layout` (-1).
  */
 typedef struct spmv_panel_opts {
     int sched;            /* -1 process default, 0 steps, 1 sweep, 2 chain */
@@ -123,7 +123,12 @@ typedef struct spmv_panel_opts {
                              through one region), 1 = hardware order (tile =
                              workgroup index), 2 = XCD-contiguous ranges of
                              equal work.  spmv_*_autotune measures all three */
-    int reserved[1];      /* must be 0 */
+    int sweep_layout;     /* sweep: 0 = buckets stored tile-major (a workgroup
+                             streams one contiguous region), 1 (and -1 =
+                             default) = panel-major inside a round (what the
+                             chip reads at one time is one compact region).
+                             NOTE: the only field whose "default" is -1; a
+                             zero-initialised struct asks for layout 0 */
 } spmv_panel_opts;
 
 /* ---- CSR handle ---- */

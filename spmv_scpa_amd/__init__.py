@@ -95,7 +95,7 @@ class PanelOpts(C.Structure):
     _fields_ = [("sched", C.c_int), ("panel_cols", C.c_int),
                 ("tile_rows", C.c_int), ("sweep_wgs_per_cu", C.c_int),
                 ("reserve_cus", C.c_int), ("lds_min", C.c_int),
-                ("tile_order", C.c_int), ("reserved", C.c_int * 1)]
+                ("tile_order", C.c_int), ("sweep_layout", C.c_int)]
 
 
 _CSRp = C.POINTER(SparseCSR)
@@ -327,7 +327,7 @@ def _env_int(name, lo, hi):
 
 
 def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
-                reserve_cus=0, lds_min=0):
+                reserve_cus=0, lds_min=0, sweep_layout=None):
     o = PanelOpts()
     o.sched = -1 if sched is None else (
         PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched))
@@ -336,6 +336,10 @@ def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
     o.sweep_wgs_per_cu = sweep_wgs_per_cu or _env_int("SPMV_SWEEP_WGS", 1, 8)
     o.reserve_cus = reserve_cus
     o.lds_min = lds_min or _env_int("SPMV_LDS_MIN", 1, 160 * 1024 - 256)
+    if sweep_layout is None:  # -1: the library's default (panel-major)
+        ev = os.environ.get("SPMV_SWEEP_LAYOUT", "")
+        sweep_layout = int(ev) if ev in ("0", "1") else -1
+    o.sweep_layout = sweep_layout
     return o
 
 
@@ -665,14 +669,15 @@ class CsrDevice:
         return ms[:iters]
 
     def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
-                     sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0):
+                     sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0,
+                     sweep_layout=None):
         """blocked copy in the process default schedule, or in an explicit
         one ("steps" / "sweep" / "chain"), with explicit build options
         (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
         SPMV_SWEEP_WGS and SPMV_LDS_MIN of tools/README.md are read HERE, in
         the harness -- the library itself reads no environment."""
         o = _panel_opts(panel_cols, sched, tile_rows, sweep_wgs_per_cu,
-                        reserve_cus, lds_min)
+                        reserve_cus, lds_min, sweep_layout)
         _check(_lib.spmv_csr_build_panels_opts(self.h, C.byref(o)),
                "spmv_csr_build_panels_opts")
 
@@ -752,14 +757,15 @@ class HllDevice:
         return cls(h)
 
     def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
-                     sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0):
+                     sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0,
+                     sweep_layout=None):
         """blocked copy in the process default schedule, or in an explicit
         one ("steps" / "sweep" / "chain"), with explicit build options
         (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
         SPMV_SWEEP_WGS and SPMV_LDS_MIN of tools/README.md are read HERE, in
         the harness -- the library itself reads no environment."""
         o = _panel_opts(panel_cols, sched, tile_rows, sweep_wgs_per_cu,
-                        reserve_cus, lds_min)
+                        reserve_cus, lds_min, sweep_layout)
         _check(_lib.spmv_hll_build_panels_opts(self.h, C.byref(o)),
                "spmv_hll_build_panels_opts")
 

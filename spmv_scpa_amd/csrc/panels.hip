@@ -79,6 +79,7 @@ struct spmv_panels {
     int grid;        /* sweep: workgroups of the launch */
     int wgs_per_cu;  /* sweep: workgroups sharing a CU's LDS */
     int reserve_cus; /* sweep: CUs left out of the grid (spmv_panel_opts) */
+    int pmajor;      /* sweep: buckets stored panel-major inside a round */
     int lds_min;     /* launch with at least this much dynamic LDS; 0: tile */
     int64_t nnz;     /* entries kept */
     int64_t total;   /* slots of ENT/VAL in use (bucket padding included) */
@@ -127,8 +128,21 @@ void panels_free(spmv_panels *p) {
 /* ---- keys: (tile * panels + panel) << shift | column-in-panel: buckets in
  * order and, inside a bucket, ascending columns, so the lanes of a gather
  * instruction ask for neighbouring lines of x and entries that share a line
- * share the request.  dropped slots: bucket id tiles*panels (sorts last) ---- */
+ * share the request.  dropped slots: bucket id nbuckets (sorts last) ---- */
+/* bucket id of (tile, panel): tile-major, or -- sweep layout 1, pm_grid > 0 --
+ * panel-major inside a round of pm_grid tiles: ((round * panels + panel) *
+ * pm_grid + tile % pm_grid), so that what the chip reads at one time (every
+ * workgroup's bucket of the same panel) is one compact region of ENT / VAL */
+__host__ __device__ __forceinline__ uint64_t bucket_id(uint64_t tile,
+                                                       uint64_t panel,
+                                                       uint64_t panels,
+                                                       uint64_t pm_grid) {
+    return pm_grid ? ((tile / pm_grid) * panels + panel) * pm_grid + tile % pm_grid
+                   : tile * panels + panel;
+}
+
 __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
+                                int pm_grid,
                                 const int *__restrict__ irp,
                                 const int *__restrict__ ja, uint64_t *key,
                                 unsigned *idx) {
@@ -137,16 +151,18 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
     long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (row >= M)
         return;
-    const uint64_t tk = (uint64_t)(row / tile_rows) * (uint64_t)panels;
+    const uint64_t tile = (uint64_t)(row / tile_rows);
     const unsigned low = (1u << shift) - 1u;
     for (int k = irp[row] + sub, e = irp[row + 1]; k < e; k += 8) {
         const unsigned c = (unsigned)ja[k];
-        key[k] = ((tk + (c >> shift)) << shift) | (c & low);
+        key[k] = (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
+                 (c & low);
         idx[k] = (unsigned)k;
     }
 }
 
 __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
+                                int pm_grid, uint64_t nbuckets,
                                 int col_major, const int64_t *__restrict__ off,
                                 const int *__restrict__ ja,
                                 const unsigned *__restrict__ padmask,
@@ -158,9 +174,8 @@ __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
     int rows = min(32, M - b * 32);
     int64_t o = off[b];
     int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
-    const uint64_t tk = (uint64_t)(row / tile_rows) * (uint64_t)panels;
-    const uint64_t dropped =
-        ((uint64_t)((M + tile_rows - 1) / tile_rows) * (uint64_t)panels) << shift;
+    const uint64_t tile = (uint64_t)(row / tile_rows);
+    const uint64_t dropped = nbuckets << shift;
     const unsigned low = (1u << shift) - 1u;
     for (int j = 0; j < w; ++j) {
         int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
@@ -169,7 +184,9 @@ __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
          * other, exactly as from a CSR source */
         const unsigned c = (unsigned)ja[t];
         const bool pad = (padmask[t >> 5] >> (t & 31)) & 1u;
-        key[t] = !pad ? ((tk + (c >> shift)) << shift) | (c & low) : dropped;
+        key[t] = !pad ? (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
+                            (c & low)
+                      : dropped;
         idx[t] = (unsigned)t;
     }
 }
@@ -436,13 +453,14 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, 0, {0}};
+    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, 0, -1};
     if (!o)
         o = &dflt;
     if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
-        o->tile_order < 0 || o->tile_order > 2 || o->reserved[0])
+        o->tile_order < 0 || o->tile_order > 2 || o->sweep_layout < -1 ||
+        o->sweep_layout > 1)
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
     int sched = o->sched;
@@ -516,8 +534,21 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P->grid = sweep ? (grid < tiles ? grid : (tiles > 0 ? tiles : 1)) : 0;
     P->wgs_per_cu = per_cu;
     P->reserve_cus = sweep ? o->reserve_cus : 0;
+    /* panel-major is the default (-1): 1.448 vs 1.464 ms on config 3, 2.88
+     * vs 2.96 ms on one shard of the 80M-column problem, and the masked tail
+     * blocks re-read a cached line instead of fetching another bucket */
+    P->pmajor = sweep && o->sweep_layout != 0;
     P->lds_min = o->lds_min;
     P->order = sweep ? 0 : o->tile_order;
+    /* bucket ids: tile-major, or panel-major inside rounds of P->grid tiles */
+    const int pm_grid = P->pmajor ? P->grid : 0;
+    const int64_t nbuckets =
+        pm_grid ? (int64_t)((tiles + pm_grid - 1) / pm_grid) * panels * pm_grid
+                : (int64_t)tiles * panels;
+    if ((uint64_t)nbuckets >= (uint64_t)INT32_MAX) {
+        free(P);
+        return -EOVERFLOW;
+    }
     uint64_t *key[2] = {NULL, NULL};
     unsigned *idx[2] = {NULL, NULL};
     uint64_t *skey = NULL;
@@ -539,12 +570,12 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             hipLaunchKernelGGL(k_keys_from_csr,
                                dim3((unsigned)(((long long)M * 8 + 255) / 256)),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
-                               irp_or_null, ja, key[0], idx[0]);
+                               pm_grid, irp_or_null, ja, key[0], idx[0]);
         else
             hipLaunchKernelGGL(k_keys_from_hll, dim3((M + 255) / 256),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
-                               col_major, off_or_null, ja, padmask, key[0],
-                               idx[0]);
+                               pm_grid, (uint64_t)nbuckets, col_major,
+                               off_or_null, ja, padmask, key[0], idx[0]);
         HIP_TRY(hipGetLastError());
         {
             hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
@@ -552,8 +583,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             /* sort only the bits in use: bucket ids up to tiles*panels (the
              * id of dropped slots) above `shift` column bits */
             int end_bit = shift + 1;
-            while (end_bit < 64 &&
-                   (((uint64_t)tiles * (uint64_t)panels) >> (end_bit - shift)))
+            while (end_bit < 64 && (((uint64_t)nbuckets) >> (end_bit - shift)))
                 ++end_bit;
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
                 NULL, tmp_bytes, dk, dv, (int)slots, 0, end_bit, 0));
@@ -566,7 +596,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         }
     }
     {
-        const int64_t buckets = (int64_t)tiles * panels;
+        const int64_t buckets = nbuckets;
         const unsigned gb = (unsigned)((buckets + 256) / 256);
         HIP_TRY(hipMalloc((void **)&raw, ((size_t)buckets + 1) * sizeof(int64_t)));
         HIP_TRY(hipMalloc((void **)&padded,
@@ -597,7 +627,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                           ((size_t)buckets + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void **)&P->nbk, ((size_t)tiles + 1) * sizeof(int)));
         HIP_TRY(hipMemset(P->nbk + tiles, 0, sizeof(int)));
-        if (tiles > 0) {
+        if (tiles > 0 && !sweep) { /* the sweep kernel reads bptr / blen only */
             hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
                                dim3(256), 0, 0, tiles, panels, P->bptr, P->blen,
                                P->cb, P->cpanel, P->nbk);
@@ -757,7 +787,7 @@ template <int NT, int Q, int ABL = 0> /* ABL: timing ablations, 1 = no LDS
                                          window (L1 hits) */
 __global__ void __launch_bounds__(NT)
     k_tiles_sweep(int M, int tile_rows, int tiles, int panels, int shift,
-                  int lag, int spin, int stagger, unsigned total,
+                  int lag, int spin, int stagger, int pmajor, unsigned total,
                   const int64_t *__restrict__ bptr,
                   const int *__restrict__ blen,
                   const unsigned *__restrict__ tent,
@@ -796,8 +826,14 @@ __global__ void __launch_bounds__(NT)
             ytile[i] = 0.0;
         __syncthreads();
 
-        const int64_t *bp = bptr + (int64_t)t * panels;
-        const int *bl = blen + (int64_t)t * panels;
+        /* bucket (this tile, panel p): tile-major tables, or panel-major
+         * inside the round (layout 1: every workgroup's bucket of a panel
+         * lies in one compact region) */
+        const int64_t bbase = pmajor ? (int64_t)q0 * grid + blockIdx.x
+                                     : (int64_t)t * panels;
+        const int64_t bstep = pmajor ? grid : 1;
+        auto bp = [&](int p) { return bptr[bbase + (int64_t)p * bstep]; };
+        auto bl = [&](int p) { return blen[bbase + (int64_t)p * bstep]; };
         bool ready = !(lag > 0 && q0 >= lag); /* panel 0 of a later round */
 
         /* position of the next chunk to load (wave-uniform).  All XCDs visit
@@ -807,7 +843,8 @@ __global__ void __launch_bounds__(NT)
          * no gain at 10 M columns, 2.97 -> 3.79 ms at 80 M.) */
         const int poff = stagger ? (int)((long long)xcd * panels / NUM_XCD) : 0;
         int fp = 0, fpa = poff % panels;
-        unsigned fk = (unsigned)bp[fpa], fe = fk + (unsigned)bl[fpa];
+        unsigned fk = (unsigned)bp(fpa), fe = fk + (unsigned)bl(fpa);
+        unsigned fb = fk; /* start of the bucket being read */
         bool ffirst = true;
 
         auto fill = [&](sweep_chunk<Q> &c) {
@@ -823,6 +860,11 @@ __global__ void __launch_bounds__(NT)
                 unsigned blk = fk + ((unsigned)g * NT + (tid & ~(WAVE - 1))) * 4u;
                 const unsigned lane = tid & (WAVE - 1);
                 c.live[g] = (int)(fe - blk) - (int)lane; /* > 64u: entry u */
+                /* layout 1: a block past the bucket's end would fetch
+                 * ANOTHER tile's bucket (pure waste; tile-major it prefetches
+                 * this tile's next bucket): re-read the bucket's first block */
+                if (pmajor && blk >= fe && fe > fb)
+                    blk = fb;
                 if (ABL & 4) /* stream from a 192 KiB window: L2 hits */
                     blk &= 0x3FFFu;
                 c.en[g] = __builtin_nontemporal_load(
@@ -842,12 +884,13 @@ __global__ void __launch_bounds__(NT)
                     fpa = fpa + 1 < panels ? fpa + 1 : 0;
                     ffirst = true;
                     if (fp < panels) {
-                        fk = (unsigned)bp[fpa];
-                        fe = fk + (unsigned)bl[fpa];
+                        fk = (unsigned)bp(fpa);
+                        fe = fk + (unsigned)bl(fpa);
                     } else { /* past the end: zeros of the tail */
                         fk = total;
                         fe = total;
                     }
+                    fb = fk;
                 }
             }
         };
@@ -1231,8 +1274,9 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A>), dim3(P->grid),       \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->tiles,      \
                            P->panels, P->shift, lag, SWEEP_SPIN_MAX,           \
-                           !!(variant & 4096), (unsigned)P->total, P->bptr,    \
-                           P->blen, P->ent, P->val, x, y, P->phase_cnt);       \
+                           !!(variant & 4096), P->pmajor, (unsigned)P->total,  \
+                           P->bptr, P->blen, P->ent, P->val, x, y,             \
+                           P->phase_cnt);                                      \
     } while (0)
         const int abl = (variant >> 8) & 7;
         const int two = !((variant >> 11) & 1); /* 2 groups of 4 per lane */
@@ -1370,13 +1414,13 @@ int panels_from_hll_opts(const spmv_hll_dev *H, const spmv_panel_opts *o,
 
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, {0}};
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1};
     return panels_from_csr_opts(A, &o, out);
 }
 
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, {0}};
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1};
     return panels_from_hll_opts(H, &o, out);
 }
 
@@ -1390,6 +1434,7 @@ void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     o->reserve_cus = P->reserve_cus;
     o->lds_min = P->lds_min;
     o->tile_order = P->order;
+    o->sweep_layout = P->pmajor;
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }

@@ -406,6 +406,16 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
         S.stream_sync()
         assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
                       (tag, "csr panels", variant, waves))
+    if sweep:  # both bucket layouts of the sweep schedule (default: 1)
+        for layout in (0, 1):
+            dA.build_panels(pc, "sweep", sweep_layout=layout)
+            for waves in (0, 4):
+                S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr,
+                          waves_per_block=waves)
+                S.stream_sync()
+                assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                              (tag, "sweep layout", layout, waves))
     for cm in (True, False):
         H = S.csr_to_hll(A, cm)
         dH = S.HllDevice.upload(H, cm)
