@@ -173,6 +173,47 @@ __global__ void k_touch_then_read(const char *__restrict__ buf, size_t region,
         *sink = (int)acc;
 }
 
+/*
+ * How much does the memory side care WHERE 256 persistent workgroups read at
+ * one time?  Every workgroup (512 lanes, one per CU) streams the same number
+ * of bytes in 3-KiB steps per wavefront; only the address pattern differs:
+ *   mode 0  tile-major: workgroup b owns one contiguous 1/256 of the buffer
+ *   mode 1  panel-major: the buffer is cut into `panels` windows; inside a
+ *           window workgroup b owns a contiguous 1/256 (all workgroups are in
+ *           the same window at the same time)
+ *   mode 2  block-major: consecutive 24-KiB steps of ALL workgroups are
+ *           adjacent (the chip reads one dense moving front)
+ */
+__global__ void __launch_bounds__(512)
+    k_where(const char *__restrict__ buf, size_t bytes, int mode, int panels, int *sink) {
+    const size_t per_wg = bytes / gridDim.x;            /* bytes per workgroup */
+    const size_t step = 512 * 16 * 3;                   /* 24 KiB per workgroup step */
+    const size_t nsteps = per_wg / step;
+    const size_t steps_per_panel = nsteps / panels;
+    unsigned acc = 0;
+    for (size_t k = 0; k < nsteps; ++k) {
+        size_t off;
+        if (mode == 0) {
+            off = blockIdx.x * per_wg + k * step;
+        } else if (mode == 1) {
+            const size_t p = k / steps_per_panel, j = k % steps_per_panel;
+            off = p * (steps_per_panel * step * gridDim.x) +
+                  blockIdx.x * (steps_per_panel * step) + j * step;
+        } else {
+            off = (k * gridDim.x + blockIdx.x) * step;
+        }
+        if (off + step > bytes)
+            break;
+        const char *q = buf + off + (size_t)threadIdx.x * 16;
+        u32x4 a = __builtin_nontemporal_load((const u32x4 *)q);
+        u32x4 b = __builtin_nontemporal_load((const u32x4 *)(q + 8192));
+        u32x4 c = __builtin_nontemporal_load((const u32x4 *)(q + 16384));
+        acc += a[0] ^ b[1] ^ c[2];
+    }
+    if (acc == 0x12345678u)
+        *sink = (int)acc;
+}
+
 template <class F> static double time_ms(F f, int iters) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -228,6 +269,17 @@ int main() {
                        wide ? "s_load_dwordx16" : "s_load_dword", stride, wpc, ms,
                        touched / ms / 1e6, bytes / ms / 1e6);
             }
+    {
+        printf("== where 256 persistent workgroups read at one time (2 GiB, 512 lanes each)\n");
+        const char *names[3] = {"tile-major (256 distant streams)",
+                                "panel-major (77 windows)", "block-major (one front)"};
+        for (int mode = 0; mode < 3; ++mode) {
+            double ms = time_ms([&] {
+                hipLaunchKernelGGL(k_where, dim3(cus), dim3(512), 0, 0, buf, bytes, mode, 77, sink);
+            }, 3);
+            printf("%-36s : %8.3f ms  %8.1f GB/s\n", names[mode], ms, bytes / ms / 1e6);
+        }
+    }
     {
         printf("== scalar touch, then vector read of the same 32 KiB (cycles of the read, "
                "mean over 2048 waves, cold regions)\n");
