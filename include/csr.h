@@ -84,6 +84,15 @@ sparse_csr *csr_alloc(const char *name, int M, int N, int NZ);
 sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
                          int64_t row0, uint64_t seed);
 
+/* Result check of a full-size synthetic run without materialising the
+ * matrix: for each of the n GLOBAL rows in `rows`, dot[k] = sum_j a_ij *
+ * synth_x(xseed, col_j) accumulated left to right like the serial CSR kernel
+ * (reference csr.c:201-216) and scale[k] = sum_j |a_ij x_j|.  One serial
+ * call, no OpenMP team (n is a few hundred).  Returns 0 or -EINVAL. */
+int csr_synth_row_dots(int kind, int N, int K, int64_t W, uint64_t seed,
+                       uint64_t xseed, const int64_t *rows, int n,
+                       double *dot, double *scale);
+
 /* Rows [r0, r1) of A as an independent matrix with GLOBAL columns. */
 sparse_csr *csr_row_slice(const sparse_csr *A, int r0, int r1);
 

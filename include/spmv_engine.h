@@ -251,6 +251,12 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
 int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
                       int allow_panels, int *best_kernel, double *best_ms);
 
+/* Handles created and not yet released (CSR + HLL, one-shot calls included
+ * while they run).  spmv_*_release() of a NULL, already released or unknown
+ * handle is ignored -- a binding's finaliser after an explicit release cannot
+ * corrupt the heap -- and a launch on such a handle returns -EBADF. */
+int spmv_live_handles(void);
+
 /* Library self-description: "spmv_scpa_amd <version> gfx950". */
 const char *spmv_version(void);
 

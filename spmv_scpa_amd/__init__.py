@@ -10,9 +10,11 @@ There is no Python or CPU fallback for the GPU path: if the shared library
 is missing the import fails, and without a GPU every ``*_hip`` call raises
 ``OSError(ENODEV)``.
 """
+import atexit
 import ctypes as C
 import os
 import re
+import weakref
 
 import numpy as np
 
@@ -180,6 +182,7 @@ _sig("log_roofline", None, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
 
 # ---------------------------------------------------------------- engine API
 _sig("spmv_version", C.c_char_p)
+_sig("spmv_live_handles", C.c_int)
 _sig("spmv_device_count", C.c_int)
 _sig("spmv_set_device", C.c_int, C.c_int)
 _sig("spmv_get_device", C.c_int)
@@ -578,15 +581,67 @@ def bench_hll_hip(H, x, kernel, waves_per_block=4):
 
 
 # ---------------------------------------------------------------- persistent
+# Lifetime of device objects.  Every DevBuffer / CsrDevice / HllDevice /
+# MultiGpu is entered in `_live` (weak references).  Objects still alive when
+# the interpreter exits -- a failed test's traceback holds its locals until
+# then -- are NOT left to `__del__` during interpreter finalisation, where
+# module globals are being cleared in no particular order and the HIP / RCCL
+# runtimes may already be unloading (round 2: `double free or corruption` at
+# the exit of a GPU test process whose handles had not been released).  An
+# atexit hook releases them first, in dependency order (multi-GPU handles
+# with their communicators, then matrices, then raw buffers), while the
+# runtime is fully up; afterwards `_closed` is set and every finaliser is a
+# no-op.  The library ignores a second release of a handle (engine.hip,
+# live_take), so an explicit release() racing a finaliser is harmless too.
+_live = weakref.WeakSet()
+_closed = False
+
+
+def live_objects():
+    """device objects created through this module and not yet released"""
+    return [o for o in list(_live) if not o._released()]
+
+
+def release_all():
+    """release every live device object, dependents first; idempotent"""
+    objs = live_objects()
+    for cls_rank in (2, 1, 0):
+        for o in objs:
+            if o._RANK == cls_rank:
+                try:
+                    o._release_now()
+                except Exception:  # noqa: BLE001 - keep releasing the rest
+                    pass
+
+
+def _at_exit():
+    global _closed
+    try:
+        release_all()
+    finally:
+        _closed = True
+
+
+atexit.register(_at_exit)
+
+
 class DevBuffer:
     """Raw device allocation (for hosts that do not bring torch tensors)."""
 
     ptr = None
+    _RANK = 0
 
     def __init__(self, nbytes):
         p = C.c_void_p()
         _check(_lib.spmv_dev_malloc(C.byref(p), nbytes), "spmv_dev_malloc")
         self.ptr, self.nbytes = p.value, nbytes
+        _live.add(self)
+
+    def _released(self):
+        return not self.ptr
+
+    def _release_now(self):
+        self.free()
 
     @classmethod
     def from_numpy(cls, a):
@@ -603,12 +658,13 @@ class DevBuffer:
         return out
 
     def free(self):
-        if self.ptr and _lib is not None:  # None at interpreter shutdown
-            _lib.spmv_dev_free(self.ptr)
-        self.ptr = None
+        ptr, self.ptr = self.ptr, None
+        if ptr and _closed is False and _lib is not None:
+            _lib.spmv_dev_free(ptr)
 
     def __del__(self):
-        self.free()
+        if _closed is False:  # None / True at or after interpreter shutdown
+            self.free()
 
 
 def dev_fill_synth(ptr, n, seed, first=0, stream=None):
@@ -624,12 +680,20 @@ class CsrDevice:
     """A CSR matrix resident in HBM (spmv_engine.h, spmv_csr_dev)."""
 
     h = None
+    _RANK = 1
 
     def __init__(self, handle):
         self.h = handle
         M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
         _lib.spmv_csr_shape(self.h, C.byref(M), C.byref(N), C.byref(NZ))
         self.M, self.N, self.NZ = M.value, N.value, NZ.value
+        _live.add(self)
+
+    def _released(self):
+        return not self.h
+
+    def _release_now(self):
+        self.release()
 
     @classmethod
     def upload(cls, A):
@@ -726,21 +790,30 @@ class CsrDevice:
         return HllDevice(h)
 
     def release(self):
-        if self.h and _lib is not None:  # None at interpreter shutdown
-            _lib.spmv_csr_release(self.h)
-        self.h = None
+        h, self.h = self.h, None
+        if h and _closed is False and _lib is not None:
+            _lib.spmv_csr_release(h)
 
     def __del__(self):
-        self.release()
+        if _closed is False:  # None / True at or after interpreter shutdown
+            self.release()
 
 
 class HllDevice:
     """An HLL matrix resident in HBM (spmv_engine.h, spmv_hll_dev)."""
 
     h = None
+    _RANK = 1
+
+    def _released(self):
+        return not self.h
+
+    def _release_now(self):
+        self.release()
 
     def __init__(self, handle):
         self.h = handle
+        _live.add(self)
         M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
         nb, S, cm = C.c_int(), C.c_int64(), C.c_int()
         _lib.spmv_hll_shape(self.h, C.byref(M), C.byref(N), C.byref(NZ),
@@ -827,12 +900,13 @@ class HllDevice:
         return ms[:iters]
 
     def release(self):
-        if self.h and _lib is not None:
-            _lib.spmv_hll_release(self.h)
-        self.h = None
+        h, self.h = self.h, None
+        if h and _closed is False and _lib is not None:
+            _lib.spmv_hll_release(h)
 
     def __del__(self):
-        self.release()
+        if _closed is False:  # None / True at or after interpreter shutdown
+            self.release()
 
 
 # ---------------------------------------------------------------- vectors
@@ -883,11 +957,19 @@ class MultiGpu:
     all-gather of y, as the C driver's `-g N` runs it."""
 
     h = None
+    _RANK = 2
 
     def __init__(self, ngpus):
         h = C.c_void_p()
         _check(_lib.spmv_mgpu_create(ngpus, C.byref(h)), "spmv_mgpu_create")
         self.h, self.n = h, ngpus
+        _live.add(self)
+
+    def _released(self):
+        return not self.h
+
+    def _release_now(self):
+        self.destroy()
 
     def load_csr(self, A, as_hll=False):
         _check(_lib.spmv_mgpu_load_csr(self.h, A, int(as_hll)),
@@ -926,12 +1008,13 @@ class MultiGpu:
         return y
 
     def destroy(self):
-        if self.h and _lib is not None:
-            _lib.spmv_mgpu_destroy(self.h)
-        self.h = None
+        h, self.h = self.h, None
+        if h and _closed is False and _lib is not None:
+            _lib.spmv_mgpu_destroy(h)
 
     def __del__(self):
-        self.destroy()
+        if _closed is False:  # None / True at or after interpreter shutdown
+            self.destroy()
 
 
 # experiment knob of the harness (tools/README.md): the library reads no

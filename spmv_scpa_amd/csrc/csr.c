@@ -9,6 +9,7 @@
  */
 #include <errno.h>
 #include <limits.h>
+#include <math.h>
 #include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -703,7 +704,10 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
     if (kind == SYNTH_BANDED || kind == SYNTH_RANDOM) {
         nz = (long long)M * K;
     } else {
-#pragma omp parallel for schedule(static) reduction(+ : nz)
+/* a team is opened only for work that pays for it: bench.py's result
+         * check regenerates single rows, and a full-width team per 1-row call
+         * burned a 16-CPU cgroup quota on a 256-thread host */
+#pragma omp parallel for schedule(static) reduction(+ : nz) if (M > 4096)
         for (int i = 0; i < M; ++i)
             nz += synth_row_len(&s, row0 + i);
     }
@@ -717,11 +721,53 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
         return A;
     for (int i = 0; i < M; ++i)
         A->IRP[i + 1] = A->IRP[i] + synth_row_len(&s, row0 + i);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) if (M > 4096)
     for (int i = 0; i < M; ++i)
         synth_fill_row(&s, row0 + i, A->IRP[i + 1] - A->IRP[i],
                        A->JA + A->IRP[i], A->AS + A->IRP[i]);
     return A;
+}
+
+int csr_synth_row_dots(int kind, int N, int K, int64_t W, uint64_t seed,
+                       uint64_t xseed, const int64_t *rows, int n,
+                       double *dot, double *scale) {
+    if (N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_STENCIL ||
+        (kind == SYNTH_BANDED && N < K) || n < 0 || (n && (!rows || !dot)))
+        return -EINVAL;
+    synth_spec s = {kind, 1, N, K, W, 0, seed};
+    int cap = 64;
+    int *cols = (int *)malloc((size_t)cap * sizeof(int));
+    double *vals = (double *)malloc((size_t)cap * sizeof(double));
+    int rc = cols && vals ? 0 : -ENOMEM;
+    for (int k = 0; k < n && !rc; ++k) {
+        const int len = synth_row_len(&s, rows[k]);
+        if (len > cap) {
+            cap = len;
+            int *c2 = (int *)realloc(cols, (size_t)cap * sizeof(int));
+            if (c2)
+                cols = c2;
+            double *v2 = (double *)realloc(vals, (size_t)cap * sizeof(double));
+            if (v2)
+                vals = v2;
+            if (!c2 || !v2) {
+                rc = -ENOMEM;
+                break;
+            }
+        }
+        synth_fill_row(&s, rows[k], len, cols, vals);
+        double acc = 0.0, sab = 0.0;
+        for (int j = 0; j < len; ++j) {
+            const double p = vals[j] * synth_x(xseed, cols[j]);
+            acc += p;
+            sab += fabs(p);
+        }
+        dot[k] = acc;
+        if (scale)
+            scale[k] = sab;
+    }
+    free(cols);
+    free(vals);
+    return rc;
 }
 
 sparse_csr *csr_row_slice(const sparse_csr *A, int r0, int r1) {

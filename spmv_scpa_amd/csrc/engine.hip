@@ -8,9 +8,11 @@
  * entry point returns -ENODEV.
  */
 #include <algorithm>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unordered_set>
 #include <vector>
 
 #include "err.h"
@@ -21,6 +23,39 @@
 
 int g_csr_waves = 8; /* 512-lane workgroups measured best on MI355X */
 int g_hll_waves = 8;
+
+/*
+ * Live handles.  spmv_csr_release / spmv_hll_release free host memory
+ * (free(d), the blocked copy's descriptor): a binding that released a handle
+ * twice -- an explicit release() followed by a finaliser, two wrappers around
+ * one handle, a finaliser running after an atexit sweep -- would corrupt the
+ * host heap ("double free or corruption", the abort of round 2's GPU test
+ * process).  Every handle is therefore entered here when it is created and a
+ * release of anything that is not (or no longer) in the set is ignored.  The
+ * set and its mutex are heap objects that are never destroyed, so a release
+ * that arrives during static destruction still finds them.
+ */
+struct live_set {
+    std::mutex mu;
+    std::unordered_set<const void *> handles;
+};
+static live_set &live(void) {
+    static live_set *s = new live_set();
+    return *s;
+}
+static void live_add(const void *h) {
+    std::lock_guard<std::mutex> g(live().mu);
+    live().handles.insert(h);
+}
+/* true exactly once per handle: the caller then owns the teardown */
+static bool live_take(const void *h) {
+    std::lock_guard<std::mutex> g(live().mu);
+    return live().handles.erase(h) == 1;
+}
+static bool live_has(const void *h) {
+    std::lock_guard<std::mutex> g(live().mu);
+    return live().handles.count(h) == 1;
+}
 
 /*
  * The 2-D blocked path as a candidate.  `*bms` is the best direct kernel's
@@ -170,6 +205,11 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
 extern "C" {
 
 const char *spmv_version(void) { return "spmv_scpa_amd 0.1 gfx950"; }
+
+int spmv_live_handles(void) {
+    std::lock_guard<std::mutex> g(live().mu);
+    return (int)live().handles.size();
+}
 
 void set_csr_waves_per_block(int waves) {
     g_csr_waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
@@ -427,8 +467,8 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
 /* ------------------------------------------------------------------ */
 
 void spmv_csr_release(spmv_csr_dev *d) {
-    if (!d)
-        return;
+    if (!d || !live_take(d))
+        return; /* NULL, released before, or never a handle: ignored */
     (void)hipFree(d->irp);
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
@@ -443,6 +483,7 @@ static int csr_alloc_dev(int M, int N, int64_t NZ, spmv_csr_dev **out) {
     spmv_csr_dev *d = (spmv_csr_dev *)calloc(1, sizeof *d);
     if (!d)
         return -ENOMEM;
+    live_add(d);
     d->M = M;
     d->N = N;
     d->NZ = NZ;
@@ -769,6 +810,8 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          void *stream) {
     if (!A)
         return -EINVAL;
+    if (!live_has(A))
+        return -EBADF; /* released (or never a) handle */
     if (kernel == SPMV_CSR_KERNEL_PANELS) {
         if (!A->panels || row_begin != 0 || row_end != A->M)
             return -EINVAL; /* build panels first; whole matrix only */
@@ -790,6 +833,8 @@ int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
                     double *d_y, void *stream) {
     if (!A)
         return -EINVAL;
+    if (!live_has(A))
+        return -EBADF;
     return spmv_csr_launch_rows(A, kernel, opts, d_x, d_y, 0, A->M, stream);
 }
 
@@ -798,8 +843,8 @@ int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
 /* ------------------------------------------------------------------ */
 
 void spmv_hll_release(spmv_hll_dev *d) {
-    if (!d)
-        return;
+    if (!d || !live_take(d))
+        return; /* NULL, released before, or never a handle: ignored */
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->off);
@@ -814,6 +859,7 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
     spmv_hll_dev *d = (spmv_hll_dev *)calloc(1, sizeof *d);
     if (!d)
         return -ENOMEM;
+    live_add(d);
     d->M = M;
     d->N = N;
     d->NZ = NZ;
@@ -989,6 +1035,8 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                            void *stream) {
     if (!H)
         return -EINVAL;
+    if (!live_has(H))
+        return -EBADF; /* released (or never a) handle */
     int waves = pick_waves(opts, g_hll_waves);
     if (kernel == SPMV_HLL_KERNEL_PANELS) {
         if (!H->panels || blk_begin != 0 || blk_end != H->nb)
@@ -1011,6 +1059,8 @@ int spmv_hll_launch(const spmv_hll_dev *H, int kernel,
                     double *d_y, void *stream) {
     if (!H)
         return -EINVAL;
+    if (!live_has(H))
+        return -EBADF;
     return spmv_hll_launch_blocks(H, kernel, opts, d_x, d_y, 0, H->nb, stream);
 }
 

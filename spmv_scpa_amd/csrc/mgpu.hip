@@ -11,6 +11,7 @@
  * bench.py does the same with one process per GPU through torch.distributed;
  * this is the path of `spmv_scpa_amd -g N`.
  */
+#include <mutex>
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,6 +34,28 @@ struct spmv_mgpu {
     std::vector<spmv_hll_dev *> hll;
     std::vector<double *> x, y;
 };
+
+/* live multi-GPU handles: a second destroy of one handle is ignored (same
+ * contract as spmv_*_release, engine.hip); never destroyed objects */
+static std::mutex &mg_mu(void) {
+    static std::mutex *m = new std::mutex();
+    return *m;
+}
+static std::vector<const spmv_mgpu *> &mg_live(void) {
+    static std::vector<const spmv_mgpu *> *v =
+        new std::vector<const spmv_mgpu *>();
+    return *v;
+}
+static bool mg_take(const spmv_mgpu *g) {
+    std::lock_guard<std::mutex> lk(mg_mu());
+    std::vector<const spmv_mgpu *> &v = mg_live();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == g) {
+            v.erase(v.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
 
 static int nccl_errno(ncclResult_t r) {
     return r == ncclSuccess ? 0 : (r == ncclSystemError ? -EIO : -EINVAL);
@@ -80,8 +103,8 @@ static void drop_shards(spmv_mgpu *g) {
 extern "C" {
 
 void spmv_mgpu_destroy(spmv_mgpu *g) {
-    if (!g)
-        return;
+    if (!g || !mg_take(g))
+        return; /* NULL or destroyed before: ignored */
     device_guard keep;
     drop_shards(g);
     for (int r = 0; r < g->n; ++r) {
@@ -103,6 +126,10 @@ int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
     int rc = 0;
     device_guard keep;
     spmv_mgpu *g = new spmv_mgpu();
+    {
+        std::lock_guard<std::mutex> lk(mg_mu());
+        mg_live().push_back(g);
+    }
     g->n = ngpus;
     g->rows_per_gpu = g->M = g->N = g->is_hll = 0;
     g->dev.resize(ngpus);

@@ -1,0 +1,120 @@
+"""Process exit with device objects still alive ("double free or
+corruption" at the exit of a GPU test process after a failed test).
+
+A failed test's traceback keeps the test's locals -- an autotuned HllDevice
+carrying a blocked copy, two DevBuffers -- alive until the interpreter exits.
+Each case below is a CHILD process that ends in exactly such a state without
+releasing anything; it must exit 0 and print nothing that smells of heap
+corruption.  The child runs with tools/abort_trace.c preloaded, so a native
+abort would name its stack in the assertion message.
+
+What makes the exit safe (spmv_scpa_amd/__init__.py, engine.hip): an atexit
+hook releases live objects in dependency order while the HIP runtime is up,
+finalisers are no-ops afterwards, and the library ignores a second release of
+a handle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import spmv_scpa_amd as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import faulthandler, sys
+faulthandler.enable()
+sys.path.insert(0, %(root)r)
+import spmv_scpa_amd as S
+
+def build():
+    # columns anywhere: the selector leaves the direct kernels for the
+    # blocked path (tune_blocked swaps keep / cand / original copies)
+    M, N = 2_000_000, 16_000_000
+    dA = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 32, 1 << 30, 0, 42)
+    dH = dA.to_hll(True)
+    dA.release()
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    best, ms = dH.autotune(d_x.ptr, d_y.ptr)
+    assert best == S.HLL_KERNEL_PANELS, best
+    dH.launch(best, d_x.ptr, d_y.ptr)
+    S.stream_sync()
+    return dH, d_x, d_y
+
+mode = sys.argv[1]
+kept = []
+if mode == "globals":          # module globals, torn down at finalisation
+    dH, d_x, d_y = build()
+elif mode == "traceback":      # what pytest keeps of a failed test
+    def failing_test():
+        dH, d_x, d_y = build()
+        like = S.CsrDevice.generate(S.SYNTH_BANDED, 100_000, 100_000, 16, 0, 0, 42)
+        raise AssertionError("the test fails before release()")
+    try:
+        failing_test()
+    except AssertionError:
+        kept.append(sys.exc_info())
+elif mode == "cycle":          # garbage only the cycle collector can free
+    class Box:
+        pass
+    b = Box()
+    b.me, b.objs = b, build()
+    del b
+elif mode == "double":         # explicit release, then finalisers again
+    dH, d_x, d_y = build()
+    h = dH.h
+    dH.release()
+    S._lib.spmv_hll_release(h)         # ignored by the library (live_take)
+    assert S._lib.spmv_live_handles() == 0
+    dH2 = S.HllDevice.__new__(S.HllDevice)
+    dH2.h = h                          # a second wrapper of a dead handle
+    assert S._lib.spmv_hll_launch(h, 1, None, d_x.ptr, d_y.ptr, None) == -9
+elif mode == "mgpu":           # communicator + shards left alive
+    g = S.MultiGpu(1)
+    g.generate(S.SYNTH_RANDOM, 64_000, 32, 4096)
+    g.fill_x()
+    g.spmv(-1, 1, 2)
+print("child-ok", mode, len(S.live_objects()), S._lib.spmv_live_handles())
+"""
+
+BAD = ("double free", "corruption", "core dumped", "Aborted", "abort_trace",
+       "Segmentation", "Fatal Python error", "free():", "munmap_chunk",
+       "malloc():")
+
+
+@pytest.mark.parametrize("mode", ["globals", "traceback", "cycle", "double",
+                                  "mgpu"])
+def test_exit_with_live_device_objects_is_clean(mode, tmp_path):
+    script = tmp_path / "child.py"
+    script.write_text(CHILD % {"root": ROOT})
+    env = dict(os.environ)
+    pre = os.path.join(ROOT, "spmv_scpa_amd", "bin", "libabort_trace.so")
+    if os.path.exists(pre):
+        env["LD_PRELOAD"] = pre
+    r = subprocess.run([sys.executable, str(script), mode],
+                       capture_output=True, text=True, timeout=600, env=env)
+    tail = (r.stdout + "\n---- stderr ----\n" + r.stderr)[-4000:]
+    assert r.returncode == 0, tail
+    assert "child-ok " + mode in r.stdout, tail
+    for word in BAD:
+        assert word not in r.stderr, tail
+
+
+def test_release_is_idempotent_and_counted():
+    """in-process: a handle released explicitly is gone from the library's
+    live set, a second release (wrapper or raw) changes nothing"""
+    before = S._lib.spmv_live_handles()
+    dA = S.CsrDevice.generate(S.SYNTH_BANDED, 50_000, 50_000, 16, 0, 0, 42)
+    dH = dA.to_hll(True)
+    assert S._lib.spmv_live_handles() == before + 2
+    raw = dH.h
+    dH.release()
+    dH.release()
+    S._lib.spmv_hll_release(raw)
+    assert S._lib.spmv_live_handles() == before + 1
+    dA.release()
+    assert S._lib.spmv_live_handles() == before
+    assert dA not in S.live_objects() and dH not in S.live_objects()

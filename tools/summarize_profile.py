@@ -142,7 +142,11 @@ def main():
                   "source": os.path.basename(dst),
                   "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests "
                                 "at 64 B; calibrated on tools/microbench)",
-                  "workload": cfg["workload"], "bench_kernel": cfg["kernel"]}
+                  "workload": cfg["workload"], "bench_kernel": cfg["kernel"],
+                  # bench.py refuses a profile taken with another build of
+                  # the kernel's source file (measured_traffic)
+                  "kernel_source": cfg.get("kernel_source"),
+                  "blocked_schedule": cfg.get("blocked_schedule")}
             json.dump(tj, open(dst[:-3] + ".traffic.json", "w"), indent=1)
             out += ["## bench.py's timed kernel", "",
                     "`%s`, last %d launches (%d per SpMV): %.4g B read + %.4g B "
