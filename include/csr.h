@@ -68,6 +68,12 @@ sparse_csr *io_load_csr(const char *path);
  * JA in [0, N)): csr_load_bin returns ERR_PTR(-EINVAL) for a foreign header,
  * -EIO for a truncated file, -EILSEQ for arrays that are not a CSR matrix,
  * -ESTALE (cached path only, then re-parsed) for another file's sidecar.
+ *
+ * Contract for writers of .mtx files: write under a temporary name and
+ * rename() into place.  io_load_csr maps the text (MAP_PRIVATE); a file that
+ * is truncated or rewritten in place while a loader parses it would end that
+ * loader with SIGBUS.  (A file modified within the last two seconds is read
+ * into memory instead of mapped, as a second line of defence.)
  */
 int csr_save_bin(const sparse_csr *A, const char *path);
 sparse_csr *csr_load_bin(const char *path);

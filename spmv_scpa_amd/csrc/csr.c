@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -192,8 +193,18 @@ static int image_open(const char *path, struct file_image *im) {
         return -errno;
     struct stat st;
     const long page = sysconf(_SC_PAGESIZE);
+    /* A mapped file that another process truncates or rewrites while the
+     * tokenisers run ends the loader with SIGBUS instead of an error code.
+     * Writers are required to write under a temporary name and rename
+     * (include/csr.h; tools/gen_kkt_mtx.c callers and the sidecar writer do);
+     * as a second line of defence a file modified within the last two
+     * seconds -- possibly still being written -- is READ, not mapped: a
+     * short read is an ordinary -EIO / parse error. */
+    struct timespec now;
+    clock_gettime(CLOCK_REALTIME, &now);
     if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 &&
-        page > 0 && (st.st_size % page) != 0) {
+        page > 0 && (st.st_size % page) != 0 &&
+        now.tv_sec - st.st_mtim.tv_sec > 2) {
         void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m != MAP_FAILED) {
             close(fd);
@@ -541,20 +552,24 @@ static int csr_write_bin(const sparse_csr *A, const char *path,
     h.src_mtime_sec = src ? (int64_t)src->st_mtim.tv_sec : 0;
     h.src_mtime_nsec = src ? (int64_t)src->st_mtim.tv_nsec : 0;
     memcpy(h.name, A->name, MAX_NAME);
-    int ok = fwrite(&h, sizeof h, 1, f) == 1 &&
-             fwrite(A->IRP, sizeof(int), (size_t)A->M + 1, f) == (size_t)A->M + 1 &&
-             fwrite(A->JA, sizeof(int), (size_t)A->NZ, f) == (size_t)A->NZ &&
-             fwrite(A->AS, sizeof(double), (size_t)A->NZ, f) == (size_t)A->NZ;
-    if (fclose(f) != 0)
-        ok = 0;
-    if (ok && rename(tmp, path) != 0)
-        ok = 0;
-    if (!ok) {
-        int e = errno ? -errno : -EIO;
+    /* the error code is taken AT the failing call (errno of an earlier,
+     * unrelated failure must not leak into the result) */
+    int err = 0;
+    errno = 0;
+    if (fwrite(&h, sizeof h, 1, f) != 1 ||
+        fwrite(A->IRP, sizeof(int), (size_t)A->M + 1, f) != (size_t)A->M + 1 ||
+        fwrite(A->JA, sizeof(int), (size_t)A->NZ, f) != (size_t)A->NZ ||
+        fwrite(A->AS, sizeof(double), (size_t)A->NZ, f) != (size_t)A->NZ)
+        err = errno ? -errno : -EIO;
+    errno = 0;
+    if (fclose(f) != 0 && !err)
+        err = errno ? -errno : -EIO;
+    errno = 0;
+    if (!err && rename(tmp, path) != 0)
+        err = errno ? -errno : -EIO;
+    if (err)
         (void)remove(tmp);
-        return e == 0 ? -EIO : e;
-    }
-    return 0;
+    return err;
 }
 
 int csr_save_bin(const sparse_csr *A, const char *path) {

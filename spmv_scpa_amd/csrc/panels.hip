@@ -621,22 +621,29 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             (void)hipFree(t2);
             HIP_TRY(e2);
         }
-        HIP_TRY(hipMalloc((void **)&P->cb,
-                          ((size_t)buckets + 1) * 2 * sizeof(int64_t)));
-        HIP_TRY(hipMalloc((void **)&P->cpanel,
-                          ((size_t)buckets + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc((void **)&P->nbk, ((size_t)tiles + 1) * sizeof(int)));
-        HIP_TRY(hipMemset(P->nbk + tiles, 0, sizeof(int)));
-        if (tiles > 0 && !sweep) { /* the sweep kernel reads bptr / blen only */
-            hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
-                               dim3(256), 0, 0, tiles, panels, P->bptr, P->blen,
-                               P->cb, P->cpanel, P->nbk);
-            hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, 0, tiles,
-                               P->nbk, P->nbk + tiles);
-            HIP_TRY(hipGetLastError());
+        /* compacted per-tile bucket lists of the chain / steps schedules.
+         * A sweep copy has none (its kernel reads bptr / blen only): cb,
+         * cpanel and nbk stay NULL and panels_launch / the setters refuse to
+         * run such a copy in another schedule. */
+        if (!sweep) {
+            HIP_TRY(hipMalloc((void **)&P->cb,
+                              ((size_t)buckets + 1) * 2 * sizeof(int64_t)));
+            HIP_TRY(hipMalloc((void **)&P->cpanel,
+                              ((size_t)buckets + 1) * sizeof(int)));
+            HIP_TRY(hipMalloc((void **)&P->nbk,
+                              ((size_t)tiles + 1) * sizeof(int)));
+            HIP_TRY(hipMemset(P->nbk, 0, ((size_t)tiles + 1) * sizeof(int)));
+            if (tiles > 0) {
+                hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
+                                   dim3(256), 0, 0, tiles, panels, P->bptr,
+                                   P->blen, P->cb, P->cpanel, P->nbk);
+                hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, 0, tiles,
+                                   P->nbk, P->nbk + tiles);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipMemcpy(&P->max_nbk, P->nbk + tiles, sizeof(int),
+                              hipMemcpyDeviceToHost));
         }
-        HIP_TRY(hipMemcpy(&P->max_nbk, P->nbk + tiles, sizeof(int),
-                          hipMemcpyDeviceToHost));
         /* dropped slots sort behind the last bucket */
         HIP_TRY(hipMemcpy(&P->nnz, raw + buckets, sizeof(int64_t),
                           hipMemcpyDeviceToHost));
@@ -1309,6 +1316,8 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     }
     if (P->tiles <= 0 || P->xcd_max <= 0)
         return 0;
+    if (!P->cb || !P->cpanel || !P->nbk)
+        return -EINVAL; /* not a chain / steps copy */
     xcd_ranges xr;
     memcpy(xr.first, P->xcd_first, sizeof xr.first);
     /* Which tile a workgroup runs (workgroups are dealt to the XCDs

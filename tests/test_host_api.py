@@ -307,11 +307,19 @@ def test_parallel_loader_equals_oracle(tmp_path, sym, pattern):
     _write_big_mtx(p, 5000, 5000, 150_000, sym, pattern)
     rc, M, N, NZ, IRP, JA, AS = O.load_mtx(p)
     assert rc == 0
-    A = S.io_load_csr(p)
+    A = S.io_load_csr(p)  # just written: read into memory, not mapped
     gI, gJ, gA = S.csr_arrays(A)
     assert A.contents.NZ == NZ
     assert np.array_equal(gI, IRP) and np.array_equal(gJ, JA)
     assert np.array_equal(bits(gA), bits(AS))
+    # a file at rest (mtime > 2 s ago) is mapped: same result either way
+    past = os.stat(p).st_mtime - 60
+    os.utime(p, (past, past))
+    A2 = S.io_load_csr(p)
+    mI, mJ, mA = S.csr_arrays(A2)
+    assert np.array_equal(mI, IRP) and np.array_equal(mJ, JA)
+    assert np.array_equal(bits(mA), bits(AS))
+    S.csr_free(A2)
     # binary sidecar round trip + cached loader
     S.csr_save_bin(A, p + ".bin")
     B = S.csr_load_bin(p + ".bin")
