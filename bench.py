@@ -456,7 +456,7 @@ def window_variants(S, torch, x, y, Mloc, Nglob, K, fmt_family):
             b = dH.algorithmic_bytes
             out[tag] = {
                 "kernel": kname,
-                "schedule": dH.panels_schedule()
+                "layout": dH.panels_describe()
                 if best == S.HLL_KERNEL_PANELS else None,
                 "kernel_ms": round(float(np.mean(ms)), 5),
                 "gflops": round(2.0 * dH.NZ / (float(np.mean(ms)) * 1e6), 1),
@@ -636,6 +636,8 @@ def single_matrix_bench(args, S, torch, dev):
                         "kernel_choice": "autotuned (spmv_csr_autotune)"
                         if tuned is not None else "fixed by --kernel",
                         "blocked_schedule": dA.panels_schedule()
+                        if kernel == S.CSR_KERNEL_PANELS else None,
+                        "blocked_layout": dA.panels_describe()
                         if kernel == S.CSR_KERNEL_PANELS else None,
                         "kernel_source": dict(zip(("file", "blob"),
                                                   kernel_source_blob(kname))),
@@ -1131,6 +1133,7 @@ def main(argv=None):
             "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
             if tuned is not None else "fixed by --kernel",
             "blocked_schedule": mat.panels_schedule() if blocked else None,
+            "blocked_layout": mat.panels_describe() if blocked else None,
             "kernel_source": dict(zip(("file", "blob"),
                                       kernel_source_blob(kname))),
             "kernel_launches_per_step": launches_per_step,
@@ -1213,7 +1216,9 @@ def strong_leg(args, S, D, torch, dist, dev, rank, world, kernel, model,
     Returns a small dict; any failure is reported, never fatal."""
     rows, total = args.rows_per_gpu, 8 * args.rows_per_gpu
     try:
-        one_ms, one_src = strong_one_gpu()
+        # the committed denominator is the FULL-size problem's
+        one_ms, one_src = (strong_one_gpu() if rows == ROWS_PER_GPU else
+                           (None, "not the 10M-rows-per-shard problem"))
         if world == 8 and Mglob_weak == total:
             return {"problem": "80M x 80M, 8 shards of 10M rows: identical to "
                                "this line's workload at N = 8",

@@ -129,6 +129,14 @@ typedef struct spmv_panel_opts {
                              chip reads at one time is one compact region).
                              NOTE: the only field whose "default" is -1; a
                              zero-initialised struct asks for layout 0 */
+    int bucket_order;     /* steps / chain, the order in which a tile visits
+                             its non-empty buckets: 0 = default (ascending
+                             panels; for banded matrices -- every tile's
+                             panels within a span K of at most half of all
+                             panels -- ascending (panel mod K), so that the
+                             neighbouring tiles an XCD runs together sit on
+                             at most two panels of x at a time), 1 = always
+                             ascending panels */
 } spmv_panel_opts;
 
 /* ---- CSR handle ---- */
@@ -172,6 +180,9 @@ int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model);
 /* schedule of the blocked copy: 0 steps, 1 sweep, 2 chain; -ENOENT if none */
 int spmv_csr_panels_schedule(const spmv_csr_dev *A);
 int spmv_csr_panels_tile_rows(const spmv_csr_dev *A); /* -ENOENT if none */
+/* one line of text: schedule, tiles x rows, panels x columns, bucket order,
+ * launch shape of the blocked copy; -ENOENT if none */
+int spmv_csr_panels_describe(const spmv_csr_dev *A, char *buf, size_t len);
 /* blocked copy in an explicit schedule (0 steps, 1 sweep, 2 chain) and tile
  * height (0: default; sweep sizes its own tiles): the ranks of a multi-GPU
  * job build what rank 0 tuned */
@@ -216,6 +227,7 @@ int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model);
 int spmv_hll_panels_schedule(const spmv_hll_dev *H);
 int spmv_hll_panels_tile_rows(const spmv_hll_dev *H);
+int spmv_hll_panels_describe(const spmv_hll_dev *H, char *buf, size_t len);
 int spmv_hll_build_panels_as(spmv_hll_dev *H, int panel_cols, int sched,
                              int tile_rows);
 int spmv_hll_release_source(spmv_hll_dev *H);
@@ -229,7 +241,10 @@ void spmv_hll_release(spmv_hll_dev *H);
  * bracketed by its own hipEvent pair on `stream`; ms_each[iters] receives
  * the per-launch kernel times.  flush_bytes > 0 streams a scratch buffer of
  * that size between iterations (outside the timed region) so that matrices
- * smaller than the 256 MiB Infinity Cache are read from HBM.
+ * smaller than the 256 MiB Infinity Cache are read from HBM.  The sweep only
+ * READS the scratch buffer (no dirty lines whose write-back would overlap the
+ * timed launch); opts.variant bit 29 selects the read-modify-write sweep of
+ * rounds 1 / 2 for comparison.
  */
 int spmv_csr_time(const spmv_csr_dev *A, int kernel,
                   const spmv_launch_opts *opts, const double *d_x, double *d_y,

@@ -97,7 +97,8 @@ class PanelOpts(C.Structure):
     _fields_ = [("sched", C.c_int), ("panel_cols", C.c_int),
                 ("tile_rows", C.c_int), ("sweep_wgs_per_cu", C.c_int),
                 ("reserve_cus", C.c_int), ("lds_min", C.c_int),
-                ("tile_order", C.c_int), ("sweep_layout", C.c_int)]
+                ("tile_order", C.c_int), ("sweep_layout", C.c_int),
+                ("bucket_order", C.c_int)]
 
 
 _CSRp = C.POINTER(SparseCSR)
@@ -218,6 +219,8 @@ _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
 _sig("spmv_csr_build_panels_opts", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_hll_build_panels_opts", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_csr_panels_describe", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t)
+_sig("spmv_hll_panels_describe", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t)
 _sig("spmv_csr_panels_tile_rows", C.c_int, C.c_void_p)
 _sig("spmv_hll_panels_tile_rows", C.c_int, C.c_void_p)
 _sig("spmv_csr_build_panels_as", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -343,6 +346,7 @@ def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
         ev = os.environ.get("SPMV_SWEEP_LAYOUT", "")
         sweep_layout = int(ev) if ev in ("0", "1") else -1
     o.sweep_layout = sweep_layout
+    o.bucket_order = _env_int("SPMV_BUCKET_ORDER", 0, 1)
     return o
 
 
@@ -749,6 +753,13 @@ class CsrDevice:
         rc = _lib.spmv_csr_panels_tile_rows(self.h)
         return None if rc < 0 else rc
 
+    def panels_describe(self):
+        """one line: schedule, geometry, bucket order, launch shape; None
+        when no blocked copy is built"""
+        buf = C.create_string_buffer(256)
+        rc = _lib.spmv_csr_panels_describe(self.h, buf, 256)
+        return None if rc else buf.value.decode()
+
     def build_panels_like(self, model):
         _check(_lib.spmv_csr_build_panels_like(self.h, model.h),
                "spmv_csr_build_panels_like")
@@ -845,6 +856,13 @@ class HllDevice:
     def panels_tile_rows(self):
         rc = _lib.spmv_hll_panels_tile_rows(self.h)
         return None if rc < 0 else rc
+
+    def panels_describe(self):
+        """one line: schedule, geometry, bucket order, launch shape; None
+        when no blocked copy is built"""
+        buf = C.create_string_buffer(256)
+        rc = _lib.spmv_hll_panels_describe(self.h, buf, 256)
+        return None if rc else buf.value.decode()
 
     def build_panels_like(self, model):
         _check(_lib.spmv_hll_build_panels_like(self.h, model.h),

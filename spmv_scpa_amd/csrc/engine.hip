@@ -106,7 +106,7 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
              * faster (W = 2^20 at 20448 rows: 0.80 vs 0.86 ms; W = N: 1.77
              * vs 1.63) */
             for (int waves = 0; waves <= (sched == 0 && chain &&
-                                          tile_rows >= 16384 ? 16 : 0);
+                                          tile_rows >= 12288 ? 16 : 0);
                  waves += 16) {
                 panels_set_waves(cand, waves);
                 double m = 0.0;
@@ -180,14 +180,22 @@ static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
     if (!err)
         try_one(0, t1);
     const double m1 = last_m;
-    if (!err && t2)
-        try_one(0, t2);
-    /* taller still (160 KiB of LDS, one workgroup per CU) when height paid,
-     * shorter still when it cost (nlpkkt160-shaped KKT matrix: 0.525 ms at
-     * 8192 rows, 0.596 at 16384) */
-    if (!err && t2 == 16384 && last_m < m1)
-        try_one(0, 20448);
-    else if (!err && t2 == 16384 && m1 < last_m)
+    /* tall tiles run one workgroup per CU, so their height is balanced over
+     * whole rounds of the chip (panels_balanced_tile_rows): 13024 rows
+     * instead of 16384, 19552 instead of 20448 at 10M rows */
+    const int tall2 = t2 == 16384 ? panels_balanced_tile_rows(M, 16384) : t2;
+    const int tall3 = t2 == 16384 ? panels_balanced_tile_rows(M, 20448) : 0;
+    if (!err && tall2)
+        try_one(0, tall2);
+    const double m2 = last_m;
+    /* taller still (160 KiB of LDS) -- always tried on large matrices: round
+     * 2 tried it only when 16384 rows had beaten 8192, a comparison within
+     * run-to-run noise on W = 2^20, and the bench line then showed 0.90 ms
+     * where this height gives 0.77 -- and shorter still when height cost
+     * (nlpkkt160-shaped KKT matrix: 0.525 ms at 8192 rows, 0.596 at 16384) */
+    if (!err && tall3 && tall3 != tall2)
+        try_one(0, tall3);
+    if (!err && t2 == 16384 && m1 < m2 && m1 < last_m)
         try_one(0, 4096);
     if (err) {
         panels_free(keep);
@@ -379,12 +387,31 @@ __global__ void k_hll_fill(int M, int col_major, const int *irp,
     }
 }
 
-/* scratch sweep used to push a small working set out of the Infinity Cache */
+/* scratch sweep used to push a small working set out of the Infinity Cache:
+ * read-modify-write form (round 1 / 2; kept for A/B, variant bit 29) */
 __global__ void k_flush(double *buf, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride)
         buf[i] = buf[i] * 1.0000001 + 1.0;
+}
+
+/* read-only form, the default since round 3: evicts just the same (reads
+ * allocate in L2 and in the Infinity Cache) but leaves no DIRTY lines behind.
+ * The read-modify-write flush left up to 256 MiB of dirty scratch in the
+ * caches, and its write-back competed with the reads of the launch being
+ * timed -- traffic that belongs to the flush, not to the SpMV: 1M x 16
+ * banded, flushed, same run (gpurun r3c2): CSR stream 0.0433 ms after the RMW
+ * flush / 0.0423 read-only / 0.0369 not flushed; thread-per-row HLL 0.0411 /
+ * 0.0375 / 0.0337; sub-wave CSR 0.0546 / 0.0492 / 0.0479. */
+__global__ void k_flush_ro(const double *buf, size_t n, double *sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (; i < n; i += stride)
+        acc += buf[i];
+    if (acc == 1.2345e300) /* never: the buffer holds zeros */
+        *sink = acc;
 }
 
 /* ------------------------------------------------------------------ */
@@ -767,6 +794,16 @@ int spmv_hll_panels_schedule(const spmv_hll_dev *H) {
     return H ? panels_schedule_of(H->panels) : -EINVAL;
 }
 
+int spmv_csr_panels_describe(const spmv_csr_dev *A, char *buf, size_t len) {
+    return !A ? -EINVAL : A->panels ? panels_describe(A->panels, buf, len)
+                                    : -ENOENT;
+}
+
+int spmv_hll_panels_describe(const spmv_hll_dev *H, char *buf, size_t len) {
+    return !H ? -EINVAL : H->panels ? panels_describe(H->panels, buf, len)
+                                    : -ENOENT;
+}
+
 int spmv_csr_panels_tile_rows(const spmv_csr_dev *A) {
     return !A ? -EINVAL : A->panels ? panels_tile_rows(A->panels) : -ENOENT;
 }
@@ -1070,9 +1107,11 @@ int spmv_hll_launch(const spmv_hll_dev *H, int kernel,
 /* event-timed loops                                                    */
 /* ------------------------------------------------------------------ */
 
+#define SPMV_VARIANT_FLUSH_RMW (1 << 29) /* A/B: the read-modify-write flush */
+
 template <typename Launch>
 static int timed_loop(Launch launch, int warmup, int iters, size_t flush_bytes,
-                      double *ms_each, hipStream_t s) {
+                      double *ms_each, hipStream_t s, bool flush_rmw = false) {
     int rc = 0;
     hipEvent_t e0 = NULL, e1 = NULL;
     double *scratch = NULL;
@@ -1084,9 +1123,12 @@ static int timed_loop(Launch launch, int warmup, int iters, size_t flush_bytes,
         HIP_TRY(hipMemsetAsync(scratch, 0, nflush * sizeof(double), s));
     }
     for (int it = -warmup; it < iters; ++it) {
-        if (nflush)
+        if (nflush && flush_rmw)
             hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, s, scratch,
                                nflush);
+        else if (nflush)
+            hipLaunchKernelGGL(k_flush_ro, dim3(2048), dim3(256), 0, s,
+                               scratch, nflush, scratch);
         HIP_TRY(hipEventRecord(e0, s));
         rc = launch();
         if (rc)
@@ -1118,7 +1160,8 @@ int spmv_csr_time(const spmv_csr_dev *A, int kernel,
         return -EINVAL;
     return timed_loop(
         [&]() { return spmv_csr_launch(A, kernel, opts, d_x, d_y, stream); },
-        warmup, iters, flush_bytes, ms_each, (hipStream_t)stream);
+        warmup, iters, flush_bytes, ms_each, (hipStream_t)stream,
+        opts && (opts->variant & SPMV_VARIANT_FLUSH_RMW));
 }
 
 int spmv_hll_time(const spmv_hll_dev *H, int kernel,
@@ -1129,7 +1172,8 @@ int spmv_hll_time(const spmv_hll_dev *H, int kernel,
         return -EINVAL;
     return timed_loop(
         [&]() { return spmv_hll_launch(H, kernel, opts, d_x, d_y, stream); },
-        warmup, iters, flush_bytes, ms_each, (hipStream_t)stream);
+        warmup, iters, flush_bytes, ms_each, (hipStream_t)stream,
+        opts && (opts->variant & SPMV_VARIANT_FLUSH_RMW));
 }
 
 /* ------------------------------------------------------------------ */

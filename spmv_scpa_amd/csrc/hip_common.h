@@ -163,6 +163,8 @@ int64_t panels_nnz(const spmv_panels *P);
 int panels_count(const spmv_panels *P);
 int panels_steps(const spmv_panels *P);
 int panels_tiles(const spmv_panels *P);
+int panels_balanced_tile_rows(int M, int max_rows);
+int panels_describe(const spmv_panels *P, char *buf, size_t len);
 
 extern int g_csr_waves; /* process defaults behind set_*_waves_per_block */
 extern int g_hll_waves;

@@ -53,6 +53,7 @@
  */
 #include <atomic>
 #include <hipcub/hipcub.hpp>
+#include <stdio.h>
 #include <string.h>
 #include <vector>
 
@@ -94,6 +95,9 @@ struct spmv_panels {
     int *cpanel;     /* DEVICE [tiles*panels] panel of that bucket */
     int *nbk;        /* DEVICE [tiles] non-empty buckets per tile */
     int max_nbk;     /* launches needed = max over tiles */
+    int span;        /* steps / chain: widest run of panels a tile touches */
+    int residue;     /* steps / chain: buckets listed in residue order */
+    int bucket_order; /* spmv_panel_opts.bucket_order the copy was built with */
     /* steps / chain: XCD k runs the CONTIGUOUS tile range
      * [xcd_first[k], xcd_first[k+1]) -- neighbouring tiles share their x
      * window, so they should meet in one L2 -- and the ranges hold about
@@ -314,25 +318,72 @@ __global__ void k_bucket_sizes(int64_t buckets, int64_t pad,
     padded[b] = (len + pad - 1) & ~(pad - 1);
 }
 
-/* compact every tile's non-empty buckets; one thread per tile */
-__global__ void k_compact_buckets(int tiles, int panels,
+/* first / last non-empty panel of every tile, and the widest such span */
+__global__ void k_tile_span(int tiles, int panels,
+                            const int *__restrict__ blen, int *first,
+                            int *last, int *max_span) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles)
+        return;
+    int f = -1, l = -1;
+    for (int p = 0; p < panels; ++p)
+        if (blen[(int64_t)t * panels + p] > 0) {
+            if (f < 0)
+                f = p;
+            l = p;
+        }
+    first[t] = f;
+    last[t] = l;
+    if (f >= 0)
+        atomicMax(max_span, l - f + 1);
+}
+
+/*
+ * Compact every tile's non-empty buckets; one thread per tile.  The list
+ * order is the order in which the chain / steps schedules visit the buckets.
+ *
+ * K = panels: ascending panels.  K < panels (every tile's non-empty panels
+ * lie within a span of K: a band): ascending (panel mod K) -- the RESIDUE
+ * order.  Why: the tiles an XCD runs at one time are neighbours (grouped
+ * order: 32 consecutive tiles), they start together and do equal work per
+ * bucket.  Visiting each tile's own panels in ascending order puts tile t on
+ * panel first(t) + q in phase q, and first(t) drifts along the diagonal: on
+ * random W = 2^20 (tiles of 19552 rows, panels of 2^17 columns, 9-10 buckets
+ * per tile) the 32 tiles of a group sit on 5-6 DIFFERENT 1 MiB panels of x
+ * at any time, more than the XCD's 4 MiB L2 holds beside the entry stream,
+ * and every line of x is fetched again by each of the 5-6 cohorts that pass
+ * it one phase apart (x refetch 1.15 GB per SpMV, profiles/r01_m_w20.md;
+ * that kernel runs at the fabric's ~6.6 TB/s of real traffic).  In residue
+ * order phase r puts every tile on ITS panel congruent to r mod K; a group
+ * spans fewer than 2K panels, so at most two distinct panels are live in an
+ * XCD at a time and each panel is fetched once per group.
+ */
+__global__ void k_compact_buckets(int tiles, int panels, int K,
                                   const int64_t *__restrict__ bptr,
-                                  const int *__restrict__ blen, int64_t *cb,
+                                  const int *__restrict__ blen,
+                                  const int *__restrict__ first,
+                                  const int *__restrict__ last, int64_t *cb,
                                   int *cpanel, int *nbk) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles)
         return;
     int n = 0;
-    for (int p = 0; p < panels; ++p) {
-        int64_t b = bptr[(int64_t)t * panels + p];
-        int64_t e = b + blen[(int64_t)t * panels + p];
-        if (e > b) {
-            cb[((int64_t)t * panels + n) * 2] = b;
-            cb[((int64_t)t * panels + n) * 2 + 1] = e;
-            cpanel[(int64_t)t * panels + n] = p;
-            ++n;
+    const int f = first[t], l = last[t];
+    if (f >= 0)
+        for (int r = 0; r < K; ++r) {
+            /* the panel of [f, f + K) congruent to r mod K */
+            const int p = f + ((r - f) % K + K) % K;
+            if (p > l)
+                continue;
+            int64_t b = bptr[(int64_t)t * panels + p];
+            int64_t e = b + blen[(int64_t)t * panels + p];
+            if (e > b) {
+                cb[((int64_t)t * panels + n) * 2] = b;
+                cb[((int64_t)t * panels + n) * 2 + 1] = e;
+                cpanel[(int64_t)t * panels + n] = p;
+                ++n;
+            }
         }
-    }
     nbk[t] = n;
 }
 
@@ -385,6 +436,21 @@ static long long sweep_tile_rows(int M, int grid, int tile_max) {
     const long long wg = (rounds > 0 ? rounds : 1) * grid;
     long long tr = (((long long)M + wg - 1) / wg + 31) / 32 * 32;
     return tr < 32 ? 32 : tr;
+}
+
+/* Tile height of the chain / steps schedules with one workgroup per CU (tall
+ * tiles): the fewest rounds of (CUs x max_rows) rows that cover M, rows
+ * spread evenly, so that the last round is as full as the others.  10M rows:
+ * 20448-row tiles are 489 tiles = 1.91 rounds of 256, 16384-row tiles 611 =
+ * 2.39 rounds (the third round runs 20 % full: W = 2^20 0.883 ms); 19552
+ * rows make exactly 512 tiles (0.774 ms), 13024 rows 768.  Returns max_rows
+ * when the device cannot be queried. */
+int panels_balanced_tile_rows(int M, int max_rows) {
+    const int cus = device_cus();
+    if (cus <= 0 || M <= 0)
+        return max_rows;
+    long long tr = sweep_tile_rows(M, cus, max_rows / 32 * 32);
+    return (int)(tr > max_rows ? max_rows : tr);
 }
 
 /* start slot of every tile (and the end of the last one) */
@@ -453,14 +519,14 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, 0, -1};
+    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, 0, -1, 0};
     if (!o)
         o = &dflt;
     if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
         o->tile_order < 0 || o->tile_order > 2 || o->sweep_layout < -1 ||
-        o->sweep_layout > 1)
+        o->sweep_layout > 1 || o->bucket_order < 0 || o->bucket_order > 1)
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
     int sched = o->sched;
@@ -539,6 +605,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
      * blocks re-read a cached line instead of fetching another bucket */
     P->pmajor = sweep && o->sweep_layout != 0;
     P->lds_min = o->lds_min;
+    P->bucket_order = o->bucket_order;
     P->order = sweep ? 0 : o->tile_order;
     /* bucket ids: tile-major, or panel-major inside rounds of P->grid tiles */
     const int pm_grid = P->pmajor ? P->grid : 0;
@@ -556,6 +623,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     void *tmp = NULL;
     size_t tmp_bytes = 0;
     int64_t *raw = NULL, *padded = NULL; /* unpadded bucket starts, scan input */
+    int *span = NULL;                    /* per-tile first / last panel */
     const size_t n = (size_t)(slots > 0 ? slots : 1);
     int64_t total = 0;
 
@@ -634,9 +702,25 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                               ((size_t)tiles + 1) * sizeof(int)));
             HIP_TRY(hipMemset(P->nbk, 0, ((size_t)tiles + 1) * sizeof(int)));
             if (tiles > 0) {
+                /* span[0] first, [tiles] last, [2 tiles] widest span */
+                HIP_TRY(hipMalloc((void **)&span,
+                                  (2 * (size_t)tiles + 1) * sizeof(int)));
+                HIP_TRY(hipMemset(span + 2 * (size_t)tiles, 0, sizeof(int)));
+                hipLaunchKernelGGL(k_tile_span, dim3((tiles + 255) / 256),
+                                   dim3(256), 0, 0, tiles, panels, P->blen,
+                                   span, span + tiles, span + 2 * (size_t)tiles);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpy(&P->span, span + 2 * (size_t)tiles,
+                                  sizeof(int), hipMemcpyDeviceToHost));
+                /* residue order for banded matrices (see k_compact_buckets);
+                 * bucket_order 1 keeps ascending panels everywhere */
+                P->residue = o->bucket_order != 1 && P->span > 1 &&
+                             2 * P->span <= panels;
                 hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
-                                   dim3(256), 0, 0, tiles, panels, P->bptr,
-                                   P->blen, P->cb, P->cpanel, P->nbk);
+                                   dim3(256), 0, 0, tiles, panels,
+                                   P->residue ? P->span : panels, P->bptr,
+                                   P->blen, span, span + tiles, P->cb,
+                                   P->cpanel, P->nbk);
                 hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, 0, tiles,
                                    P->nbk, P->nbk + tiles);
                 HIP_TRY(hipGetLastError());
@@ -697,6 +781,7 @@ fail:
     (void)hipFree(tmp);
     (void)hipFree(raw);
     (void)hipFree(padded);
+    (void)hipFree(span);
     panels_free(P);
     return rc;
 }
@@ -1423,13 +1508,13 @@ int panels_from_hll_opts(const spmv_hll_dev *H, const spmv_panel_opts *o,
 
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1};
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1, 0};
     return panels_from_csr_opts(A, &o, out);
 }
 
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1};
+    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1, 0};
     return panels_from_hll_opts(H, &o, out);
 }
 
@@ -1444,6 +1529,30 @@ void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     o->lds_min = P->lds_min;
     o->tile_order = P->order;
     o->sweep_layout = P->pmajor;
+    o->bucket_order = P->bucket_order;
+}
+
+/* one-line description of a blocked copy: schedule, geometry, launch shape
+ * (bench.py prints it; profiles are keyed on it) */
+int panels_describe(const spmv_panels *P, char *buf, size_t len) {
+    if (!P || !buf || !len)
+        return -EINVAL;
+    if (P->sweep)
+        snprintf(buf, len,
+                 "sweep tiles=%d x %d rows, panels=%d x 2^%d cols, grid=%d "
+                 "(%d wg/cu, reserve %d), buckets %s-major, waves=%d",
+                 P->tiles, P->tile_rows, P->panels, P->shift, P->grid,
+                 P->wgs_per_cu, P->reserve_cus, P->pmajor ? "panel" : "tile",
+                 P->waves_hint);
+    else
+        snprintf(buf, len,
+                 "%s tiles=%d x %d rows, panels=%d x 2^%d cols, <=%d buckets "
+                 "per tile (span %d, %s order), tile order %d, waves=%d",
+                 P->chain ? "chain" : "steps", P->tiles, P->tile_rows,
+                 P->panels, P->shift, P->max_nbk, P->span,
+                 P->residue ? "residue" : "ascending", P->order,
+                 P->waves_hint);
+    return 0;
 }
 
 int panels_is_sweep(const spmv_panels *P) { return P ? P->sweep : 0; }

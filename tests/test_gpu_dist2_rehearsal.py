@@ -35,10 +35,12 @@ pytestmark = pytest.mark.gpu
     ["--strong", "--kernel", "4", "--window", "0"],
 ])
 def test_two_ranks_share_one_gpu(extra):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29581", os.path.join(S.ROOT, "bench.py"),
+    # no launcher: `python bench.py --gpus 2` starts its own two ranks
+    # (bench.py launch_ranks)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(S.ROOT, "bench.py"),
            "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
            "--rows-per-gpu", "320000", "--no-cpu-baseline", "--no-extras"]
     r = subprocess.run(cmd + extra, capture_output=True, text=True, env=env,
@@ -67,7 +69,10 @@ def test_two_ranks_share_one_gpu(extra):
         assert c["logical_shards_per_gpu"] in (1, 2)
         st = c["strong"]
         assert "error" not in st, st
-        assert st["ms_per_step"] > 0 and st["speedup_vs_1gpu"] > 0
+        assert st["ms_per_step"] > 0
+        # the 1-GPU denominator is a committed full-size measurement: a
+        # 320000-row rehearsal has none, and says why
+        assert st["speedup_vs_1gpu"] is None and st["one_gpu_source"]
         assert "4 logical shards" in st["problem"]
     else:
         assert c["exchange"] in ("staged", "allgather")

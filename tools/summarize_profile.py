@@ -146,7 +146,8 @@ def main():
                   # bench.py refuses a profile taken with another build of
                   # the kernel's source file (measured_traffic)
                   "kernel_source": cfg.get("kernel_source"),
-                  "blocked_schedule": cfg.get("blocked_schedule")}
+                  "blocked_schedule": cfg.get("blocked_schedule"),
+                  "blocked_layout": cfg.get("blocked_layout")}
             json.dump(tj, open(dst[:-3] + ".traffic.json", "w"), indent=1)
             out += ["## bench.py's timed kernel", "",
                     "`%s`, last %d launches (%d per SpMV): %.4g B read + %.4g B "
