@@ -90,6 +90,12 @@ def stat_delta(a, b):
     return {k: b[k] - a[k] for k in b if k in a}
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Working sets under 512 MB are pushed out of the 256 MiB Infinity Cache
+# between timed launches by a READ-ONLY sweep of a 1 GiB scratch
+# buffer: four times the cache (a 512 MiB sweep left the stream kernel 3.5 %
+# faster, i.e. not everything was gone), and no dirty lines whose write-back
+# would overlap the timed launch (engine.hip k_flush_ro; A/B in DESIGN.md).
+FLUSH_BYTES = 1 << 30
 ROWS_PER_GPU = 10_000_000
 NNZ_PER_ROW = 32
 MATRIX_SEED, X_SEED = 42, 7
@@ -476,7 +482,7 @@ def extra_measurements(S, torch, mat, x, y, Mloc, Nglob, K):
     per tag: the direct HLL kernels on the headline matrix (kernel 1 is the
     literal north-star form), the banded 10M matrix, and BASELINE config 2
     (1M banded CSR; 212 MB < Infinity Cache, so every launch follows a
-    512 MiB flush)."""
+    1 GiB read-only flush)."""
     import numpy as np
     st = torch.cuda.current_stream().cuda_stream
     dx, dy = x.data_ptr(), y.data_ptr()
@@ -505,10 +511,10 @@ def extra_measurements(S, torch, mat, x, y, Mloc, Nglob, K):
                                   0, 0, MATRIX_SEED)
         for k in (1, 2, 4):
             row("config2 csr_%s flushed" % S.CSR_KERNEL_NAMES[k], dB,
-                dB.time(k, dx, dy, 2, 20, 512 << 20, 0, stream=st))
+                dB.time(k, dx, dy, 2, 20, FLUSH_BYTES, 0, stream=st))
         best, _ = dB.autotune(dx, dy, True)
         row("config2 autotuned csr_%s flushed" % S.CSR_KERNEL_LABELS[best],
-            dB, dB.time(best, dx, dy, 2, 20, 512 << 20, 0, stream=st))
+            dB, dB.time(best, dx, dy, 2, 20, FLUSH_BYTES, 0, stream=st))
         dB.release()
     except OSError as e:
         out["error"] = str(e)
@@ -570,9 +576,9 @@ def single_matrix_bench(args, S, torch, dev):
         NZ = dA.NZ
         x = torch.empty(N, dtype=torch.float64, device=dev)
         S.dev_fill_synth(x.data_ptr(), N, X_SEED, 0, st)
-        flush = 512 << 20  # 212 MB working set < 256 MiB Infinity Cache
+        flush = FLUSH_BYTES  # 212 MB working set < 256 MiB Infinity Cache
         workload = ("banded CSR 1000000x1000000, 16 nnz/row (BASELINE "
-                    "config 2), 512 MiB flush between launches")
+                    "config 2), 1 GiB read-only flush between launches")
     y = torch.zeros(M, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     if args.kernel >= 0:

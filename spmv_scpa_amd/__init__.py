@@ -540,13 +540,13 @@ def max_rel_err(expected, res, scale=None):
 
 
 # ---------------------------------------------------------------- GPU one-shot
-def csr_spmv_hip(A, x, kernel=2, waves_per_block=0, group=0):
+def csr_spmv_hip(A, x, kernel=2, waves_per_block=0, group=0, variant=0):
     """y = A x through the one-shot C-ABI entry point (hip_csr.h): host
     arrays in, host y out, returns (y, kernel_ms)."""
     x, xp = _as_d(x)
     assert len(x) == A.contents.N
     y = np.zeros(A.contents.M)
-    o = _opts(waves_per_block, group)
+    o = _opts(waves_per_block, group, variant)
     fn = getattr(_lib, "csr_spmv_hip_" + CSR_KERNEL_NAMES[kernel])
     ms = fn(A, xp, y.ctypes.data_as(_dp), C.cast(C.pointer(o), C.c_void_p))
     if ms < 0:

@@ -554,6 +554,12 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * like the thread-per-row HLL kernel): slower everywhere -- 1M x 16
          * 0.0454 vs 0.0438 ms, banded 10M x 32 0.766 vs 0.725, 27-point
          * stencil 0.687 vs 0.608, random W = 2048 0.865 vs 0.798. */
+        /* ... and (round 3) a finer form, 128 lanes / 1024 entries per range
+         * with its own table for matrices under 2M rows (the thread-per-row
+         * HLL kernel gains 10 % from 256- instead of 512-lane workgroups on
+         * 1M x 16): no gain there (0.0410 vs 0.0411 ms, read-only flush) and
+         * slower elsewhere (random 1M x 32, W = 2048: 0.0932 vs 0.0842;
+         * 27-point stencil 1.5M: 0.1153 vs 0.1078). */
         if (A->n_rowblk <= 0)
             break;
         {

@@ -1192,7 +1192,7 @@ static double median_of(std::vector<double> v) {
  * anything else between two products -- and the benchmark, SURVEY 8d: "MALL
  * flushed between iterations for working sets < 512 MB" -- sees HBM. */
 static size_t tune_flush_bytes(int64_t algorithmic_bytes) {
-    return algorithmic_bytes < ((int64_t)512 << 20) ? (size_t)512 << 20 : 0;
+    return algorithmic_bytes < ((int64_t)512 << 20) ? (size_t)1 << 30 : 0;
 }
 
 int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,

@@ -217,9 +217,10 @@ static void run_gpu(void) {
         rc = spmv_hll_upload(H_row, 0, &dHr);
     if (!rc)
         rc = spmv_hll_upload(H_col, 1, &dHc);
-    /* working sets under 512 MB are flushed out of the Infinity Cache */
+    /* working sets under 512 MB are flushed out of the 256 MiB Infinity
+     * Cache by a read-only sweep of 1 GiB between timed launches */
     size_t flush = spmv_csr_algorithmic_bytes(dA) < (512ll << 20)
-                       ? (size_t)512 << 20 : 0;
+                       ? (size_t)1 << 30 : 0;
     for (int kid = 0; !rc && kid < SPMV_NUM_CSR_KERNELS; ++kid) {
         spmv_launch_opts o = {.waves_per_block = 4};
         rc = spmv_csr_time(dA, kid, &o, d_x, d_y, 3, opt.iters, flush, ms, NULL);

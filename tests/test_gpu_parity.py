@@ -44,6 +44,11 @@ def run_all_kernels(A, x, y_ref, scale, tag):
     for g in (2, 4, 8, 16, 32):
         y, _ = S.csr_spmv_hip(A, x, kernel=2, waves_per_block=4, group=g)
         assert_parity(y, y_ref, scale, (tag, "csr subwave G", g))
+    # stream kernel: 4- / 8-byte loads only (bit 4), grouped range order
+    # (bit 5), hardware order (bit 6)
+    for v in (16, 32, 64, 16 | 32):
+        y, _ = S.csr_spmv_hip(A, x, kernel=4, variant=v)
+        assert_parity(y, y_ref, scale, (tag, "csr stream variant", v))
     for k in range(S.NUM_HLL_KERNELS):
         H = S.csr_to_hll(A, S.HLL_KERNEL_COL_MAJOR[k])
         for w in WPB:

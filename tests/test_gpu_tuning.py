@@ -67,7 +67,7 @@ def test_autotune_times_small_matrices_out_of_the_infinity_cache():
         S.dev_fill_synth(d_x.ptr, N, 7)
         best, ms = dA.autotune(d_x.ptr, d_y.ptr)
         flushed = float(np.median(dA.time(best, d_x.ptr, d_y.ptr, warmup=2,
-                                          iters=10, flush_bytes=512 << 20)))
+                                          iters=10, flush_bytes=1 << 30)))
         cached = float(np.median(dA.time(best, d_x.ptr, d_y.ptr, warmup=2,
                                          iters=10, flush_bytes=0)))
         assert abs(ms - flushed) <= 0.25 * flushed + 0.01, (ms, flushed, cached)
