@@ -409,34 +409,67 @@ def roofline_dict(alg_bytes, kern_ms, kname, nnz, traffic, why=None):
 
 
 # The W = N kernel is not HBM-bound: rocprofv3's TCP/TCC counters
-# (profiles/r02_tcp_counters_sweep.md) show every CU's vector L1 holding its
-# ~107 outstanding line requests for the whole kernel; what the kernel runs out
-# of is L2 line requests in flight.  The line therefore carries a second
-# roofline: requests per launch (measured, TCP_TCC_READ_REQ summed over the
-# chip) against what the 8 L2s accept -- 16 channels per XCD, one request per
-# channel and clock.
+# (profiles/r02_tcp_counters_sweep.md, re-collected per round into
+# profiles/*.l2req.json by tools/pmc.sh + tools/l2req_profile.py) show every
+# CU's vector L1 holding its ~107 outstanding line requests for the whole
+# kernel: what the kernel runs out of is L2 line requests in flight.  The
+# line therefore carries a second roofline: requests per launch (measured,
+# TCP_TCC_READ_REQ summed over the chip) against what the eight L2s accept --
+# 16 channels per XCD, one request per channel and clock at 2.4 GHz.
 L2_CHANNELS = 128
-L2_REQ_PROFILE = "r02_tcp_counters_sweep.md"
-L2_REQ_PER_LAUNCH = 2.43e8   # W = N sweep kernel, 10M x 10M x 32
 L2_CLOCK_GHZ = 2.4
+TCP_SLOTS = 107  # outstanding line requests a CU's vector L1 tracks (r02)
+NUM_CUS = 256
 
 
-def secondary_roofline(kname, sweep, kavg_ms, nnz):
-    """bound "l2_line_requests" for the blocked sweep kernel on W = N; the
-    request count scales with the entries (0.76 line requests per entry:
-    0.62 gathers + 0.14 stream/metadata)"""
-    if not sweep:
-        return None
-    reqs = L2_REQ_PER_LAUNCH * nnz / 3.2e8
+def measured_l2_requests(workload, kname):
+    """-> (profile dict or None, why-not): committed *.l2req.json of the same
+    workload, kernel and kernel-source blob (same staleness rule as
+    measured_traffic)"""
+    import glob
+    fn_src, blob = kernel_source_blob(kname)
+    why = "no committed l2req profile of this workload + kernel"
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.l2req.json")),
+                     reverse=True):
+        try:
+            t = json.load(open(fn))
+        except ValueError:
+            continue
+        if t.get("workload") != workload or t.get("bench_kernel") != kname:
+            continue
+        if not blob or (t.get("kernel_source") or {}).get("blob") != blob:
+            why = ("profiles/%s was taken with another build of %s"
+                   % (os.path.basename(fn), fn_src))
+            continue
+        return t, None
+    return None, why
+
+
+def secondary_roofline(workload, kname, kavg_ms):
+    """bound "l2_line_requests" (what the blocked sweep kernel on W = N is
+    held by): measured CU->L2 line requests per launch against the L2s' peak
+    acceptance rate, and the floor the per-CU outstanding-request capacity
+    sets at the measured mean latency (Little's law)"""
+    prof, why = measured_l2_requests(workload, kname)
+    if not prof:
+        return {"bound": "l2_line_requests", "frac": None, "source": why}
+    reqs = float(prof["requests_per_launch"])
     peak = L2_CHANNELS * L2_CLOCK_GHZ * 1e9
     ach = reqs / (kavg_ms * 1e-3)
-    return {"bound": "l2_line_requests",
-            "requests_per_launch": round(reqs),
-            "achieved_requests_per_s": round(ach, -6),
-            "peak_requests_per_s": peak, "frac": round(ach / peak, 4),
-            "floor_ms_at_peak": round(reqs / peak * 1e3, 3),
-            "tcp_slots": "107 of ~107 outstanding per CU, 394 cycles mean",
-            "source": "profiles/" + L2_REQ_PROFILE}
+    out = {"bound": "l2_line_requests",
+           "requests_per_launch": round(reqs),
+           "achieved_requests_per_s": round(ach, -6),
+           "peak_requests_per_s": peak, "frac": round(ach / peak, 4),
+           "floor_ms_at_peak": round(reqs / peak * 1e3, 3),
+           "source": "profiles/" + prof["source"]}
+    lat = prof.get("mean_latency_cycles")
+    if lat:
+        # requests x latency / (CUs x slots) cycles: the time the vector L1s'
+        # outstanding-request capacity allows at this mean latency
+        out["mean_latency_cycles"] = round(lat, 1)
+        out["tcp_slot_floor_ms"] = round(
+            reqs * lat / (NUM_CUS * TCP_SLOTS) / (L2_CLOCK_GHZ * 1e6), 3)
+    return out
 
 
 # ------------------------------------------------------ secondary measurements
@@ -1111,11 +1144,9 @@ def main(argv=None):
     traffic, why = (measured_traffic(workload, kname) if world == 1
                     else (None, "single-GPU profiles only"))
     roof = roofline_dict(alg_bytes, kern_ms, kname, nnz_local, traffic, why)
-    sec = secondary_roofline(kname, sweep and W >= 2 * Nglob
-                             and args.family == "random",
-                             float(np.mean(kern_ms)), nnz_local)
-    if sec:
-        roof["secondary"] = sec
+    if world == 1 and sweep:  # the schedule for rows that reach beyond an L2
+        roof["secondary"] = secondary_roofline(workload, kname,
+                                               float(np.mean(kern_ms)))
     out = {
         "metric": METRIC,
         "value": round(value, 2),

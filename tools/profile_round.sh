@@ -1,0 +1,44 @@
+#!/usr/bin/env bash
+# All rocprofv3 evidence of a round in one gpurun call (run on the GPU box):
+#   tools/profile_round.sh r03
+# For each workload three passes of the same bench.py command (tools/profile.sh:
+# kernel trace + stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE; counters never share
+# a pass with the hip/hsa trace domains), summarised into
+# profiles/<round>_<tag>.md + .traffic.json; plus the TCP->TCC request counters
+# of the headline kernel (profiles/<round>_wn.l2req.json), the un-profiled
+# bench lines and the 1-GPU run of the fixed 80M x 80M problem that N > 1
+# lines use as their speed-up denominator.  Stops at the first failing step.
+set -uo pipefail
+round="${1:-r03}"
+root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd "$root"
+mkdir -p gpurun_out profiles
+step() { echo "== $*"; "$@" || { echo "FAILED: $*"; exit 1; }; }
+prof() {  # prof <tag> <bench args...>
+    local tag="$1"; shift
+    step tools/profile.sh "${round}_$tag" --steps 20 "$@"
+    step python3 tools/summarize_profile.py "gpurun_out/prof_${round}_$tag" \
+        "profiles/${round}_$tag.md" > /dev/null
+    echo "-- profiles/${round}_$tag.md written"
+}
+prof wn_hll_tile_panels
+prof w20 --window 1048576
+prof w17 --window 131072
+prof c2_banded1M_csr --config 2
+prof c4_kkt_csr --config 4
+prof banded10M_hll --family banded --kernel 1
+step tools/pmc.sh "${round}_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
+    bench.py --no-extras --no-cpu-baseline --steps 20
+step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_l2req" \
+    "profiles/${round}_wn.l2req.json" > /dev/null
+step tools/pmc.sh "${round}_tcc" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
+    bench.py --no-extras --no-cpu-baseline --steps 20
+# un-profiled lines of the round
+python3 bench.py --strong --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline \
+    > "profiles/${round}_strong_1gpu.json" 2> gpurun_out/${round}_strong.err || { echo "FAILED strong"; exit 1; }
+python3 bench.py --config 2 --steps 30 > "profiles/${round}_bench_config2.json" 2> /dev/null || exit 1
+python3 bench.py --config 4 --steps 20 > "profiles/${round}_bench_config4.json" 2> /dev/null || exit 1
+python3 bench.py --steps 20 --warmup 5 > "profiles/${round}_bench_full.json" 2> /dev/null || exit 1
+cp -f profiles/${round}_* gpurun_out/ 2>/dev/null
+mkdir -p gpurun_out/profiles_${round} && cp -f profiles/${round}_* gpurun_out/profiles_${round}/
+echo "== done"
