@@ -16,10 +16,13 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     s = json.load(open(src + "/summary.json"))
     cfg = s["bench"]["config"]
-    funcs = ("k_tiles_sweep", "k_tiles_chain", "k_tiles_step")
+    # the device function of bench.py's own loop: the one of the schedule the
+    # line reports (the selector also ran the other schedules before it)
+    func = {"sweep": "k_tiles_sweep", "chain": "k_tiles_chain",
+            "steps": "k_tiles_step"}[cfg["blocked_schedule"]]
     best = None
     for kname, ctr in s["counters"].items():
-        if any(f in kname for f in funcs) and "TCP_TCC_READ_REQ_sum" in ctr:
+        if func in kname and "TCP_TCC_READ_REQ_sum" in ctr:
             if best is None or ctr["TCP_TCC_READ_REQ_sum"]["n"] > best[1]["TCP_TCC_READ_REQ_sum"]["n"]:
                 best = (kname, ctr)
     if not best:
