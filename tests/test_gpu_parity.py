@@ -468,6 +468,57 @@ def test_steps_schedule_tile_heights(tile_rows, default_panel_schedule,
     S.csr_free(A)
 
 
+@pytest.mark.parametrize("sched", ["chain", "steps"])
+def test_residue_bucket_order_on_a_band(sched, default_panel_schedule,
+                                        monkeypatch):
+    """Banded matrix whose tiles reach over several narrow panels: the chain
+    / steps schedules then visit a tile's buckets in ascending (panel mod K)
+    -- the residue order of k_compact_buckets, K = widest span of panels a
+    tile touches -- instead of ascending panels.  Same y either way, and the
+    same as with bucket_order = 1 (always ascending); a matrix without a band
+    (columns anywhere) keeps ascending order by itself."""
+    M = N = 120_000
+    K, W = 24, 6000
+    IRP, JA, AS = O.synth_csr(S.SYNTH_RANDOM, M, N, K, W, 42)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("band", M, N, IRP, JA, AS)
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+    dA = S.CsrDevice.upload(A)
+    monkeypatch.setenv("SPMV_TILE_ROWS", "2048")
+    seen = {}
+    for order in (0, 1):
+        monkeypatch.setenv("SPMV_BUCKET_ORDER", str(order))
+        dA.build_panels(1024, sched)  # 118 panels of 1024 columns
+        desc = dA.panels_describe()
+        seen[order] = desc
+        assert ("residue order" in desc) == (order == 0), desc
+        info = dA.panels_info()
+        assert info["entries"] == int(IRP[-1]) and info["panels"] == 118
+        for variant, waves in ((0, 0), (0, 4), (1, 8), (2, 0), (4, 4)):
+            S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+            dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant,
+                      waves_per_block=waves)
+            S.stream_sync()
+            assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                          ("band", sched, order, variant, waves))
+    # span: 2048 rows + 6000 columns of window over 1024-column panels
+    import re
+    assert 8 <= int(re.search(r"span (\d+)", seen[0]).group(1)) <= 10, seen[0]
+    monkeypatch.setenv("SPMV_BUCKET_ORDER", "0")
+    dA.release()
+    S.csr_free(A)
+    # no band: every tile touches every panel -> ascending order by itself
+    IRP, JA, AS = O.synth_csr(S.SYNTH_RANDOM, 20_000, 20_000, 16, 1 << 30, 42)
+    B = S.csr_from_arrays("wide", 20_000, 20_000, IRP, JA, AS)
+    dB = S.CsrDevice.upload(B)
+    dB.build_panels(1024, sched)
+    assert "ascending order" in dB.panels_describe()
+    dB.release()
+    S.csr_free(B)
+
+
 def test_build_panels_like_copies_schedule_and_tile_height(
         default_panel_schedule, monkeypatch):
     """Shards of one matrix: tune (here: build) one, build the others with
