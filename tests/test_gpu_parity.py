@@ -312,6 +312,32 @@ def test_config3_random_hll_full_size_properties(W):
     assert np.max(np.abs(ys["hll1"] - ys["csr2"])) < 1e-11
     assert np.max(np.abs(ys["hll1"] - ys["hll4"])) < 1e-11
     assert np.array_equal(ys["hll1"], ys["hll2"])  # same order of operations
+    # the chain schedule at the selector's tall, balanced tile height: on the
+    # band (W = 2^20) the buckets are visited in residue order (panels.hip,
+    # k_compact_buckets), with columns anywhere in ascending order; the WHOLE
+    # y must agree with the thread-per-row kernel either way, and the blocked
+    # kernel must be linear: A (2 x - z / 2) = 2 A x - A z / 2
+    dH.build_panels(0, "chain", tile_rows=19552)
+    desc = dH.panels_describe()
+    assert ("residue order" in desc) == (W == 1 << 20), desc
+    S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+    dH.launch(S.HLL_KERNEL_PANELS, d_x.ptr, d_y.ptr)
+    S.stream_sync()
+    y_chain = d_y.to_numpy(np.float64, M)
+    assert np.max(np.abs(ys["hll1"] - y_chain)) < 1e-11
+    d_z = S.DevBuffer(N * 8)
+    S.dev_fill_synth(d_z.ptr, N, 11)
+    dH.launch(S.HLL_KERNEL_PANELS, d_z.ptr, d_y.ptr)
+    S.stream_sync()
+    y_z = d_y.to_numpy(np.float64, M)
+    mix = 2.0 * d_x.to_numpy(np.float64, N) - 0.5 * d_z.to_numpy(np.float64, N)
+    d_m = S.DevBuffer.from_numpy(mix)
+    dH.launch(S.HLL_KERNEL_PANELS, d_m.ptr, d_y.ptr)
+    S.stream_sync()
+    y_m = d_y.to_numpy(np.float64, M)
+    # |terms| <= 1 each, 32 per row: rounding of three products of <= 32
+    # terms and of the combination stays far below 1e-11
+    assert np.max(np.abs(y_m - (2.0 * y_chain - 0.5 * y_z))) < 1e-11
     dH.release()
     dA.release()
 
