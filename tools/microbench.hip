@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -254,8 +255,57 @@ template <typename F> static double time_ms(F f, int reps = 7) {
     return v[v.size() / 2];
 }
 
-int main() {
+/* read-only sweep: evicts a small working set from L2 / Infinity Cache */
+__global__ void k_sweep_ro(const double *buf, size_t n, double *sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (; i < n; i += stride)
+        acc += buf[i];
+    if (acc == 1.2345e300)
+        *sink = acc;
+}
+
+/*
+ * `microbench small`: what ONE launch can stream when the whole job is the
+ * size of BASELINE config 2 (16M slots: 64 MB of int32 + 128 MB of fp64 = 192
+ * MB, read once, non-temporal), each launch after a 1 GiB read-only sweep --
+ * the regime of bench.py --config 2.  The ceiling a 1M x 16 SpMV launch can be
+ * compared with: ramp-up and tail of a ~35 us launch included.
+ */
+static int small_stream(void) {
+    const size_t n = 16000000, fl = (size_t)1 << 27; /* 1 GiB of doubles */
+    int *ja; double *as, *scratch, *sink;
+    CK(hipMalloc((void **)&ja, n * 4)); CK(hipMalloc((void **)&as, n * 8));
+    CK(hipMalloc((void **)&scratch, fl * 8)); CK(hipMalloc((void **)&sink, 64));
+    CK(hipMemset(ja, 1, n * 4)); CK(hipMemset(as, 0, n * 8));
+    CK(hipMemset(scratch, 0, fl * 8));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    printf("== small stream: 16M slots (192 MB) once per launch, nt loads, 1 GiB read-only sweep before each\n");
+    for (int flush = 1; flush >= 0; --flush)
+        for (int g : {1024, 2048, 4096, 8192, 16384}) {
+            std::vector<float> v;
+            for (int it = 0; it < 33; ++it) {
+                if (flush)
+                    k_sweep_ro<<<2048, 256>>>(scratch, fl, sink);
+                CK(hipEventRecord(a));
+                k_spmvmix<true><<<g, 256>>>(ja, as, n, sink);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+                float ms; CK(hipEventElapsedTime(&ms, a, b));
+                if (it >= 3) v.push_back(ms);
+            }
+            std::sort(v.begin(), v.end());
+            printf("%s grid %6d x 256: median %7.2f us  min %7.2f us  -> %6.2f TB/s (median)\n",
+                   flush ? "flushed  " : "unflushed", g, v[v.size() / 2] * 1e3, v[0] * 1e3,
+                   12.0 * n / v[v.size() / 2] * 1e-9);
+        }
+    return 0;
+}
+
+int main(int argc, char **argv) {
     setvbuf(stdout, NULL, _IOLBF, 0);
+    if (argc > 1 && !strcmp(argv[1], "small"))
+        return small_stream();
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s %s CUs=%d clock=%d MHz L2=%d KB\n", p.name, p.gcnArchName,
            p.multiProcessorCount, p.clockRate / 1000, p.l2CacheSize / 1024);
