@@ -131,9 +131,9 @@ typedef struct spmv_panel_opts {
                              zero-initialised struct asks for layout 0 */
     int bucket_order;     /* steps / chain, the order in which a tile visits
                              its non-empty buckets: 0 = default (ascending
-                             panels; for banded matrices -- every tile's
-                             panels within a span K of at most half of all
-                             panels -- ascending (panel mod K), so that the
+                             panels; when every tile's panels lie within a
+                             span K smaller than the number of panels -- a
+                             band -- ascending (panel mod K), so that the
                              neighbouring tiles an XCD runs together sit on
                              at most two panels of x at a time), 1 = always
                              ascending panels */

@@ -712,10 +712,11 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpy(&P->span, span + 2 * (size_t)tiles,
                                   sizeof(int), hipMemcpyDeviceToHost));
-                /* residue order for banded matrices (see k_compact_buckets);
-                 * bucket_order 1 keeps ascending panels everywhere */
+                /* residue order whenever the tiles do not touch every panel
+                 * (see k_compact_buckets; with span == panels it would be the
+                 * identity); bucket_order 1 keeps ascending panels */
                 P->residue = o->bucket_order != 1 && P->span > 1 &&
-                             2 * P->span <= panels;
+                             P->span < panels;
                 hipLaunchKernelGGL(k_compact_buckets, dim3((tiles + 255) / 256),
                                    dim3(256), 0, 0, tiles, panels,
                                    P->residue ? P->span : panels, P->bptr,

@@ -38,12 +38,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
     ap.add_argument("--only", default="")
+    ap.add_argument("--rows", type=int, default=0,
+                    help="replace the 10M-row cases by this many rows")
     a = ap.parse_args()
+    cases = CASES
+    if a.rows:
+        cases = [(lab.replace("10M", "%gM" % (a.rows / 1e6)), fam, a.rows, K, W)
+                 for lab, fam, M, K, W in CASES if M == 10_000_000]
     lines = ["# spmv_*_autotune picks, one MI355X (%s), %s"
              % (S.device_info(0)[0], time.strftime("%Y-%m-%d")),
              "# workload | format | pick | ms | GFLOP/s | %% of 8 TB/s | "
              "tune s | layout of the blocked copy"]
-    for label, fam, M, K, W in CASES:
+    for label, fam, M, K, W in cases:
         if a.only and a.only not in label:
             continue
         N = M
