@@ -50,7 +50,11 @@ typedef struct spmv_launch_opts {
                             in hardware order); none of them: the handle's
                             order (what spmv_*_autotune measured faster;
                             before tuning: grouped from 2M rows up).  CSR
-                            stream kernel: bit 4 = 4- / 8-byte loads only.  The
+                            stream kernel: bit 4 = 4- / 8-byte loads only.
+                            CSR sub-wave kernel: bit 9 = load IRP even when
+                            every row has one length (A/B of the constant-
+                            row-length path).  Timed loops: bit 29 = the
+                            read-modify-write cache flush of rounds 1 / 2.  The
                             blocked schedules read their own bits
                             (panels.hip) and spmv_panel_opts.tile_order */
     int reserved[5];     /* must be 0 */

@@ -458,6 +458,14 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     }
     build_rowblk(host_irp, d->M, STREAM_NNZ, STREAM_THREADS, tab, mode,
                  &d->max_row_len);
+    {
+        /* constant row length?  (O(M) over the host copy of IRP) */
+        int len = d->M > 0 ? host_irp[1] - host_irp[0] : 0;
+        for (int r = 1; r < d->M && len > 0; ++r)
+            if (host_irp[r + 1] - host_irp[r] != len)
+                len = 0;
+        d->uniform_len = len;
+    }
     d->n_rowblk = (int)tab.size() - 1;
     {
         /* (first row, first entry) per range: the kernel learns both with one

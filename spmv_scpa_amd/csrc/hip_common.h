@@ -86,6 +86,10 @@ struct spmv_csr_dev {
     int n_rowblk;
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
     int max_row_len;
+    int uniform_len; /* > 0: EVERY row holds exactly this many entries (banded
+                        and fixed-degree matrices: IRP[r] = r * uniform_len),
+                        so the sub-wave kernel need not wait for IRP before it
+                        can fetch JA / AS; 0: row lengths vary */
     int order; /* sub-wave kernel, workgroup order: 0 hardware, 1 XCD-contiguous
                   equal ranges, 2 grouped runs of 32 workgroups per XCD
                   (spmv_csr_autotune measures all three) */

@@ -44,6 +44,11 @@ def run_all_kernels(A, x, y_ref, scale, tag):
     for g in (2, 4, 8, 16, 32):
         y, _ = S.csr_spmv_hip(A, x, kernel=2, waves_per_block=4, group=g)
         assert_parity(y, y_ref, scale, (tag, "csr subwave G", g))
+    # sub-wave kernel with the IRP loads kept (bit 9) -- matrices whose rows
+    # all have one length otherwise take the path that computes IRP[r]
+    for v in (512, 512 | 1, 512 | 2, 512 | 32):
+        y, _ = S.csr_spmv_hip(A, x, kernel=2, waves_per_block=4, variant=v)
+        assert_parity(y, y_ref, scale, (tag, "csr subwave variant", v))
     # stream kernel: 4- / 8-byte loads only (bit 4), grouped range order
     # (bit 5), hardware order (bit 6)
     for v in (16, 32, 64, 16 | 32):
