@@ -21,8 +21,19 @@
 #include "hip_hll.h"
 #include "spmv_synth.h"
 
-int g_csr_waves = 8; /* 512-lane workgroups measured best on MI355X */
-int g_hll_waves = 8;
+/* Process defaults behind set_*_waves_per_block (the reference's seam sets
+ * them before every call).  0 = never set: the launch then picks by size --
+ * 512-lane workgroups measured best on 10M-row matrices, 256-lane ones on
+ * launches that last only a few workgroup lifetimes (1M x 16, flushed:
+ * thread-per-row HLL 0.0383 vs 0.0435 ms, sub-wave CSR 0.0447 vs 0.0461; a
+ * pure 192 MB stream likewise prefers many small workgroups,
+ * profiles/r03_microbench_small.txt). */
+int g_csr_waves = 0;
+int g_hll_waves = 0;
+
+static int default_waves(int user_default, long long rows) {
+    return user_default > 0 ? user_default : rows < 2000000 ? 4 : 8;
+}
 
 /*
  * Live handles.  spmv_csr_release / spmv_hll_release free host memory
@@ -867,7 +878,8 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
     }
     if (!A->ja && A->NZ > 0)
         return -ENODATA; /* spmv_csr_release_source(): blocked path only */
-    return csr_launch_kernel(A, kernel, pick_waves(opts, g_csr_waves),
+    return csr_launch_kernel(A, kernel,
+                             pick_waves(opts, default_waves(g_csr_waves, A->M)),
                              opts ? opts->group : 0, opts ? opts->variant : 0,
                              d_x, d_y, row_begin,
                              row_end, (hipStream_t)stream);
@@ -1082,7 +1094,7 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
         return -EINVAL;
     if (!live_has(H))
         return -EBADF; /* released (or never a) handle */
-    int waves = pick_waves(opts, g_hll_waves);
+    int waves = pick_waves(opts, default_waves(g_hll_waves, H->M));
     if (kernel == SPMV_HLL_KERNEL_PANELS) {
         if (!H->panels || blk_begin != 0 || blk_end != H->nb)
             return -EINVAL; /* build panels first; whole matrix only */
