@@ -728,6 +728,8 @@ def launch_ranks(args, argv):
             return 2
     env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    # RCCL between processes needs dmabuf IPC on this pool's host driver
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
