@@ -589,6 +589,19 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * 1M x 16): no gain there (0.0410 vs 0.0411 ms, read-only flush) and
          * slower elsewhere (random 1M x 32, W = 2048: 0.0932 vs 0.0842;
          * 27-point stencil 1.5M: 0.1153 vs 0.1078). */
+        /* ... and (round 3) a wavefront-PIPELINED form built on the lesson of
+         * the first attempt: a wavefront walks mini-ranges of <= 508 entries
+         * (their own table), transposes each through 6 KiB of LDS and issues
+         * the NEXT mini-range's JA / AS / IRP loads right after its last
+         * gathers (younger loads, so the gathers' data returns first;
+         * straight-line, countable vmcnt), mini-ranges dealt grid-stride so
+         * that the chip keeps one compact front.  Correct (parity suite) and
+         * the pipelining does what it should -- 1.20 ms without it, 0.76 with
+         * 7-8 mini-ranges per wavefront on banded 10M x 32 -- but the
+         * per-mini-range work of a lone wavefront (masked LDS transposition,
+         * lane-team bookkeeping, cross-lane reductions, ~10 LDS round trips in
+         * series) costs more than the workgroup form's idle phases: 0.76 vs
+         * 0.70 ms there, 0.0515 vs 0.0414 ms on 1M x 16.  Not kept. */
         if (A->n_rowblk <= 0)
             break;
         {
