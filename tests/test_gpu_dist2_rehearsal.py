@@ -76,3 +76,28 @@ def test_two_ranks_share_one_gpu(extra):
         assert "4 logical shards" in st["problem"]
     else:
         assert c["exchange"] in ("staged", "allgather")
+
+
+def test_four_ranks_share_one_gpu():
+    """the N = 4 line of a scaling run, rehearsed: sweep schedule, both
+    exchange arrangements timed, config.strong = 2 logical shards per rank of
+    the fixed problem, each rank checking rows of the three others"""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(S.ROOT, "bench.py"),
+           "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--rows-per-gpu", "320000", "--no-cpu-baseline", "--no-extras",
+           "--kernel", "4", "--window", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = j["config"]
+    assert j["n_gpus"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["rows_checked"] >= 258 + 9  # own rows + 3 of each other rank
+    assert c["nnz_global"] == 4 * 320000 * 32
+    assert "exchange after the kernel" in c["exchange_arrangement"]
+    st = c["strong"]
+    assert "error" not in st and "2 logical shards" in st["problem"], st
+    assert st["ms_per_step"] > 0
