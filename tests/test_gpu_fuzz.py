@@ -59,7 +59,9 @@ def test_blocked_path_random_shapes(case, monkeypatch):
         # the workgroup orders of the direct kernels (variant bit 0: hardware
         # order, bit 1: XCD-contiguous ranges, bit 5 (CSR) / bit 2 (HLL):
         # grouped runs; stream kernel: bit 6 hardware order, bit 4 narrow loads)
-        for k, variant in ((2, 1), (2, 2), (2, 32), (4, 32), (4, 64),
+        # bit 9: the sub-wave kernel loads IRP even when all rows have one
+        # length (banded / fixed-degree cases take the computed-IRP path else)
+        for k, variant in ((2, 1), (2, 2), (2, 32), (2, 512), (4, 32), (4, 64),
                            (4, 16 | 32)):
             S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
             dA.launch(k, d_x.ptr, d_y.ptr, variant=variant)
@@ -73,6 +75,9 @@ def test_blocked_path_random_shapes(case, monkeypatch):
             S.set_panel_schedule(sched)
             if sched != "sweep":
                 monkeypatch.setenv("SPMV_TILE_ROWS", str(tile))
+                # odd cases: ascending bucket order instead of the residue
+                # order banded shapes get by default
+                monkeypatch.setenv("SPMV_BUCKET_ORDER", str(case[0] & 1))
             for m, blocked in ((dA, S.CSR_KERNEL_PANELS),
                                (dH, S.HLL_KERNEL_PANELS)):
                 m.build_panels(pc)
@@ -81,6 +86,7 @@ def test_blocked_path_random_shapes(case, monkeypatch):
                     m.launch(blocked, d_x.ptr, d_y.ptr, waves_per_block=waves)
                     check((sched, blocked, waves))
             monkeypatch.delenv("SPMV_TILE_ROWS", raising=False)
+            monkeypatch.delenv("SPMV_BUCKET_ORDER", raising=False)
     finally:
         S.set_panel_schedule("sweep")
         dH.release()
