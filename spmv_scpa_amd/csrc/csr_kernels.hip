@@ -601,7 +601,15 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
          * per-mini-range work of a lone wavefront (masked LDS transposition,
          * lane-team bookkeeping, cross-lane reductions, ~10 LDS round trips in
          * series) costs more than the workgroup form's idle phases: 0.76 vs
-         * 0.70 ms there, 0.0515 vs 0.0414 ms on 1M x 16.  Not kept. */
+         * 0.70 ms there, 0.0515 vs 0.0414 ms on 1M x 16.  Not kept.  The
+         * same pipeline at WORKGROUP level (persistent 256-lane workgroups,
+         * grid-stride ranges, next range's loads in registers behind the
+         * last gathers, batch count per range precomputed on the host):
+         * correct, and slower again -- banded 10M x 32 0.86-0.88 vs 0.71 ms
+         * with 3-12 workgroups per CU, 1M x 16 0.0546 vs 0.0421, random
+         * W = 2048 0.970 vs 0.755, 27-point stencil 0.733 vs 0.564.  Six
+         * short-lived one-shot workgroups per CU, replaced by the hardware
+         * as they finish, are the better pipeline. */
         if (A->n_rowblk <= 0)
             break;
         {
