@@ -105,10 +105,20 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
  * Everything a build depends on travels in this struct -- the library reads
  * no environment variable and, apart from the process default schedule of
  * spmv_set_panel_schedule(), keeps no mutable global: two host threads may
- * build and launch different handles concurrently.  Zero-initialise; 0 means
- * "default" in every field except `sched` and `sweep_layout` (-1).
+ * build and launch different handles concurrently.  Initialise with
+ * spmv_panel_opts_default(); 0 means "default" in every field except
+ * `struct_size`, `sched` and `sweep_layout` (-1).
  */
 typedef struct spmv_panel_opts {
+    int struct_size;      /* sizeof(spmv_panel_opts) of the header the caller
+                             was compiled with: a build call refuses any other
+                             value (-EINVAL), so a caller built against an
+                             older, shorter struct fails loudly instead of
+                             having the library read past it.  ABI: the struct
+                             grew in library versions 0.3 (bucket_order) and
+                             0.4 (this field, first); spmv_version() tells
+                             which library is loaded.  Fill the struct with
+                             spmv_panel_opts_default() and then set fields */
     int sched;            /* -1 process default, 0 steps, 1 sweep, 2 chain */
     int panel_cols;       /* columns per panel (rounded down to 2^k); 0: 2^18 */
     int tile_rows;        /* rows per tile of steps / chain (32..20448); 0: 4096;
@@ -142,6 +152,10 @@ typedef struct spmv_panel_opts {
                              at most two panels of x at a time), 1 = always
                              ascending panels */
 } spmv_panel_opts;
+
+/* every field at its default (struct_size set, sched -1, sweep_layout -1,
+ * the rest 0) -- the one place the defaults live */
+void spmv_panel_opts_default(spmv_panel_opts *opts);
 
 /* ---- CSR handle ---- */
 typedef struct spmv_csr_dev spmv_csr_dev;
@@ -270,11 +284,42 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
 int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
                       int allow_panels, int *best_kernel, double *best_ms);
 
-/* Handles created and not yet released (CSR + HLL, one-shot calls included
- * while they run).  spmv_*_release() of a NULL, already released or unknown
- * handle is ignored -- a binding's finaliser after an explicit release cannot
- * corrupt the heap -- and a launch on such a handle returns -EBADF. */
+/* per-kernel medians (ms) of the last spmv_*_autotune on this handle, kernel
+ * ids 0 .. n-1 (0.0: not a candidate for this matrix), and what the selector
+ * did: one text line per phase with host-clock seconds -- direct kernels,
+ * every blocked candidate (build s, configurations timed, s, best ms), total
+ * (-ENOENT before any autotune) */
+int spmv_csr_tune_times(const spmv_csr_dev *A, double *ms, int n);
+int spmv_hll_tune_times(const spmv_hll_dev *H, double *ms, int n);
+int spmv_csr_tune_log(const spmv_csr_dev *A, char *buf, size_t len);
+int spmv_hll_tune_log(const spmv_hll_dev *H, char *buf, size_t len);
+
+/*
+ * Dead-handle contract.  Every entry point that takes a handle checks it
+ * first: NULL -> -EINVAL, a pointer that is not (or no longer) a live handle
+ * -> -EBADF, before anything is allocated or dereferenced
+ * (spmv_*_algorithmic_bytes return the code as a negative byte count).
+ * spmv_*_release() of such a pointer is ignored AND counted:
+ * spmv_ignored_releases() returns the count, spmv_set_debug(1) adds one line
+ * on stderr per ignored release (the library reads no environment variable;
+ * the Python binding passes SPMV_DEBUG on).  spmv_live_handles(): handles
+ * created and not yet released (CSR + HLL, one-shot calls included while they
+ * run).
+ *
+ * Address reuse: a released handle's address may be handed out again by the
+ * allocator.  Every handle therefore carries a process-wide generation
+ * (1, 2, 3, ... never reused; spmv_handle_generation, 0 for a pointer that is
+ * not live), and spmv_*_release_checked(h, generation) releases only the
+ * handle that was created with that generation -- a stale wrapper object
+ * (finaliser, atexit sweep) cannot release a newer handle that happens to live
+ * at the old address.  Bindings with finalisers should use the checked form.
+ */
 int spmv_live_handles(void);
+long spmv_ignored_releases(void);
+void spmv_set_debug(int on);
+uint64_t spmv_handle_generation(const void *handle);
+void spmv_csr_release_checked(spmv_csr_dev *A, uint64_t generation);
+void spmv_hll_release_checked(spmv_hll_dev *H, uint64_t generation);
 
 /* Library self-description: "spmv_scpa_amd <version> gfx950". */
 const char *spmv_version(void);

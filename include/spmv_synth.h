@@ -28,6 +28,22 @@
  *                 three band groups -- the structure class of nlpkkt160 /
  *                 FEM matrices (stand-in for config 4, which cannot be
  *                 downloaded here).
+ *   SYNTH_POWERLAW web / road / co-purchase graph class (the reference's
+ *                 webbase-1M, amazon0302, roadNet-PA, reference
+ *                 scripts/download-matrices.py:7-38): row length is a
+ *                 discrete power law, P(len >= k) = min(1, (s/k)^1.5) with
+ *                 s = (2K+1)/6, i.e. mean ~ K (K = 3: 55 % of the rows hold
+ *                 one entry, one row in 10^6 holds >= 10^4, longest 30342),
+ *                 computed in integers so that every compiler gets the same
+ *                 lengths; columns stratified over the window (slot j of a
+ *                 row of L entries is uniform in the j-th of L equal strata
+ *                 -- ascending by construction, O(1) per slot, "anywhere"
+ *                 when W >= 2N).
+ *   SYNTH_HUB     circuit class (the reference's dc1): short rows (1..2K-1
+ *                 entries, stratified over the window) + ONE hub row (global
+ *                 row N/3) of min(N, max(N/8, 131072)) entries spread over
+ *                 all columns + ONE hub column (N/2) present in three rows
+ *                 out of four.
  * Values are uniform in [-1, 1); x is uniform in [0, 1).
  */
 #ifndef SPMV_SYNTH_H
@@ -46,8 +62,12 @@ enum synth_kind {
     SYNTH_RANDOM = 1,
     SYNTH_RAGGED = 2,
     SYNTH_KKT = 3,
-    SYNTH_STENCIL = 4
+    SYNTH_STENCIL = 4,
+    SYNTH_POWERLAW = 5,
+    SYNTH_HUB = 6,
+    SYNTH_KIND_LAST = SYNTH_HUB
 };
+#define SYNTH_POWERLAW_MAX_K 40 /* (2K+1)^3 << 44 has to fit 64 bits */
 
 typedef struct synth_spec {
     int kind;       /* enum synth_kind */
@@ -115,11 +135,65 @@ SYNTH_FN int synth_stencil_cols(const synth_spec *s, int64_t g, int *cols) {
     return n;
 }
 
+/* floor(cbrt(q)), integers only (q < 2^63) */
+SYNTH_FN int64_t synth_icbrt(uint64_t q) {
+    int64_t r = 0;
+    for (int b = 20; b >= 0; --b) {
+        const int64_t t = r | ((int64_t)1 << b);
+        if ((uint64_t)t * (uint64_t)t * (uint64_t)t <= q)
+            r = t;
+    }
+    return r;
+}
+
+/* power-law row length: len = floor(s * u^(-2/3)), u = U / 2^22 with U
+ * uniform in 1..2^22, s = (2K+1)/6 -- as the largest len with
+ * len^3 <= (2K+1)^3 * 2^44 / (216 * U^2); at least 1, at most N */
+SYNTH_FN int synth_powerlaw_len(const synth_spec *s, int64_t g) {
+    const uint64_t h = synth_hash2(s->seed, 0x70776cu, (uint64_t)g);
+    const uint64_t U = (h >> 42) + 1;
+    const uint64_t k = (uint64_t)(2 * (s->K > SYNTH_POWERLAW_MAX_K
+                                           ? SYNTH_POWERLAW_MAX_K
+                                           : s->K) + 1);
+    const uint64_t q = ((k * k * k) << 44) / (216u * U * U);
+    int64_t len = synth_icbrt(q);
+    if (len < 1)
+        len = 1;
+    if (len > (int64_t)s->N)
+        len = s->N;
+    return (int)len;
+}
+
+/* the hub family: the hub row / column and what an ordinary row holds */
+SYNTH_FN int64_t synth_hub_row(const synth_spec *s) { return (int64_t)s->N / 3; }
+SYNTH_FN int synth_hub_col(const synth_spec *s) { return s->N / 2; }
+SYNTH_FN int synth_hub_row_len(const synth_spec *s) {
+    int64_t len = (int64_t)s->N / 8;
+    if (len < 131072)
+        len = 131072;
+    if (len > (int64_t)s->N)
+        len = s->N;
+    return (int)len;
+}
+SYNTH_FN int synth_hub_base_len(const synth_spec *s, int64_t g) {
+    const uint64_t h = synth_hash2(s->seed, 0x687562u, (uint64_t)g);
+    return 1 + (int)(h % (uint64_t)(2 * s->K - 1));
+}
+SYNTH_FN int synth_hub_has_col(const synth_spec *s, int64_t g) {
+    return (synth_hash2(s->seed, 0x686363u, (uint64_t)g) & 3) != 0;
+}
+
 /* number of entries of GLOBAL row g */
 SYNTH_FN int synth_row_len(const synth_spec *s, int64_t g) {
     switch (s->kind) {
     case SYNTH_STENCIL:
         return synth_stencil_cols(s, g, 0);
+    case SYNTH_POWERLAW:
+        return synth_powerlaw_len(s, g);
+    case SYNTH_HUB:
+        if (g == synth_hub_row(s))
+            return synth_hub_row_len(s);
+        return synth_hub_base_len(s, g) + synth_hub_has_col(s, g);
     case SYNTH_BANDED:
     case SYNTH_RANDOM:
         return s->K;
@@ -160,14 +234,69 @@ SYNTH_FN int synth_col_draw(const synth_spec *s, int64_t g, int t) {
     return (int)(lo + (int64_t)(synth_u01(h) * (double)(hi - lo)));
 }
 
+/* stratified column: slot j of `len` over [lo, hi), ascending in j */
+SYNTH_FN int synth_col_strat(const synth_spec *s, int64_t g, int j, int len,
+                             int64_t lo, int64_t hi) {
+    const int64_t span = hi - lo;
+    const int64_t a = lo + (int64_t)j * span / len;
+    const int64_t b = lo + ((int64_t)j + 1) * span / len;
+    uint64_t h = synth_hash2(s->seed ^ 0x636f6cull, (uint64_t)g, (uint64_t)j);
+    return (int)(a + (int64_t)(synth_u01(h) * (double)(b - a)));
+}
+
+/* the window of GLOBAL row g, as synth_col_draw clips it */
+SYNTH_FN void synth_window(const synth_spec *s, int64_t g, int64_t *plo,
+                           int64_t *phi) {
+    int64_t half = s->W / 2;
+    int64_t lo = g - half, hi = g + (s->W - half);
+    if (lo < 0)
+        lo = 0;
+    if (hi > s->N)
+        hi = s->N;
+    if (lo >= hi) {
+        lo = 0;
+        hi = s->N;
+    }
+    *plo = lo;
+    *phi = hi;
+}
+
 /*
  * Fill one row: cols[0..len) ascending, vals[0..len).  `len` must be
- * synth_row_len(s, g).  Insertion sort: rows are short (K ~ 16..256).
+ * synth_row_len(s, g).  Insertion sort for the random families: their rows
+ * are short (K ~ 16..256); the power-law and hub families, whose rows reach
+ * 10^4..10^5 entries, draw ascending columns directly.
  */
 SYNTH_FN void synth_fill_row(const synth_spec *s, int64_t g, int len,
                              int *cols, double *vals) {
     if (s->kind == SYNTH_STENCIL) {
         synth_stencil_cols(s, g, cols);
+    } else if (s->kind == SYNTH_POWERLAW) {
+        int64_t lo, hi;
+        synth_window(s, g, &lo, &hi);
+        for (int j = 0; j < len; ++j)
+            cols[j] = synth_col_strat(s, g, j, len, lo, hi);
+    } else if (s->kind == SYNTH_HUB) {
+        if (g == synth_hub_row(s)) {
+            for (int j = 0; j < len; ++j)
+                cols[j] = synth_col_strat(s, g, j, len, 0, s->N);
+        } else {
+            const int hub = synth_hub_has_col(s, g);
+            const int base = len - hub;
+            int64_t lo, hi;
+            synth_window(s, g, &lo, &hi);
+            for (int j = 0; j < base; ++j)
+                cols[j] = synth_col_strat(s, g, j, base, lo, hi);
+            if (hub) { /* the hub column goes to its sorted place */
+                const int c = synth_hub_col(s);
+                int p = base;
+                while (p > 0 && cols[p - 1] > c) {
+                    cols[p] = cols[p - 1];
+                    --p;
+                }
+                cols[p] = c;
+            }
+        }
     } else if (s->kind == SYNTH_BANDED) {
         int64_t st = g - s->K / 2;
         if (st > (int64_t)s->N - len)

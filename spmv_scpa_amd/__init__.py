@@ -33,8 +33,11 @@ _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 MAX_NAME = 64
 HACK_SIZE = 32
 SYNTH_BANDED, SYNTH_RANDOM, SYNTH_RAGGED, SYNTH_KKT, SYNTH_STENCIL = 0, 1, 2, 3, 4
+SYNTH_POWERLAW, SYNTH_HUB = 5, 6  # webbase/amazon/roadNet class, dc1 class
 NUM_CSR_KERNELS = 5
 NUM_HLL_KERNELS = 4
+NUM_CSR_KERNELS_ALL = 6  # + the 2-D blocked path (SPMV_CSR_KERNEL_PANELS)
+NUM_HLL_KERNELS_ALL = 5
 #: extra kernel ids: the column-panel path (spmv_engine.h)
 CSR_KERNEL_PANELS = 5
 HLL_KERNEL_PANELS = 4
@@ -94,7 +97,8 @@ class LaunchOpts(C.Structure):
 
 class PanelOpts(C.Structure):
     """spmv_panel_opts (include/spmv_engine.h)"""
-    _fields_ = [("sched", C.c_int), ("panel_cols", C.c_int),
+    _fields_ = [("struct_size", C.c_int),
+                ("sched", C.c_int), ("panel_cols", C.c_int),
                 ("tile_rows", C.c_int), ("sweep_wgs_per_cu", C.c_int),
                 ("reserve_cus", C.c_int), ("lds_min", C.c_int),
                 ("tile_order", C.c_int), ("sweep_layout", C.c_int),
@@ -184,6 +188,16 @@ _sig("log_roofline", None, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
 # ---------------------------------------------------------------- engine API
 _sig("spmv_version", C.c_char_p)
 _sig("spmv_live_handles", C.c_int)
+_sig("spmv_ignored_releases", C.c_long)
+_sig("spmv_set_debug", None, C.c_int)
+_sig("spmv_handle_generation", C.c_uint64, C.c_void_p)
+_sig("spmv_csr_release_checked", None, C.c_void_p, C.c_uint64)
+_sig("spmv_hll_release_checked", None, C.c_void_p, C.c_uint64)
+_sig("spmv_panel_opts_default", None, C.POINTER(PanelOpts))
+_sig("spmv_csr_tune_times", C.c_int, C.c_void_p, _dp, C.c_int)
+_sig("spmv_hll_tune_times", C.c_int, C.c_void_p, _dp, C.c_int)
+_sig("spmv_csr_tune_log", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t)
+_sig("spmv_hll_tune_log", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t)
 _sig("spmv_device_count", C.c_int)
 _sig("spmv_set_device", C.c_int, C.c_int)
 _sig("spmv_get_device", C.c_int)
@@ -306,6 +320,16 @@ def version():
     return _lib.spmv_version().decode()
 
 
+def ignored_releases():
+    """releases the library ignored (double release / stale wrapper): 0 in a
+    correct program.  SPMV_DEBUG=1 prints one stderr line per occurrence."""
+    return _lib.spmv_ignored_releases()
+
+
+if os.environ.get("SPMV_DEBUG", "") not in ("", "0"):
+    _lib.spmv_set_debug(1)
+
+
 def device_count():
     return _lib.spmv_device_count()
 
@@ -335,6 +359,8 @@ def _env_int(name, lo, hi):
 def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
                 reserve_cus=0, lds_min=0, sweep_layout=None):
     o = PanelOpts()
+    _lib.spmv_panel_opts_default(C.byref(o))  # struct_size, the -1 defaults
+    assert o.struct_size == C.sizeof(PanelOpts), "spmv_panel_opts ABI drift"
     o.sched = -1 if sched is None else (
         PANEL_SCHED[sched] if sched in PANEL_SCHED else int(sched))
     o.panel_cols = panel_cols
@@ -688,8 +714,12 @@ class CsrDevice:
 
     def __init__(self, handle):
         self.h = handle
+        # the generation the library gave this handle: release_checked() acts
+        # only on THAT handle, never on a newer one at a recycled address
+        self.gen = _lib.spmv_handle_generation(self.h)
         M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
-        _lib.spmv_csr_shape(self.h, C.byref(M), C.byref(N), C.byref(NZ))
+        _check(_lib.spmv_csr_shape(self.h, C.byref(M), C.byref(N),
+                                   C.byref(NZ)), "spmv_csr_shape")
         self.M, self.N, self.NZ = M.value, N.value, NZ.value
         _live.add(self)
 
@@ -789,6 +819,19 @@ class CsrDevice:
                "spmv_csr_autotune")
         return k.value, ms.value
 
+    def tune_times(self):
+        """per-kernel median ms of the last autotune (0.0: not a candidate)"""
+        ms = (C.c_double * NUM_CSR_KERNELS_ALL)()
+        _check(_lib.spmv_csr_tune_times(self.h, ms, NUM_CSR_KERNELS_ALL),
+               "spmv_csr_tune_times")
+        return list(ms)
+
+    def tune_log(self):
+        """what the last autotune did (text, one line per phase) or None"""
+        buf = C.create_string_buffer(4096)
+        rc = _lib.spmv_csr_tune_log(self.h, buf, 4096)
+        return None if rc else buf.value.decode()
+
     def download(self):
         p = _CSRp()
         _check(_lib.spmv_csr_download(self.h, C.byref(p)), "spmv_csr_download")
@@ -803,7 +846,7 @@ class CsrDevice:
     def release(self):
         h, self.h = self.h, None
         if h and _closed is False and _lib is not None:
-            _lib.spmv_csr_release(h)
+            _lib.spmv_csr_release_checked(h, self.gen)
 
     def __del__(self):
         if _closed is False:  # None / True at or after interpreter shutdown
@@ -824,11 +867,13 @@ class HllDevice:
 
     def __init__(self, handle):
         self.h = handle
+        self.gen = _lib.spmv_handle_generation(self.h)
         _live.add(self)
         M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
         nb, S, cm = C.c_int(), C.c_int64(), C.c_int()
-        _lib.spmv_hll_shape(self.h, C.byref(M), C.byref(N), C.byref(NZ),
-                            C.byref(nb), C.byref(S), C.byref(cm))
+        _check(_lib.spmv_hll_shape(self.h, C.byref(M), C.byref(N),
+                                   C.byref(NZ), C.byref(nb), C.byref(S),
+                                   C.byref(cm)), "spmv_hll_shape")
         self.M, self.N, self.NZ = M.value, N.value, NZ.value
         self.num_blocks, self.slots = nb.value, S.value
         self.col_major = bool(cm.value)
@@ -893,6 +938,19 @@ class HllDevice:
                "spmv_hll_autotune")
         return k.value, ms.value
 
+    def tune_times(self):
+        """per-kernel median ms of the last autotune (0.0: not a candidate)"""
+        ms = (C.c_double * NUM_HLL_KERNELS_ALL)()
+        _check(_lib.spmv_hll_tune_times(self.h, ms, NUM_HLL_KERNELS_ALL),
+               "spmv_hll_tune_times")
+        return list(ms)
+
+    def tune_log(self):
+        """what the last autotune did (text, one line per phase) or None"""
+        buf = C.create_string_buffer(4096)
+        rc = _lib.spmv_hll_tune_log(self.h, buf, 4096)
+        return None if rc else buf.value.decode()
+
     @property
     def algorithmic_bytes(self):
         return _lib.spmv_hll_algorithmic_bytes(self.h)
@@ -920,7 +978,7 @@ class HllDevice:
     def release(self):
         h, self.h = self.h, None
         if h and _closed is False and _lib is not None:
-            _lib.spmv_hll_release(h)
+            _lib.spmv_hll_release_checked(h, self.gen)
 
     def __del__(self):
         if _closed is False:  # None / True at or after interpreter shutdown

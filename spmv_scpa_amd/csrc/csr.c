@@ -711,7 +711,7 @@ sparse_csr *io_load_csr_cached(const char *path) {
 
 sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
                          int64_t row0, uint64_t seed) {
-    if (M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_STENCIL ||
+    if (M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_KIND_LAST ||
         (kind == SYNTH_BANDED && N < K))
         return ERR_PTR(-EINVAL);
     synth_spec s = {kind, M, N, K, W, row0, seed};
@@ -730,7 +730,8 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
         return ERR_PTR(-EOVERFLOW);
     static const char *names[] = {"synth_banded", "synth_random",
                                   "synth_ragged", "synth_kkt",
-                                  "synth_stencil"};
+                                  "synth_stencil", "synth_powerlaw",
+                                  "synth_hub"};
     sparse_csr *A = csr_alloc(names[kind], M, N, (int)nz);
     if (IS_ERR(A))
         return A;
@@ -746,7 +747,7 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
 int csr_synth_row_dots(int kind, int N, int K, int64_t W, uint64_t seed,
                        uint64_t xseed, const int64_t *rows, int n,
                        double *dot, double *scale) {
-    if (N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_STENCIL ||
+    if (N <= 0 || K <= 0 || kind < SYNTH_BANDED || kind > SYNTH_KIND_LAST ||
         (kind == SYNTH_BANDED && N < K) || n < 0 || (n && (!rows || !dot)))
         return -EINVAL;
     synth_spec s = {kind, 1, N, K, W, 0, seed};

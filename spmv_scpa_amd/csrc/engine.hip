@@ -12,7 +12,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <unordered_set>
+#include <string>
+#include <time.h>
+#include <unordered_map>
 #include <vector>
 
 #include "err.h"
@@ -20,6 +22,7 @@
 #include "hip_csr.h"
 #include "hip_hll.h"
 #include "spmv_synth.h"
+#include "tune_blocked.h"
 
 /* Process defaults behind set_*_waves_per_block (the reference's seam sets
  * them before every call).  0 = never set: the launch then picks by size --
@@ -40,15 +43,29 @@ static int default_waves(int user_default, long long rows) {
  * (free(d), the blocked copy's descriptor): a binding that released a handle
  * twice -- an explicit release() followed by a finaliser, two wrappers around
  * one handle, a finaliser running after an atexit sweep -- would corrupt the
- * host heap ("double free or corruption", the abort of round 2's GPU test
- * process).  Every handle is therefore entered here when it is created and a
- * release of anything that is not (or no longer) in the set is ignored.  The
- * set and its mutex are heap objects that are never destroyed, so a release
- * that arrives during static destruction still finds them.
+ * host heap.  Every handle is therefore entered here when it is created,
+ * together with a process-wide GENERATION number (1, 2, 3 ... never reused),
+ * and
+ *   - every public entry point that takes a handle checks it first (-EBADF for
+ *     a pointer that is not, or no longer, a live handle -- before anything is
+ *     allocated or dereferenced);
+ *   - a release of anything that is not in the set is ignored AND COUNTED
+ *     (spmv_ignored_releases(); one line on stderr per ignored release after
+ *     spmv_set_debug(1)), so a double release stays visible;
+ *   - spmv_*_release_checked(h, generation) releases only when the live handle
+ *     at that address still carries the generation the caller was given at
+ *     creation (spmv_handle_generation): a stale wrapper cannot release a NEW
+ *     handle that calloc happened to place at the old address.  Bindings with
+ *     finalisers (the Python one) use this form.
+ * The set and its mutex are heap objects that are never destroyed, so a
+ * release that arrives during static destruction still finds them.
  */
 struct live_set {
     std::mutex mu;
-    std::unordered_set<const void *> handles;
+    std::unordered_map<const void *, uint64_t> handles; /* -> generation */
+    uint64_t next_gen = 1;
+    long ignored = 0;
+    int debug = 0;
 };
 static live_set &live(void) {
     static live_set *s = new live_set();
@@ -56,186 +73,104 @@ static live_set &live(void) {
 }
 static void live_add(const void *h) {
     std::lock_guard<std::mutex> g(live().mu);
-    live().handles.insert(h);
+    live().handles[h] = live().next_gen++;
 }
-/* true exactly once per handle: the caller then owns the teardown */
-static bool live_take(const void *h) {
+static void live_ignored(const void *h, const char *why) {
+    /* caller holds the mutex */
+    ++live().ignored;
+    if (live().debug)
+        fprintf(stderr, "spmv_scpa_amd: release of %p ignored (%s)\n", h, why);
+}
+/* true exactly once per handle: the caller then owns the teardown.  gen != 0:
+ * only when the live handle at this address has that generation */
+static bool live_take(const void *h, uint64_t gen = 0) {
     std::lock_guard<std::mutex> g(live().mu);
-    return live().handles.erase(h) == 1;
+    auto it = live().handles.find(h);
+    if (it == live().handles.end()) {
+        live_ignored(h, "not a live handle: released before, or never one");
+        return false;
+    }
+    if (gen && it->second != gen) {
+        live_ignored(h, "stale generation: the address now holds a newer handle");
+        return false;
+    }
+    live().handles.erase(it);
+    return true;
 }
 static bool live_has(const void *h) {
     std::lock_guard<std::mutex> g(live().mu);
     return live().handles.count(h) == 1;
 }
+/* first statement of every public entry point that takes a handle */
+#define HANDLE_OK(h)                                                          \
+    do {                                                                      \
+        if (!(h))                                                             \
+            return -EINVAL;                                                   \
+        if (!live_has(h))                                                     \
+            return -EBADF; /* released, or never a handle */                  \
+    } while (0)
 
-/*
- * The 2-D blocked path as a candidate.  `*bms` is the best direct kernel's
- * time on entry.  Near the stream rate (within 1.2x of it at 7 TB/s) nothing
- * is built.  Otherwise the steps layout is built at two tile heights (8192
- * and 16384 rows for 10M rows, lower for smaller matrices) and timed both as
- * one chain launch and as one launch per step:
- * column-sorted buckets turn the gathers of a banded / clustered / skewed
- * matrix into a few whole-line requests (chain, random W = 2^14: 0.63 vs
- * 1.19 ms direct; W = 2^17: 0.68 vs 1.58; W = 2^20: 0.89 vs 2.9; skewed rows
- * 0.165 vs 0.51; 27-point stencil 0.44 vs 0.52).  When the direct kernels
- * run beyond 2.5x the stream time the rows reach far outside an L2 and the
- * sweep schedule is tried too (config 3: 1.6 ms vs 1.9 chain vs 5.8 direct).
- * The winner stays in `*slot` (12 B per entry); returns 1 when a blocked
- * form won, 0 when not, < 0 on a device error.  Out of memory / index
- * overflow just drops the candidate.
- */
-template <class Build, class Time>
-static int tune_blocked(spmv_panels **slot, int M, double stream_ms,
-                        double *bms, Build build, Time time_it) {
-    if (*bms <= 1.2 * stream_ms)
-        return 0;
-    spmv_panels *const original = *slot; /* caller-built copy, if any */
-    spmv_panels *keep = NULL;            /* best blocked copy so far */
-    int err = 0;
-    /* a blocked copy costs 12 B per entry: it has to win by 5 % over the
-     * direct kernels (not over another blocked candidate) to be kept */
-    const double direct_ms = *bms;
-    double last_m = 1e300; /* time of the candidate tried last */
-    /* build + time one candidate (steps layout: in both launch modes); keeps
-     * it when it beats everything so far */
-    auto try_one = [&](int sched, int tile_rows) {
-        spmv_panels *cand = NULL;
-        int rc = build(sched, tile_rows, &cand);
-        if (rc == -ENOMEM || rc == -EOVERFLOW)
-            return;
-        if (rc) {
-            err = rc;
-            return;
-        }
-        *slot = cand;
-        double best_m = 1e300;
-        int best_chain = 0, best_waves = 0;
-        for (int chain = (sched == 0 ? 1 : 0); chain >= 0 && !err; --chain) {
-            panels_set_chain(cand, chain);
-            /* tall tiles leave room for one workgroup per CU: 1024 lanes
-             * (16 wavefronts) or the 512 of the heuristic, whichever runs
-             * faster (W = 2^20 at 20448 rows: 0.80 vs 0.86 ms; W = N: 1.77
-             * vs 1.63) */
-            for (int waves = 0; waves <= (sched == 0 && chain &&
-                                          tile_rows >= 12288 ? 16 : 0);
-                 waves += 16) {
-                panels_set_waves(cand, waves);
-                double m = 0.0;
-                rc = time_it(&m);
-                if (rc) {
-                    err = rc;
-                    break;
-                }
-                if (m < best_m) {
-                    best_m = m;
-                    best_chain = chain;
-                    best_waves = waves;
-                }
-            }
-        }
-        panels_set_waves(cand, best_waves);
-        panels_set_chain(cand, best_chain);
-        if (!err && sched == 0) {
-            /* the best launch mode in the other two tile orders (the copy is
-             * built with order 0, grouped); another order has to win by 2 % */
-            int best_order = 0;
-            for (int order = 1; order <= 2 && !err; ++order) {
-                panels_set_order(cand, order);
-                double m = 0.0;
-                rc = time_it(&m);
-                if (rc)
-                    err = rc;
-                else if (m < 0.98 * best_m) {
-                    best_m = m;
-                    best_order = order;
-                }
-            }
-            panels_set_order(cand, best_order);
-        }
-        *slot = original;
-        last_m = err ? 1e300 : best_m;
-        /* a later blocked candidate has to beat the kept one by 3 %: two
-         * forms within run-to-run noise of each other (config 3: sweep 1.53
-         * vs chain at 20448 rows 1.55-1.60 ms) must not flip the pick from
-         * run to run -- a job's ranks, and the three passes of a profile,
-         * are to see the same kernel */
-        if (!err && best_m < *bms * (keep ? 0.97 : 1.0) &&
-            best_m < 0.95 * direct_ms) {
-            *bms = best_m;
-            panels_free(keep);
-            keep = cand;
-        } else {
-            panels_free(cand);
-        }
-    };
-    const bool far = *bms > 2.5 * stream_ms;
-    /* tile heights: tall tiles put more entries on a line of x, but the
-     * launch wants a few hundred of them (1M rows: 4096 rows 0.073 ms, 8192
-     * rows 0.109; 3M rows: 0.233 vs 0.267; 10M rows: 8192 or 16384) */
-    int t1 = 8192, t2 = 16384;
-    if (M < 4900000) {
-        t1 = 4096;
-        t2 = 8192;
+/* the blocked path as a candidate: tune_blocked.h with panels.hip's
+ * operations (the same template runs under ASan with mock copies) */
+struct panels_ops {
+    static void free(spmv_panels *p) { panels_free(p); }
+    static void set_chain(spmv_panels *p, int v) { panels_set_chain(p, v); }
+    static void set_waves(spmv_panels *p, int v) { panels_set_waves(p, v); }
+    static void set_order(spmv_panels *p, int v) { panels_set_order(p, v); }
+    static int balanced_tile_rows(int M, int max_rows) {
+        return panels_balanced_tile_rows(M, max_rows);
     }
-    if (M < 1500000) {
-        t1 = 256;
-        while (t1 * 2 <= M / 192 && t1 < 4096)
-            t1 *= 2;
-        t2 = t1 > 256 ? t1 / 2 : 0;
+    static double now_s(void) {
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
     }
-    /* rows that reach far beyond an L2 of x: the sweep schedule goes first
-     * and is the form to beat (it also scales better with the column count:
-     * one shard of the 80M-column problem 3.0 ms vs 3.4 chain) */
-    if (far)
-        try_one(1, 0);
-    if (!err)
-        try_one(0, t1);
-    const double m1 = last_m;
-    /* tall tiles run one workgroup per CU, so their height is balanced over
-     * whole rounds of the chip (panels_balanced_tile_rows): 13024 rows
-     * instead of 16384, 19552 instead of 20448 at 10M rows */
-    const int tall2 = t2 == 16384 ? panels_balanced_tile_rows(M, 16384) : t2;
-    const int tall3 = t2 == 16384 ? panels_balanced_tile_rows(M, 20448) : 0;
-    if (!err && tall2)
-        try_one(0, tall2);
-    const double m2 = last_m;
-    /* taller still (160 KiB of LDS) -- always tried on large matrices: round
-     * 2 tried it only when 16384 rows had beaten 8192, a comparison within
-     * run-to-run noise on W = 2^20, and the bench line then showed 0.90 ms
-     * where this height gives 0.77 -- and shorter still when height cost
-     * (nlpkkt160-shaped KKT matrix: 0.525 ms at 8192 rows, 0.596 at 16384) */
-    if (!err && tall3 && tall3 != tall2)
-        try_one(0, tall3);
-    if (!err && t2 == 16384 && m1 < m2 && m1 < last_m)
-        try_one(0, 4096);
-    if (err) {
-        panels_free(keep);
-        *slot = original;
-        return err;
+};
+
+/* what the selector did, kept in the handle (spmv_*_tune_log) */
+struct tune_log {
+    std::string text;
+    void operator()(const char *line) {
+        text += line;
+        text += '\n';
     }
-    if (keep) {
-        panels_free(original);
-        *slot = keep;
-        return 1;
-    }
-    return 0;
-}
+    char *release(void) const { return strdup(text.c_str()); }
+};
 
 extern "C" {
 
-const char *spmv_version(void) { return "spmv_scpa_amd 0.1 gfx950"; }
+/* 0.3: spmv_panel_opts.bucket_order; 0.4: spmv_panel_opts.struct_size (first
+ * field), spmv_*_release_checked, handle checks on every entry point */
+const char *spmv_version(void) { return "spmv_scpa_amd 0.4 gfx950"; }
 
 int spmv_live_handles(void) {
     std::lock_guard<std::mutex> g(live().mu);
     return (int)live().handles.size();
 }
 
+long spmv_ignored_releases(void) {
+    std::lock_guard<std::mutex> g(live().mu);
+    return live().ignored;
+}
+
+void spmv_set_debug(int on) {
+    std::lock_guard<std::mutex> g(live().mu);
+    live().debug = on ? 1 : 0;
+}
+
+uint64_t spmv_handle_generation(const void *handle) {
+    std::lock_guard<std::mutex> g(live().mu);
+    auto it = live().handles.find(handle);
+    return it == live().handles.end() ? 0 : it->second;
+}
+
+/* 1..16; 0 (or less) returns to the size-based default above */
 void set_csr_waves_per_block(int waves) {
-    g_csr_waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+    g_csr_waves = waves < 1 ? 0 : (waves > 16 ? 16 : waves);
 }
 
 void set_hll_waves_per_block(int waves) {
-    g_hll_waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+    g_hll_waves = waves < 1 ? 0 : (waves > 16 ? 16 : waves);
 }
 
 /* ------------------------------------------------------------------ */
@@ -471,7 +406,9 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
                  &d->max_row_len);
     {
         /* constant row length?  (O(M) over the host copy of IRP) */
-        int len = d->M > 0 ? host_irp[1] - host_irp[0] : 0;
+        /* (IRP[r] = r * len is what the kernel then computes: only for an
+         * IRP that starts at 0) */
+        int len = d->M > 0 && host_irp[0] == 0 ? host_irp[1] - host_irp[0] : 0;
         for (int r = 1; r < d->M && len > 0; ++r)
             if (host_irp[r + 1] - host_irp[r] != len)
                 len = 0;
@@ -512,16 +449,25 @@ int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
 /* CSR handle                                                           */
 /* ------------------------------------------------------------------ */
 
-void spmv_csr_release(spmv_csr_dev *d) {
-    if (!d || !live_take(d))
-        return; /* NULL, released before, or never a handle: ignored */
+static void csr_teardown(spmv_csr_dev *d) {
     (void)hipFree(d->irp);
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
     (void)hipFree(d->rowblk_mode);
     panels_free(d->panels);
+    free(d->tune_log);
     free(d);
+}
+
+void spmv_csr_release(spmv_csr_dev *d) {
+    if (d && live_take(d)) /* else: ignored, counted (spmv_ignored_releases) */
+        csr_teardown(d);
+}
+
+void spmv_csr_release_checked(spmv_csr_dev *d, uint64_t generation) {
+    if (d && generation && live_take(d, generation))
+        csr_teardown(d);
 }
 
 static int csr_alloc_dev(int M, int N, int64_t NZ, spmv_csr_dev **out) {
@@ -584,7 +530,7 @@ fail:
 int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
                       uint64_t seed, spmv_csr_dev **out) {
     if (!out || M < 0 || N <= 0 || K <= 0 || kind < SYNTH_BANDED ||
-        kind > SYNTH_STENCIL || (kind == SYNTH_BANDED && N < K))
+        kind > SYNTH_KIND_LAST || (kind == SYNTH_BANDED && N < K))
         return -EINVAL;
     *out = NULL;
     if (spmv_device_count() == 0)
@@ -633,8 +579,7 @@ fail:
 }
 
 int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ) {
-    if (!A)
-        return -EINVAL;
+    HANDLE_OK(A);
     if (M)
         *M = A->M;
     if (N)
@@ -645,12 +590,14 @@ int spmv_csr_shape(const spmv_csr_dev *A, int *M, int *N, int64_t *NZ) {
 }
 
 int64_t spmv_csr_algorithmic_bytes(const spmv_csr_dev *A) {
+    HANDLE_OK(A);
     return 12 * A->NZ + 4 * ((int64_t)A->M + 1) + 8 * (int64_t)A->M +
            8 * (int64_t)A->N;
 }
 
 int spmv_csr_download(const spmv_csr_dev *A, sparse_csr **out) {
-    if (!A || !out)
+    HANDLE_OK(A);
+    if (!out)
         return -EINVAL;
     if (!A->ja && A->NZ > 0)
         return -ENODATA; /* spmv_csr_release_source() */
@@ -676,28 +623,25 @@ fail:
 }
 
 int spmv_csr_build_panels(spmv_csr_dev *A, int panel_cols) {
-    if (A && !A->ja && A->NZ > 0)
+    HANDLE_OK(A);
+    if (!A->ja && A->NZ > 0)
         return -ENODATA;
-    if (!A)
-        return -EINVAL;
     panels_free(A->panels);
     A->panels = NULL;
     return panels_from_csr(A, panel_cols, -1, 0, &A->panels);
 }
 
 int spmv_hll_build_panels(spmv_hll_dev *H, int panel_cols) {
-    if (H && !H->ja && H->slots > 0)
+    HANDLE_OK(H);
+    if (!H->ja && H->slots > 0)
         return -ENODATA;
-    if (!H)
-        return -EINVAL;
     panels_free(H->panels);
     H->panels = NULL;
     return panels_from_hll(H, panel_cols, -1, 0, &H->panels);
 }
 
 int spmv_csr_build_panels_opts(spmv_csr_dev *A, const spmv_panel_opts *opts) {
-    if (!A)
-        return -EINVAL;
+    HANDLE_OK(A);
     if (!A->ja && A->NZ > 0)
         return -ENODATA;
     panels_free(A->panels);
@@ -706,8 +650,7 @@ int spmv_csr_build_panels_opts(spmv_csr_dev *A, const spmv_panel_opts *opts) {
 }
 
 int spmv_hll_build_panels_opts(spmv_hll_dev *H, const spmv_panel_opts *opts) {
-    if (!H)
-        return -EINVAL;
+    HANDLE_OK(H);
     if (!H->ja && H->slots > 0)
         return -ENODATA;
     panels_free(H->panels);
@@ -718,7 +661,9 @@ int spmv_hll_build_panels_opts(spmv_hll_dev *H, const spmv_panel_opts *opts) {
 /* same schedule and tile height as `model`'s blocked copy (shards of one
  * matrix: tune one, build the others alike) */
 int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
-    if (!A || !model || !model->panels)
+    HANDLE_OK(A);
+    HANDLE_OK(model);
+    if (!model->panels)
         return -EINVAL;
     if (!A->ja && A->NZ > 0)
         return -ENODATA;
@@ -733,7 +678,9 @@ int spmv_csr_build_panels_like(spmv_csr_dev *A, const spmv_csr_dev *model) {
 }
 
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model) {
-    if (!H || !model || !model->panels)
+    HANDLE_OK(H);
+    HANDLE_OK(model);
+    if (!model->panels)
         return -EINVAL;
     if (!H->ja && H->slots > 0)
         return -ENODATA;
@@ -764,7 +711,8 @@ static int panels_info(const spmv_panels *P, int *steps, int *tiles,
 
 int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
                          int *panels, int64_t *entries) {
-    return A ? panels_info(A->panels, steps, tiles, panels, entries) : -EINVAL;
+    HANDLE_OK(A);
+    return panels_info(A->panels, steps, tiles, panels, entries);
 }
 
 /*
@@ -774,8 +722,7 @@ int spmv_csr_panels_info(const spmv_csr_dev *A, int *steps, int *tiles,
  * download, conversion and further build_panels calls return -ENODATA.
  */
 int spmv_csr_release_source(spmv_csr_dev *A) {
-    if (!A)
-        return -EINVAL;
+    HANDLE_OK(A);
     if (!A->panels)
         return -ENOENT; /* nothing else could run the matrix */
     (void)hipFree(A->ja);
@@ -786,8 +733,7 @@ int spmv_csr_release_source(spmv_csr_dev *A) {
 }
 
 int spmv_hll_release_source(spmv_hll_dev *H) {
-    if (!H)
-        return -EINVAL;
+    HANDLE_OK(H);
     if (!H->panels)
         return -ENOENT;
     (void)hipFree(H->ja);
@@ -806,36 +752,41 @@ static int panels_schedule_of(const spmv_panels *P) {
 }
 
 int spmv_csr_panels_schedule(const spmv_csr_dev *A) {
-    return A ? panels_schedule_of(A->panels) : -EINVAL;
+    HANDLE_OK(A);
+    return panels_schedule_of(A->panels);
 }
 
 int spmv_hll_panels_schedule(const spmv_hll_dev *H) {
-    return H ? panels_schedule_of(H->panels) : -EINVAL;
+    HANDLE_OK(H);
+    return panels_schedule_of(H->panels);
 }
 
 int spmv_csr_panels_describe(const spmv_csr_dev *A, char *buf, size_t len) {
-    return !A ? -EINVAL : A->panels ? panels_describe(A->panels, buf, len)
-                                    : -ENOENT;
+    HANDLE_OK(A);
+    return A->panels ? panels_describe(A->panels, buf, len) : -ENOENT;
 }
 
 int spmv_hll_panels_describe(const spmv_hll_dev *H, char *buf, size_t len) {
-    return !H ? -EINVAL : H->panels ? panels_describe(H->panels, buf, len)
-                                    : -ENOENT;
+    HANDLE_OK(H);
+    return H->panels ? panels_describe(H->panels, buf, len) : -ENOENT;
 }
 
 int spmv_csr_panels_tile_rows(const spmv_csr_dev *A) {
-    return !A ? -EINVAL : A->panels ? panels_tile_rows(A->panels) : -ENOENT;
+    HANDLE_OK(A);
+    return A->panels ? panels_tile_rows(A->panels) : -ENOENT;
 }
 
 int spmv_hll_panels_tile_rows(const spmv_hll_dev *H) {
-    return !H ? -EINVAL : H->panels ? panels_tile_rows(H->panels) : -ENOENT;
+    HANDLE_OK(H);
+    return H->panels ? panels_tile_rows(H->panels) : -ENOENT;
 }
 
 /* explicit schedule (0 steps, 1 sweep, 2 chain) and tile height (0: default;
  * ignored by sweep): ranks of a multi-GPU job build what rank 0 tuned */
 int spmv_csr_build_panels_as(spmv_csr_dev *A, int panel_cols, int sched,
                              int tile_rows) {
-    if (!A || sched < 0 || sched > 2)
+    HANDLE_OK(A);
+    if (sched < 0 || sched > 2)
         return -EINVAL;
     if (!A->ja && A->NZ > 0)
         return -ENODATA;
@@ -846,7 +797,8 @@ int spmv_csr_build_panels_as(spmv_csr_dev *A, int panel_cols, int sched,
 
 int spmv_hll_build_panels_as(spmv_hll_dev *H, int panel_cols, int sched,
                              int tile_rows) {
-    if (!H || sched < 0 || sched > 2)
+    HANDLE_OK(H);
+    if (sched < 0 || sched > 2)
         return -EINVAL;
     if (!H->ja && H->slots > 0)
         return -ENODATA;
@@ -857,17 +809,15 @@ int spmv_hll_build_panels_as(spmv_hll_dev *H, int panel_cols, int sched,
 
 int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries) {
-    return H ? panels_info(H->panels, steps, tiles, panels, entries) : -EINVAL;
+    HANDLE_OK(H);
+    return panels_info(H->panels, steps, tiles, panels, entries);
 }
 
 int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          const spmv_launch_opts *opts, const double *d_x,
                          double *d_y, int row_begin, int row_end,
                          void *stream) {
-    if (!A)
-        return -EINVAL;
-    if (!live_has(A))
-        return -EBADF; /* released (or never a) handle */
+    HANDLE_OK(A);
     if (kernel == SPMV_CSR_KERNEL_PANELS) {
         if (!A->panels || row_begin != 0 || row_end != A->M)
             return -EINVAL; /* build panels first; whole matrix only */
@@ -888,10 +838,7 @@ int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
 int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
                     const spmv_launch_opts *opts, const double *d_x,
                     double *d_y, void *stream) {
-    if (!A)
-        return -EINVAL;
-    if (!live_has(A))
-        return -EBADF;
+    HANDLE_OK(A);
     return spmv_csr_launch_rows(A, kernel, opts, d_x, d_y, 0, A->M, stream);
 }
 
@@ -899,15 +846,24 @@ int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
 /* HLL handle                                                           */
 /* ------------------------------------------------------------------ */
 
-void spmv_hll_release(spmv_hll_dev *d) {
-    if (!d || !live_take(d))
-        return; /* NULL, released before, or never a handle: ignored */
+static void hll_teardown(spmv_hll_dev *d) {
     (void)hipFree(d->ja);
     (void)hipFree(d->as);
     (void)hipFree(d->off);
     (void)hipFree(d->padmask);
     panels_free(d->panels);
+    free(d->tune_log);
     free(d);
+}
+
+void spmv_hll_release(spmv_hll_dev *d) {
+    if (d && live_take(d))
+        hll_teardown(d);
+}
+
+void spmv_hll_release_checked(spmv_hll_dev *d, uint64_t generation) {
+    if (d && generation && live_take(d, generation))
+        hll_teardown(d);
 }
 
 static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
@@ -1018,7 +974,8 @@ fail:
 
 int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
                       spmv_hll_dev **out) {
-    if (!A || !out)
+    HANDLE_OK(A);
+    if (!out)
         return -EINVAL;
     if (!A->ja && A->NZ > 0)
         return -ENODATA;
@@ -1064,8 +1021,7 @@ fail:
 
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major) {
-    if (!H)
-        return -EINVAL;
+    HANDLE_OK(H);
     if (M)
         *M = H->M;
     if (N)
@@ -1082,6 +1038,7 @@ int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
 }
 
 int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H) {
+    HANDLE_OK(H);
     return 12 * H->slots + 12 * (int64_t)H->nb + 8 * (int64_t)H->M +
            8 * (int64_t)H->N;
 }
@@ -1090,10 +1047,7 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                            const spmv_launch_opts *opts, const double *d_x,
                            double *d_y, int blk_begin, int blk_end,
                            void *stream) {
-    if (!H)
-        return -EINVAL;
-    if (!live_has(H))
-        return -EBADF; /* released (or never a) handle */
+    HANDLE_OK(H);
     int waves = pick_waves(opts, default_waves(g_hll_waves, H->M));
     if (kernel == SPMV_HLL_KERNEL_PANELS) {
         if (!H->panels || blk_begin != 0 || blk_end != H->nb)
@@ -1114,10 +1068,7 @@ int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
 int spmv_hll_launch(const spmv_hll_dev *H, int kernel,
                     const spmv_launch_opts *opts, const double *d_x,
                     double *d_y, void *stream) {
-    if (!H)
-        return -EINVAL;
-    if (!live_has(H))
-        return -EBADF;
+    HANDLE_OK(H);
     return spmv_hll_launch_blocks(H, kernel, opts, d_x, d_y, 0, H->nb, stream);
 }
 
@@ -1129,18 +1080,42 @@ int spmv_hll_launch(const spmv_hll_dev *H, int kernel,
 
 #define SPMV_VARIANT_FLUSH_RMW (1 << 29) /* A/B: the read-modify-write flush */
 
+/* scratch buffer of the cache flush; a selector run owns one for all its
+ * timed loops */
+struct flush_scratch {
+    double *buf = NULL;
+    size_t bytes = 0;
+    int reserve(size_t want) {
+        if (want <= bytes)
+            return 0;
+        (void)hipFree(buf);
+        buf = NULL;
+        bytes = 0;
+        HIP_RET(hipMalloc((void **)&buf, want));
+        HIP_RET(hipMemset(buf, 0, want));
+        bytes = want;
+        return 0;
+    }
+    ~flush_scratch() { (void)hipFree(buf); }
+};
+
 template <typename Launch>
 static int timed_loop(Launch launch, int warmup, int iters, size_t flush_bytes,
-                      double *ms_each, hipStream_t s, bool flush_rmw = false) {
+                      double *ms_each, hipStream_t s, bool flush_rmw = false,
+                      flush_scratch *shared = NULL) {
     int rc = 0;
     hipEvent_t e0 = NULL, e1 = NULL;
+    flush_scratch own;
+    flush_scratch *sc = shared ? shared : &own;
     double *scratch = NULL;
     size_t nflush = flush_bytes / sizeof(double);
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     if (nflush) {
-        HIP_TRY(hipMalloc((void **)&scratch, nflush * sizeof(double)));
-        HIP_TRY(hipMemsetAsync(scratch, 0, nflush * sizeof(double), s));
+        rc = sc->reserve(nflush * sizeof(double));
+        if (rc)
+            goto fail;
+        scratch = sc->buf;
     }
     for (int it = -warmup; it < iters; ++it) {
         if (nflush && flush_rmw)
@@ -1166,7 +1141,6 @@ fail:
         (void)hipEventDestroy(e0);
     if (e1)
         (void)hipEventDestroy(e1);
-    (void)hipFree(scratch);
     return rc;
 }
 
@@ -1176,7 +1150,8 @@ int spmv_csr_time(const spmv_csr_dev *A, int kernel,
                   const spmv_launch_opts *opts, const double *d_x, double *d_y,
                   int warmup, int iters, size_t flush_bytes, double *ms_each,
                   void *stream) {
-    if (!A || iters < 0 || warmup < 0 || (iters && !ms_each))
+    HANDLE_OK(A); /* before the scratch buffer of the flush is allocated */
+    if (iters < 0 || warmup < 0 || (iters && !ms_each))
         return -EINVAL;
     return timed_loop(
         [&]() { return spmv_csr_launch(A, kernel, opts, d_x, d_y, stream); },
@@ -1188,7 +1163,8 @@ int spmv_hll_time(const spmv_hll_dev *H, int kernel,
                   const spmv_launch_opts *opts, const double *d_x, double *d_y,
                   int warmup, int iters, size_t flush_bytes, double *ms_each,
                   void *stream) {
-    if (!H || iters < 0 || warmup < 0 || (iters && !ms_each))
+    HANDLE_OK(H);
+    if (iters < 0 || warmup < 0 || (iters && !ms_each))
         return -EINVAL;
     return timed_loop(
         [&]() { return spmv_hll_launch(H, kernel, opts, d_x, d_y, stream); },
@@ -1217,7 +1193,8 @@ static size_t tune_flush_bytes(int64_t algorithmic_bytes) {
 
 int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
                       int allow_panels, int *best_kernel, double *best_ms) {
-    if (!H || !best_kernel)
+    HANDLE_OK(H);
+    if (!best_kernel)
         return -EINVAL;
     const int cand_cm[2] = {1, 2}, cand_rm[2] = {3, 0};
     const int *cand = H->col_major ? cand_cm : cand_rm;
@@ -1226,6 +1203,16 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
     std::vector<double> ms(5);
     const size_t flush = tune_flush_bytes(spmv_hll_algorithmic_bytes(H));
     int best_order = H->order;
+    tune_log log;
+    char line[200];
+    const double t_begin = panels_ops::now_s();
+    memset(H->tune_ms, 0, sizeof H->tune_ms);
+    /* ONE scratch buffer for the cache flush of every timed loop below (a
+     * 1 GiB hipMalloc + memset + hipFree per loop otherwise) */
+    flush_scratch scratch;
+    int rc = scratch.reserve(flush);
+    if (rc)
+        return rc;
     for (int k = 0; k < 2; ++k)
         for (int order = 0; order < 3; ++order) { /* the workgroup orders */
             if (!H->col_major && order > 0)
@@ -1233,11 +1220,14 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
             spmv_launch_opts o;
             memset(&o, 0, sizeof o);
             o.variant = 1 << order; /* bit 0 hardware, 1 ranges, 2 grouped */
-            int rc = spmv_hll_time(H, cand[k], &o, d_x, d_y, 1, 5, flush,
-                                   ms.data(), NULL);
+            rc = timed_loop(
+                [&]() { return spmv_hll_launch(H, cand[k], &o, d_x, d_y, NULL); },
+                1, 5, flush, ms.data(), NULL, false, &scratch);
             if (rc)
                 return rc;
             double m = median_of(ms);
+            if (H->tune_ms[cand[k]] == 0.0 || m < H->tune_ms[cand[k]])
+                H->tune_ms[cand[k]] = m;
             /* another order has to win by 2 % over hardware order */
             if (m < (order == 0 || best != cand[k] ? bms : 0.98 * bms)) {
                 bms = m;
@@ -1246,56 +1236,107 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
             }
         }
     H->order = best_order;
+    snprintf(line, sizeof line,
+             "direct kernels: %.3f s; slots / nnz = %.3f (padding of the "
+             "format), widest hack block %d",
+             panels_ops::now_s() - t_begin,
+             H->NZ > 0 ? (double)H->slots / (double)H->NZ : 0.0, H->max_width);
+    log(line);
     if (allow_panels) {
         const double stream_ms =
             (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
-        int rc = tune_blocked(
+        rc = tune_blocked<spmv_panels, panels_ops>(
             &H->panels, H->M, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
                 return panels_from_hll(H, 0, sched, tile_rows, out);
             },
             [&](double *m) {
-                int r = spmv_hll_time(H, SPMV_HLL_KERNEL_PANELS, NULL, d_x, d_y,
-                                      1, 5, flush, ms.data(), NULL);
+                int r = timed_loop(
+                    [&]() {
+                        return spmv_hll_launch(H, SPMV_HLL_KERNEL_PANELS, NULL,
+                                               d_x, d_y, NULL);
+                    },
+                    1, 5, flush, ms.data(), NULL, false, &scratch);
                 *m = median_of(ms);
                 return r;
-            });
+            },
+            log);
         if (rc < 0)
             return rc;
-        if (rc > 0)
+        if (rc > 0) {
             best = SPMV_HLL_KERNEL_PANELS;
+            H->tune_ms[SPMV_HLL_KERNEL_PANELS] = bms;
+        }
     }
+    snprintf(line, sizeof line, "total %.3f s", panels_ops::now_s() - t_begin);
+    log(line);
+    free(H->tune_log);
+    H->tune_log = log.release();
     *best_kernel = best;
     if (best_ms)
         *best_ms = bms;
     return 0;
 }
 
+/*
+ * CSR candidates.  Always: the sub-wave kernel (three workgroup orders) and
+ * the stream kernel (two).  By the shape of the rows:
+ *   wave_row    (1)  mean row length >= 48 (a 64-lane wavefront per row wastes
+ *                    its lanes below that);
+ *   thread_row  (0)  mean row length < 6 -- the reference's plots show its
+ *                    thread-per-row kernel winning on roadNet / amazon
+ *                    (cuda_csr.cu:19-31), so the selector
+ *                    MEASURES it on such matrices instead of assuming;
+ *   block_row   (3)  longest row > 64 x the mean (cuda_csr.cu:96-140: the
+ *                    kernel for very long rows; it pays a workgroup per row,
+ *                    so it is timed with 2 launches, not 5, and skipped when
+ *                    the first one runs beyond 20x the best so far).
+ * profiles/r04_autotune_irregular.txt records what wins where.
+ */
 int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
                       int allow_panels, int *best_kernel, double *best_ms) {
-    if (!A || !best_kernel)
+    HANDLE_OK(A);
+    if (!best_kernel)
         return -EINVAL;
-    const int cand[3] = {2, 4, 1};
+    const double mean = A->M > 0 ? (double)A->NZ / A->M : 0.0;
+    const int cand[5] = {2, 4, 1, 0, 3};
     int best = -1;
     double bms = 1e300;
     std::vector<double> ms(5);
     const size_t flush = tune_flush_bytes(spmv_csr_algorithmic_bytes(A));
-    for (int k = 0; k < 3; ++k) {
-        if (cand[k] == 1 && A->M > 0 && (double)A->NZ / A->M < 48.0)
+    tune_log log;
+    char line[200];
+    const double t_begin = panels_ops::now_s();
+    memset(A->tune_ms, 0, sizeof A->tune_ms);
+    flush_scratch scratch;
+    int rc = scratch.reserve(flush);
+    if (rc)
+        return rc;
+    auto time_k = [&](int kernel, int variant, int iters, double *m) {
+        spmv_launch_opts o;
+        memset(&o, 0, sizeof o);
+        o.variant = variant;
+        int r = timed_loop(
+            [&]() { return spmv_csr_launch(A, kernel, &o, d_x, d_y, NULL); }, 1,
+            iters, flush, ms.data(), NULL, false, &scratch);
+        *m = median_of(std::vector<double>(ms.begin(), ms.begin() + iters));
+        return r;
+    };
+    for (int k = 0; k < 5; ++k) {
+        if (cand[k] == 1 && mean < 48.0)
             continue; /* a wavefront per row wastes lanes on short rows */
+        if (cand[k] == 0 && !(mean < 6.0))
+            continue; /* a lane per row: very short rows only */
+        if (cand[k] == 3 && !(A->M > 0 && (double)A->max_row_len > 64.0 * mean))
+            continue; /* a workgroup per row: a far longer row than the rest */
         double m;
         if (cand[k] == 2) { /* the sub-wave kernel in its three orders */
             static const int bit[3] = {1, 2, 32};
             double mo[3];
             for (int order = 0; order < 3; ++order) {
-                spmv_launch_opts o;
-                memset(&o, 0, sizeof o);
-                o.variant = bit[order];
-                int rc = spmv_csr_time(A, 2, &o, d_x, d_y, 1, 5, flush,
-                                       ms.data(), NULL);
+                rc = time_k(2, bit[order], 5, &mo[order]);
                 if (rc)
                     return rc;
-                mo[order] = median_of(ms);
             }
             int pick = 0;
             for (int order = 1; order < 3; ++order)
@@ -1306,51 +1347,111 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
         } else if (cand[k] == 4) { /* the stream kernel in its two orders */
             double mo[2];
             for (int grp = 0; grp < 2; ++grp) {
-                spmv_launch_opts o;
-                memset(&o, 0, sizeof o);
-                o.variant = grp ? 32 : 64;
-                int rc = spmv_csr_time(A, 4, &o, d_x, d_y, 1, 5, flush,
-                                       ms.data(), NULL);
+                rc = time_k(4, grp ? 32 : 64, 5, &mo[grp]);
                 if (rc)
                     return rc;
-                mo[grp] = median_of(ms);
             }
             A->stream_grouped = mo[1] < mo[0];
             m = mo[A->stream_grouped];
-        } else {
-            int rc = spmv_csr_time(A, cand[k], NULL, d_x, d_y, 1, 5, flush,
-                                   ms.data(), NULL);
+        } else if (cand[k] == 3) {
+            rc = time_k(3, 0, 1, &m); /* one launch first: it may be very slow */
+            if (!rc && m < 20.0 * bms)
+                rc = time_k(3, 0, 2, &m);
             if (rc)
                 return rc;
-            m = median_of(ms);
+        } else {
+            rc = time_k(cand[k], 0, 5, &m);
+            if (rc)
+                return rc;
         }
+        A->tune_ms[cand[k]] = m;
         if (m < bms) {
             bms = m;
             best = cand[k];
         }
     }
+    snprintf(line, sizeof line,
+             "direct kernels: %.3f s; mean row %.2f, longest %d; ms: "
+             "thread_row %.4f wave_row %.4f subwave_row %.4f block_row %.4f "
+             "stream %.4f (0 = not a candidate)",
+             panels_ops::now_s() - t_begin, mean, A->max_row_len,
+             A->tune_ms[0], A->tune_ms[1], A->tune_ms[2], A->tune_ms[3],
+             A->tune_ms[4]);
+    log(line);
     if (allow_panels) {
         const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
-        int rc = tune_blocked(
+        rc = tune_blocked<spmv_panels, panels_ops>(
             &A->panels, A->M, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
                 return panels_from_csr(A, 0, sched, tile_rows, out);
             },
             [&](double *m) {
-                int r = spmv_csr_time(A, SPMV_CSR_KERNEL_PANELS, NULL, d_x, d_y,
-                                      1, 5, flush, ms.data(), NULL);
+                int r = timed_loop(
+                    [&]() {
+                        return spmv_csr_launch(A, SPMV_CSR_KERNEL_PANELS, NULL,
+                                               d_x, d_y, NULL);
+                    },
+                    1, 5, flush, ms.data(), NULL, false, &scratch);
                 *m = median_of(ms);
                 return r;
-            });
+            },
+            log);
         if (rc < 0)
             return rc;
-        if (rc > 0)
+        if (rc > 0) {
             best = SPMV_CSR_KERNEL_PANELS;
+            A->tune_ms[SPMV_CSR_KERNEL_PANELS] = bms;
+        }
     }
+    snprintf(line, sizeof line, "total %.3f s", panels_ops::now_s() - t_begin);
+    log(line);
+    free(A->tune_log);
+    A->tune_log = log.release();
     *best_kernel = best;
     if (best_ms)
         *best_ms = bms;
     return 0;
+}
+
+/* per-kernel medians of the last spmv_*_autotune (ms; 0 = not a candidate),
+ * kernel ids 0 .. n-1 */
+int spmv_csr_tune_times(const spmv_csr_dev *A, double *ms, int n) {
+    HANDLE_OK(A);
+    if (!ms || n < 0)
+        return -EINVAL;
+    for (int k = 0; k < n; ++k)
+        ms[k] = k < 8 ? A->tune_ms[k] : 0.0;
+    return 0;
+}
+
+int spmv_hll_tune_times(const spmv_hll_dev *H, double *ms, int n) {
+    HANDLE_OK(H);
+    if (!ms || n < 0)
+        return -EINVAL;
+    for (int k = 0; k < n; ++k)
+        ms[k] = k < 8 ? H->tune_ms[k] : 0.0;
+    return 0;
+}
+
+static int copy_log(const char *log, char *buf, size_t len) {
+    if (!buf || !len)
+        return -EINVAL;
+    if (!log)
+        return -ENOENT; /* never tuned */
+    snprintf(buf, len, "%s", log);
+    return 0;
+}
+
+/* what the last spmv_*_autotune did, one line per phase with host-clock
+ * seconds (build / timing per blocked candidate); -ENOENT before any */
+int spmv_csr_tune_log(const spmv_csr_dev *A, char *buf, size_t len) {
+    HANDLE_OK(A);
+    return copy_log(A->tune_log, buf, len);
+}
+
+int spmv_hll_tune_log(const spmv_hll_dev *H, char *buf, size_t len) {
+    HANDLE_OK(H);
+    return copy_log(H->tune_log, buf, len);
 }
 
 /* ------------------------------------------------------------------ */

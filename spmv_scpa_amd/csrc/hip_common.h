@@ -96,6 +96,9 @@ struct spmv_csr_dev {
     int stream_grouped; /* stream kernel: ranges in grouped runs instead of
                            hardware order (spmv_csr_autotune measures both) */
     spmv_panels *panels; /* optional column-panel copy (kernel 5) */
+    double tune_ms[8];   /* last spmv_csr_autotune: best median per kernel id
+                            (0: not timed) */
+    char *tune_log;      /* ... and what it did, one line per phase (malloc) */
 };
 
 struct spmv_hll_dev {
@@ -122,6 +125,8 @@ struct spmv_hll_dev {
                           before the rewrite; read only when the blocked copy
                           is built */
     spmv_panels *panels; /* optional column-panel copy (kernel 4) */
+    double tune_ms[8];   /* last spmv_hll_autotune: best median per kernel id */
+    char *tune_log;
 };
 
 /* clamp the launch knob: waves per workgroup */

@@ -519,9 +519,12 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     *out = NULL;
     if (slots > (int64_t)INT32_MAX)
         return -EOVERFLOW;
-    static const spmv_panel_opts dflt = {-1, 0, 0, 0, 0, 0, 0, -1, 0};
+    spmv_panel_opts dflt;
+    spmv_panel_opts_default(&dflt);
     if (!o)
         o = &dflt;
+    if (o->struct_size != (int)sizeof(spmv_panel_opts))
+        return -EINVAL; /* caller built against another header (ABI note) */
     if (o->sched > 2 || o->panel_cols < 0 || o->tile_rows < 0 ||
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
@@ -1507,21 +1510,38 @@ int panels_from_hll_opts(const spmv_hll_dev *H, const spmv_panel_opts *o,
                         H->col_major, H->ja, H->as, H->padmask, out);
 }
 
+extern "C" void spmv_panel_opts_default(spmv_panel_opts *o) {
+    if (!o)
+        return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = (int)sizeof *o;
+    o->sched = -1;
+    o->sweep_layout = -1;
+}
+
 int panels_from_csr(const spmv_csr_dev *A, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1, 0};
+    spmv_panel_opts o;
+    spmv_panel_opts_default(&o);
+    o.sched = sched;
+    o.panel_cols = panel_cols;
+    o.tile_rows = tile_rows;
     return panels_from_csr_opts(A, &o, out);
 }
 
 int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
                     int tile_rows, spmv_panels **out) {
-    const spmv_panel_opts o = {sched, panel_cols, tile_rows, 0, 0, 0, 0, -1, 0};
+    spmv_panel_opts o;
+    spmv_panel_opts_default(&o);
+    o.sched = sched;
+    o.panel_cols = panel_cols;
+    o.tile_rows = tile_rows;
     return panels_from_hll_opts(H, &o, out);
 }
 
 /* the options a copy was built with (build_panels_like) */
 void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
-    memset(o, 0, sizeof *o);
+    spmv_panel_opts_default(o);
     o->sched = P->sweep ? 1 : P->chain ? 2 : 0;
     o->panel_cols = 0;
     o->tile_rows = P->sweep ? 0 : P->tile_rows;

@@ -9,7 +9,8 @@ MTX_CASES = ["gen", "sym", "pat", "cage4_like", "tail40", "ragged100", "sym70",
              "skew", "herm", "patgen", "freeform"]
 SYNTH_CASES = ["synth_banded", "synth_random", "synth_random_wide",
                "synth_ragged", "synth_kkt", "synth_stencil27",
-               "synth_stencil7"]
+               "synth_stencil7", "synth_powerlaw", "synth_powerlaw_k8",
+               "synth_hub"]
 
 _INT_KEYS = ("IRP", "JA", "shape", "hdr", "validate", "omp_nnz_threads",
              "error", "stride", "hll_bit_equal", "spec")

@@ -149,6 +149,11 @@ SYNTH = {
     "synth_kkt": (3, 3000, 3000, 16, 3000, 42, 7, 3000),
     "synth_stencil27": (4, 3500, 3500, 27, 0, 42, 7, 3500),   # 15x15x16 grid, ragged top
     "synth_stencil7": (4, 4096, 4096, 7, 16, 42, 7, 4096),
+    # reference matrix classes with very short rows + a heavy tail
+    # (scripts/download-matrices.py:7-38: webbase-1M / amazon0302 / roadNet-PA; dc1)
+    "synth_powerlaw": (5, 6000, 6000, 3, 12000, 42, 7, 6000),
+    "synth_powerlaw_k8": (5, 3000, 3500, 8, 1024, 42, 7, 3000),
+    "synth_hub": (6, 4000, 4000, 6, 256, 42, 7, 4000),   # hub row = all 4000 columns
 }
 
 

@@ -16,7 +16,7 @@ def _cases(n, seed):
     out = []
     for i in range(n):
         kind = int(rng.choice([S.SYNTH_BANDED, S.SYNTH_RANDOM, S.SYNTH_RAGGED,
-                               S.SYNTH_KKT]))
+                               S.SYNTH_KKT, S.SYNTH_POWERLAW, S.SYNTH_HUB]))
         M = int(rng.choice([1, 31, 33, 257, 5_000, 20_011, 60_000]))
         N = int(rng.choice([1, 64, 4_097, 30_000, 150_000]))
         K = int(rng.integers(1, 41))
@@ -33,7 +33,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(int(__import__("os").environ.get("SPMV_FUZZ_CASES", "24")), int(__import__("os").environ.get("SPMV_FUZZ_SEED", "2024"))), ids=lambda c: "c%d" % c[0])
+@pytest.mark.parametrize("case", _cases(int(__import__("os").environ.get("SPMV_FUZZ_CASES", "30")), int(__import__("os").environ.get("SPMV_FUZZ_SEED", "2024"))), ids=lambda c: "c%d" % c[0])
 def test_blocked_path_random_shapes(case, monkeypatch):
     _, kind, M, N, K, W, pc, tile = case
     IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)

@@ -90,6 +90,14 @@ SYNTH_SMALL = [
     ("31_rows", S.SYNTH_RANDOM, 31, 5, 64),
     ("33_rows", S.SYNTH_RAGGED, 33, 8, 64),
     ("long_rows", S.SYNTH_RANDOM, 300, 5000, 1 << 30),
+    # the reference's irregular classes (scripts/download-matrices.py:7-38):
+    # webbase / amazon / roadNet (mean 3, power-law tail) and dc1 (one row and
+    # one column far heavier than the rest)
+    ("powerlaw3", S.SYNTH_POWERLAW, 60_000, 3, 1 << 30),
+    ("powerlaw3_windowed", S.SYNTH_POWERLAW, 40_000, 3, 2048),
+    ("powerlaw8", S.SYNTH_POWERLAW, 30_011, 8, 1 << 30),
+    ("hub", S.SYNTH_HUB, 40_000, 6, 512),
+    ("hub_short", S.SYNTH_HUB, 20_000, 2, 1 << 30),
 ]
 
 
@@ -175,10 +183,14 @@ def test_bench_wrappers_and_reference_abi_names():
     S.csr_free(A)
 
 
-def test_persistent_handles_and_device_generation():
+@pytest.mark.parametrize("kind,M,N,K,W", [
+    (S.SYNTH_RAGGED, 50_021, 60_000, 32, 2048),
+    (S.SYNTH_POWERLAW, 150_001, 150_001, 3, 1 << 30),
+    (S.SYNTH_HUB, 50_021, 60_000, 6, 2048),
+], ids=["ragged", "powerlaw", "hub"])
+def test_persistent_handles_and_device_generation(kind, M, N, K, W):
     """upload once / launch many; device-side generation and device-side
     CSR->HLL agree bit-for-bit with the host path."""
-    kind, M, N, K, W = S.SYNTH_RAGGED, 50_021, 60_000, 32, 2048
     IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
     x = O.synth_x(7, 0, N)
     y_ref = O.csr_spmv(IRP, JA, AS, x)

@@ -1,0 +1,27 @@
+"""The selector's ownership logic (which blocked copies are built, kept and
+freed: spmv_scpa_amd/csrc/tune_blocked.h, the template engine.hip instantiates
+with panels.hip's operations) compiled for the CPU with mock copies and run
+under AddressSanitizer + UBSan: 20 000 seeded scenarios with failing builds,
+failing timing calls and every win / lose order.  ADVICE r03: the host-side
+swap / free logic of the round-2 abort's suspects, covered where a sanitizer
+exists (GPU sanitizers are not available on the pool)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tune_blocked_ownership_under_asan(tmp_path):
+    exe = str(tmp_path / "tune_blocked_asan")
+    subprocess.run(
+        ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined",
+         "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+         "-I", os.path.join(ROOT, "spmv_scpa_amd", "csrc"),
+         os.path.join(ROOT, "tests", "asan", "tune_blocked_asan.cc"),
+         "-o", exe], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
+    r = subprocess.run([exe, "20000"], capture_output=True, text=True, env=env)
+    sys.stdout.write(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "books balance" in r.stdout and "ERROR" not in r.stderr
