@@ -40,8 +40,10 @@ extern "C" {
 
 #define SPMV_NUM_CSR_KERNELS 5
 
-/* Wavefronts (64 lanes) per workgroup for subsequent one-shot calls;
- * valid 1..16, default 8.  (reference: set_csr_warps_per_block) */
+/* Wavefronts (64 lanes) per workgroup for subsequent calls that do not name
+ * one: 1..16 (larger values are clamped to 16); 0 or less returns to the
+ * default, which is picked by matrix size (4 below 2M rows, 8 from there).
+ * (reference: set_csr_warps_per_block) */
 void set_csr_waves_per_block(int waves);
 
 double csr_spmv_hip_thread_row(const sparse_csr *A, const double *x, double *y,

@@ -26,6 +26,7 @@ extern "C" {
 
 #define SPMV_NUM_HLL_KERNELS 4
 
+/* as set_csr_waves_per_block: 1..16, 0 = back to the size-based default */
 void set_hll_waves_per_block(int waves);
 
 double hll_spmv_hip_threads_row_major(const sparse_hll *H, const double *x,

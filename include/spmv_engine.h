@@ -68,6 +68,9 @@ int spmv_get_device(void);   /* current device or negative errno */
 int spmv_device_info(int device, char *name, size_t len, int *compute_units,
                      size_t *hbm_bytes);
 
+/* PCI bus id of a device, "dddd:bb:dd.f" (len >= 16) */
+int spmv_device_pci_bus_id(int device, char *buf, size_t len);
+
 /* free / total bytes of HBM on the current device (leak checks) */
 int spmv_dev_mem_info(size_t *free_bytes, size_t *total_bytes);
 

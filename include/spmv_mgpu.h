@@ -18,6 +18,7 @@
 #ifndef SPMV_MGPU_H
 #define SPMV_MGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "csr.h"
@@ -47,6 +48,30 @@ int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed);       /* synth_x on device */
  * kernel < 0: default of the shard format. */
 int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
                    double *ms_each);
+
+/* The bench shape: `warmup` untimed steps, then EXACTLY `steps` steps enqueued
+ * back to back between two all-device synchronisations; *wall_ms_total = the
+ * host clock across them (one process drives all devices, so this is the
+ * job's time), kernel_ms_avg[ngpus] = each device's mean event-timed kernel
+ * per step (events on the device's stream around the shard launch; may be
+ * NULL).  What `bench.py --native-mgpu` times. */
+int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
+                  double *wall_ms_total, double *kernel_ms_avg);
+
+/* the all-gather of y by itself, `iters` times; *ms_avg per exchange (0 with
+ * one device: there is no exchange) */
+int spmv_mgpu_exchange_only(spmv_mgpu *g, int iters, double *ms_avg);
+
+/* RCCL as linked (ncclGetVersion code, e.g. 22203), ranks of the
+ * communicator (ncclCommCount of device 0's), PCI bus id of device `rank` */
+int spmv_mgpu_rccl_version(void);
+int spmv_mgpu_comm_ranks(const spmv_mgpu *g);
+int spmv_mgpu_device_bus_id(const spmv_mgpu *g, int rank, char *buf, size_t len);
+
+/* shard `rank`: stored slots (HLL) or entries (CSR), algorithmic bytes per
+ * launch, one-line layout of its blocked copy ("" when none) */
+int spmv_mgpu_shard_info(const spmv_mgpu *g, int rank, int64_t *stored,
+                         int64_t *alg_bytes, char *layout, size_t len);
 
 /* measured kernel choice for the loaded shards (spmv_*_autotune per device,
  * device 0's pick for all); pass *kernel to spmv_mgpu_spmv() */

@@ -22,7 +22,10 @@
  *                            prints a strided sample of y + a checksum.
  *   time  <kind> <M> <N> <K> <W> <seed> <xseed> <reps> <thr> [<thr>...]
  *                            CPU baseline: reference serial + OpenMP benches
- *                            timed on the host cores (JSON on stdout).
+ *                            timed on the host cores (JSON on stdout);
+ *                            REF_TIME_WINDOW_MS: every sample repeats the
+ *                            single-shot bench until that much time is
+ *                            covered (CFS quota: see cmd_time).
  *
  * Doubles are printed as C99 hex floats (%a): exact round trip.
  */
@@ -236,11 +239,46 @@ static double median(double *v, int n) {
 }
 
 /*
- * CPU baseline: the reference's own serial and OpenMP benches (single shot
- * each, as the reference times them: clock() for serial, omp_get_wtime()
- * for OpenMP) repeated `reps` times; we report the first (cold, the
- * reference's own protocol) and the median.
+ * CPU baseline: the reference's own serial and OpenMP benches, each call a
+ * single shot as the reference times it (clock() for serial, omp_get_wtime()
+ * for OpenMP).  One SAMPLE = calls repeated until their reported durations add
+ * up to REF_TIME_WINDOW_MS (default 0: one call), its value the mean duration
+ * per call; `reps` samples per leg; we report the first call (cold, the
+ * reference's own protocol) and the MEDIAN of the samples.  The window exists
+ * because of CFS bandwidth control: under a cgroup CPU quota a run shorter
+ * than one 100 ms period can burn more CPU than the quota sustains (round 3:
+ * a 44 ms HLL run at 40 threads under a 16-CPU quota read 14.4 GFLOP/s, twice
+ * what the same box sustains); a window of >= 3 periods cannot.
  */
+typedef struct leg_times {
+    double cold_ms, median_ms;
+    int calls; /* per sample, largest */
+} leg_times;
+
+#define LEG(out_, reps_, window_ms_, decl_, call_, dur_, put_)                 \
+    do {                                                                       \
+        double smp_[64];                                                       \
+        (out_).calls = 0;                                                      \
+        for (int r_ = 0; r_ < (reps_); ++r_) {                                 \
+            double acc_ = 0.0;                                                 \
+            int n_ = 0;                                                        \
+            do {                                                               \
+                decl_;                                                         \
+                if (call_)                                                     \
+                    return 2;                                                  \
+                if (r_ == 0 && n_ == 0)                                        \
+                    (out_).cold_ms = (dur_);                                   \
+                acc_ += (dur_);                                                \
+                ++n_;                                                          \
+                put_;                                                          \
+            } while (acc_ < (window_ms_) && n_ < 4096);                        \
+            smp_[r_] = acc_ / n_;                                              \
+            if (n_ > (out_).calls)                                             \
+                (out_).calls = n_;                                             \
+        }                                                                      \
+        (out_).median_ms = median(smp_, (reps_));                              \
+    } while (0)
+
 static int cmd_time(int argc, char **a) {
     synth_spec s;
     uint64_t xseed;
@@ -250,6 +288,8 @@ static int cmd_time(int argc, char **a) {
         reps = 1;
     if (reps > 64)
         reps = 64;
+    const char *ew = getenv("REF_TIME_WINDOW_MS");
+    const double window_ms = ew ? atof(ew) : 0.0;
     double t0 = wall_ms();
     sparse_csr *A = synth_csr(&s);
     if (!A)
@@ -262,7 +302,8 @@ static int cmd_time(int argc, char **a) {
      * the 10M x 32 matrix.  REF_TIME_HLL=best (what bench.py asks for) keeps
      * them bounded instead: ONE conversion after the CSR ladder, then
      * bench_hll_serial and bench_hll_omp at the thread count that was best
-     * for CSR, one repetition each (hll.c:127-150, 178-211). */
+     * for CSR, `reps` samples each like every other leg (hll.c:127-150,
+     * 178-211). */
     const char *eh = getenv("REF_TIME_HLL");
     const int hll_best = eh && !strcmp(eh, "best");
     const int with_hll = !hll_best && !(eh && eh[0] == '0');
@@ -270,40 +311,30 @@ static int cmd_time(int argc, char **a) {
     if (with_hll && IS_ERR(H))
         return 2;
     double t_prep = wall_ms() - t0;
-    double d[64];
+    leg_times lt;
 
     printf("{\"rows\": %d, \"cols\": %d, \"nnz\": %d, \"prep_ms\": %.3f, "
-           "\"omp_max_threads\": %d, \"procs\": %d, \"runs\": [",
+           "\"omp_max_threads\": %d, \"procs\": %d, \"reps\": %d, "
+           "\"window_ms\": %.1f, \"runs\": [",
            A->M, A->N, A->NZ, t_prep, omp_get_max_threads(),
-           omp_get_num_procs());
+           omp_get_num_procs(), reps, window_ms);
     int first = 1;
 #define EMIT(fmt_, bench_, thr_)                                               \
     do {                                                                       \
-        double cold = d[0];                                                    \
-        double med = median(d, reps);                                          \
         printf("%s{\"format\": \"%s\", \"bench\": \"%s\", \"threads\": %d, "   \
-               "\"cold_ms\": %.6f, \"median_ms\": %.6f, \"gflops\": %.6f}",    \
-               first ? "" : ", ", fmt_, bench_, thr_, cold, med,               \
-               compute_gflops(med, A->NZ));                                    \
+               "\"cold_ms\": %.6f, \"median_ms\": %.6f, \"gflops\": %.6f, "    \
+               "\"calls_per_sample\": %d}",                                    \
+               first ? "" : ", ", fmt_, bench_, thr_, lt.cold_ms,              \
+               lt.median_ms, compute_gflops(lt.median_ms, A->NZ), lt.calls);   \
         first = 0;                                                             \
     } while (0)
 
-    for (int r = 0; r < reps; ++r) {
-        bench b;
-        if (bench_csr_serial(A, x.data, &b))
-            return 2;
-        d[r] = b.duration_ms;
-        vec_put(&b.data);
-    }
+    LEG(lt, reps, window_ms, bench b, bench_csr_serial(A, x.data, &b),
+        b.duration_ms, vec_put(&b.data));
     EMIT("CSR", "serial", 1);
     if (with_hll) {
-        for (int r = 0; r < reps; ++r) {
-            bench b;
-            if (bench_hll_serial(H, x.data, &b))
-                return 2;
-            d[r] = b.duration_ms;
-            vec_put(&b.data);
-        }
+        LEG(lt, reps, window_ms, bench b, bench_hll_serial(H, x.data, &b),
+            b.duration_ms, vec_put(&b.data));
         EMIT("HLL", "serial", 1);
     }
 
@@ -314,51 +345,29 @@ static int cmd_time(int argc, char **a) {
         if (thr < 1 || thr > omp_get_max_threads())
             continue; /* reference asserts on this (hll.c:184, csr.c:320) */
         OMP_WARMUP(thr);
-        for (int r = 0; r < reps; ++r) {
-            bench_omp b = {.num_threads = thr};
-            if (bench_csr_omp_guided(A, x.data, &b))
-                return 2;
-            d[r] = b.bench.duration_ms;
-            vec_put(&b.bench.data);
-        }
-        {
-            double tmp[64];
-            memcpy(tmp, d, sizeof(double) * (size_t)reps);
-            const double m = median(tmp, reps);
-            if (m < best_csr_ms) {
-                best_csr_ms = m;
-                best_thr = thr;
-            }
+        LEG(lt, reps, window_ms, bench_omp b = {.num_threads = thr},
+            bench_csr_omp_guided(A, x.data, &b), b.bench.duration_ms,
+            vec_put(&b.bench.data));
+        if (lt.median_ms < best_csr_ms) {
+            best_csr_ms = lt.median_ms;
+            best_thr = thr;
         }
         EMIT("CSR", "omp_guided", thr);
         int used = thr;
-        for (int r = 0; r < reps; ++r) {
-            bench_omp b = {.num_threads = thr};
-            if (bench_csr_omp_nnz_balancing(A, x.data, &b))
-                return 2;
-            d[r] = b.bench.duration_ms;
-            used = b.num_threads;
-            vec_put(&b.bench.data);
-        }
-        {
-            double tmp[64];
-            memcpy(tmp, d, sizeof(double) * (size_t)reps);
-            const double m = median(tmp, reps);
-            if (m < best_csr_ms) {
-                best_csr_ms = m;
-                best_thr = thr;
-            }
+        LEG(lt, reps, window_ms, bench_omp b = {.num_threads = thr},
+            bench_csr_omp_nnz_balancing(A, x.data, &b), b.bench.duration_ms,
+            (used = b.num_threads, vec_put(&b.bench.data)));
+        if (lt.median_ms < best_csr_ms) {
+            best_csr_ms = lt.median_ms;
+            best_thr = thr;
         }
         EMIT("CSR", "omp_nnz", used);
-        for (int r = 0; with_hll && r < reps; ++r) {
-            bench_omp b = {.num_threads = thr};
-            if (bench_hll_omp(H, x.data, &b))
-                return 2;
-            d[r] = b.bench.duration_ms;
-            vec_put(&b.bench.data);
-        }
-        if (with_hll)
+        if (with_hll) {
+            LEG(lt, reps, window_ms, bench_omp b = {.num_threads = thr},
+                bench_hll_omp(H, x.data, &b), b.bench.duration_ms,
+                vec_put(&b.bench.data));
             EMIT("HLL", "omp_guided", thr);
+        }
     }
     double hll_prep = 0.0;
     if (hll_best) {
@@ -367,20 +376,14 @@ static int cmd_time(int argc, char **a) {
         if (IS_ERR(H))
             return 2;
         hll_prep = wall_ms() - t1;
-        reps = 1;
-        bench b;
-        if (bench_hll_serial(H, x.data, &b))
-            return 2;
-        d[0] = b.duration_ms;
-        vec_put(&b.data);
+        LEG(lt, reps, window_ms, bench b, bench_hll_serial(H, x.data, &b),
+            b.duration_ms, vec_put(&b.data));
         EMIT("HLL", "serial", 1);
         if (best_thr > 1) {
             OMP_WARMUP(best_thr);
-            bench_omp bo = {.num_threads = best_thr};
-            if (bench_hll_omp(H, x.data, &bo))
-                return 2;
-            d[0] = bo.bench.duration_ms;
-            vec_put(&bo.bench.data);
+            LEG(lt, reps, window_ms, bench_omp bo = {.num_threads = best_thr},
+                bench_hll_omp(H, x.data, &bo), bo.bench.duration_ms,
+                vec_put(&bo.bench.data));
             EMIT("HLL", "omp_guided", best_thr);
         }
     }

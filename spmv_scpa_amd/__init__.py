@@ -334,6 +334,21 @@ def device_count():
     return _lib.spmv_device_count()
 
 
+def device_pci_bus_id(device):
+    buf = C.create_string_buffer(32)
+    _check(_lib.spmv_device_pci_bus_id(device, buf, 32),
+           "spmv_device_pci_bus_id")
+    return buf.value.decode()
+
+
+def rccl_version():
+    """RCCL linked into the product library, as "2.22.3" (ncclGetVersion)"""
+    v = _lib.spmv_mgpu_rccl_version()
+    if v < 0:
+        return None
+    return "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100)
+
+
 def set_device(d):
     _check(_lib.spmv_set_device(d), "spmv_set_device")
 
@@ -828,8 +843,8 @@ class CsrDevice:
 
     def tune_log(self):
         """what the last autotune did (text, one line per phase) or None"""
-        buf = C.create_string_buffer(4096)
-        rc = _lib.spmv_csr_tune_log(self.h, buf, 4096)
+        buf = C.create_string_buffer(16384)
+        rc = _lib.spmv_csr_tune_log(self.h, buf, 16384)
         return None if rc else buf.value.decode()
 
     def download(self):
@@ -947,8 +962,8 @@ class HllDevice:
 
     def tune_log(self):
         """what the last autotune did (text, one line per phase) or None"""
-        buf = C.create_string_buffer(4096)
-        rc = _lib.spmv_hll_tune_log(self.h, buf, 4096)
+        buf = C.create_string_buffer(16384)
+        rc = _lib.spmv_hll_tune_log(self.h, buf, 16384)
         return None if rc else buf.value.decode()
 
     @property
@@ -1023,6 +1038,15 @@ _sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
 _sig("spmv_mgpu_fill_x", C.c_int, C.c_void_p, C.c_uint64)
 _sig("spmv_mgpu_spmv", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp)
 _sig("spmv_mgpu_autotune", C.c_int, C.c_void_p, _ip)
+_sig("spmv_mgpu_run", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp)
+_sig("spmv_mgpu_exchange_only", C.c_int, C.c_void_p, C.c_int, _dp)
+_sig("spmv_mgpu_rccl_version", C.c_int)
+_sig("spmv_mgpu_comm_ranks", C.c_int, C.c_void_p)
+_sig("spmv_mgpu_device_bus_id", C.c_int, C.c_void_p, C.c_int, C.c_char_p,
+     C.c_size_t)
+_sig("spmv_mgpu_shard_info", C.c_int, C.c_void_p, C.c_int,
+     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_size_t)
+_sig("spmv_device_pci_bus_id", C.c_int, C.c_int, C.c_char_p, C.c_size_t)
 _sig("spmv_mgpu_get_y", C.c_int, C.c_void_p, C.c_int, _dp)
 _sig("spmv_mgpu_info", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64),
      C.POINTER(C.c_int64))
@@ -1076,6 +1100,51 @@ class MultiGpu:
         _check(_lib.spmv_mgpu_spmv(self.h, kernel, warmup, iters,
                                    ms.ctypes.data_as(_dp)), "spmv_mgpu_spmv")
         return ms[:iters]
+
+    def run(self, kernel, warmup, steps):
+        """the bench shape (spmv_mgpu_run): -> (wall ms of the `steps` steps,
+        per-device mean kernel ms)"""
+        wall = C.c_double()
+        kms = np.zeros(self.n)
+        _check(_lib.spmv_mgpu_run(self.h, kernel, warmup, steps,
+                                  C.byref(wall), kms.ctypes.data_as(_dp)),
+               "spmv_mgpu_run")
+        return wall.value, kms
+
+    def exchange_only(self, iters=10):
+        ms = C.c_double()
+        _check(_lib.spmv_mgpu_exchange_only(self.h, iters, C.byref(ms)),
+               "spmv_mgpu_exchange_only")
+        return ms.value
+
+    def comm_ranks(self):
+        return _lib.spmv_mgpu_comm_ranks(self.h)
+
+    def bus_ids(self):
+        out = []
+        for r in range(self.n):
+            buf = C.create_string_buffer(32)
+            _check(_lib.spmv_mgpu_device_bus_id(self.h, r, buf, 32),
+                   "spmv_mgpu_device_bus_id")
+            out.append(buf.value.decode())
+        return out
+
+    def shard_info(self, rank=0):
+        """-> (stored slots / entries, algorithmic bytes, blocked layout or "")"""
+        st, by = C.c_int64(), C.c_int64()
+        buf = C.create_string_buffer(256)
+        _check(_lib.spmv_mgpu_shard_info(self.h, rank, C.byref(st),
+                                         C.byref(by), buf, 256),
+               "spmv_mgpu_shard_info")
+        return st.value, by.value, buf.value.decode()
+
+    def info(self):
+        """-> (ngpus, rows per gpu, nnz total, algorithmic bytes per gpu)"""
+        n, r = C.c_int(), C.c_int()
+        nz, by = C.c_int64(), C.c_int64()
+        _check(_lib.spmv_mgpu_info(self.h, C.byref(n), C.byref(r),
+                                   C.byref(nz), C.byref(by)), "spmv_mgpu_info")
+        return n.value, r.value, nz.value, by.value
 
     def get_y(self, rank=0):
         y = np.zeros(self.M)

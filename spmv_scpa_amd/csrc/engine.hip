@@ -120,6 +120,7 @@ struct panels_ops {
     static int balanced_tile_rows(int M, int max_rows) {
         return panels_balanced_tile_rows(M, max_rows);
     }
+    static const char *build_phases(void) { return panels_last_build_phases(); }
     static double now_s(void) {
         struct timespec t;
         clock_gettime(CLOCK_MONOTONIC, &t);
@@ -211,6 +212,16 @@ int spmv_device_info(int device, char *name, size_t len, int *compute_units,
         *compute_units = p.multiProcessorCount;
     if (hbm_bytes)
         *hbm_bytes = p.totalGlobalMem;
+    return 0;
+}
+
+/* "0000:c1:00.0": which physical card a rank drives (multi-GPU lines) */
+int spmv_device_pci_bus_id(int device, char *buf, size_t len) {
+    if (!buf || len < 16)
+        return -EINVAL;
+    if (spmv_device_count() == 0)
+        return -ENODEV;
+    HIP_RET(hipDeviceGetPCIBusId(buf, (int)len, device));
     return 0;
 }
 
@@ -1260,7 +1271,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
                 *m = median_of(ms);
                 return r;
             },
-            log);
+            [&](const char *l) { log(l); }); /* by reference */
         if (rc < 0)
             return rc;
         if (rc > 0) {
@@ -1288,9 +1299,9 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
  *                    (cuda_csr.cu:19-31), so the selector
  *                    MEASURES it on such matrices instead of assuming;
  *   block_row   (3)  longest row > 64 x the mean (cuda_csr.cu:96-140: the
- *                    kernel for very long rows; it pays a workgroup per row,
- *                    so it is timed with 2 launches, not 5, and skipped when
- *                    the first one runs beyond 20x the best so far).
+ *                    kernel for very long rows; it pays a workgroup per row).
+ *                    Both extras are timed with ONE launch first and dropped
+ *                    there when that runs beyond 20x the best so far.
  * profiles/r04_autotune_irregular.txt records what wins where.
  */
 int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
@@ -1353,10 +1364,13 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
             }
             A->stream_grouped = mo[1] < mo[0];
             m = mo[A->stream_grouped];
-        } else if (cand[k] == 3) {
-            rc = time_k(3, 0, 1, &m); /* one launch first: it may be very slow */
+        } else if (cand[k] == 3 || cand[k] == 0) {
+            /* one launch first: a workgroup per row over millions of short
+             * rows, or one lane walking a row of 10^5 entries, can be orders
+             * of magnitude off -- then one sample is the answer */
+            rc = time_k(cand[k], 0, 1, &m);
             if (!rc && m < 20.0 * bms)
-                rc = time_k(3, 0, 2, &m);
+                rc = time_k(cand[k], 0, cand[k] == 3 ? 2 : 5, &m);
             if (rc)
                 return rc;
         } else {
@@ -1395,7 +1409,7 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
                 *m = median_of(ms);
                 return r;
             },
-            log);
+            [&](const char *l) { log(l); }); /* by reference */
         if (rc < 0)
             return rc;
         if (rc > 0) {

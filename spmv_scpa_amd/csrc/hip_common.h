@@ -174,6 +174,7 @@ int panels_steps(const spmv_panels *P);
 int panels_tiles(const spmv_panels *P);
 int panels_balanced_tile_rows(int M, int max_rows);
 int panels_describe(const spmv_panels *P, char *buf, size_t len);
+const char *panels_last_build_phases(void);
 
 extern int g_csr_waves; /* process defaults behind set_*_waves_per_block */
 extern int g_hll_waves;

@@ -57,6 +57,24 @@ static bool mg_take(const spmv_mgpu *g) {
     return false;
 }
 
+static bool mg_has(const spmv_mgpu *g) {
+    std::lock_guard<std::mutex> lk(mg_mu());
+    const std::vector<const spmv_mgpu *> &v = mg_live();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == g)
+            return true;
+    return false;
+}
+/* first statement of every entry point: NULL -> -EINVAL, a destroyed (or
+ * never created) handle -> -EBADF, before it is dereferenced */
+#define MG_OK(g)                                                              \
+    do {                                                                      \
+        if (!(g))                                                             \
+            return -EINVAL;                                                   \
+        if (!mg_has(g))                                                       \
+            return -EBADF;                                                    \
+    } while (0)
+
 static int nccl_errno(ncclResult_t r) {
     return r == ncclSuccess ? 0 : (r == ncclSystemError ? -EIO : -EINVAL);
 }
@@ -169,6 +187,7 @@ fail:
 
 /* shard a host matrix: contiguous row ranges, boundaries multiples of 32 */
 int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
+    MG_OK(g);
     if (!g || !A)
         return -EINVAL;
     int *starts = partition_rows_even(A->M, g->n, HACK_SIZE);
@@ -208,6 +227,7 @@ fail:
 /* every device generates its own shard (spmv_synth.h), weak scaling */
 int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
                        int64_t W, uint64_t seed, int as_hll) {
+    MG_OK(g);
     if (!g || rows_per_gpu < 0 || rows_per_gpu % HACK_SIZE)
         return -EINVAL;
     int rc = 0;
@@ -233,6 +253,7 @@ fail:
 }
 
 int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host) {
+    MG_OK(g);
     if (!g || !x_host)
         return -EINVAL;
     int rc = 0;
@@ -247,6 +268,7 @@ fail:
 }
 
 int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed) {
+    MG_OK(g);
     if (!g)
         return -EINVAL;
     int rc = 0;
@@ -265,6 +287,7 @@ fail:
  * that did not keep a blocked copy builds one when the pick needs it).
  */
 int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
+    MG_OK(g);
     if (!g || !kernel)
         return -EINVAL;
     int rc = 0, pick = -1;
@@ -305,6 +328,9 @@ fail:
     return rc;
 }
 
+static int launch_shard(spmv_mgpu *g, int r, int kernel);
+static int gather_y(spmv_mgpu *g);
+
 static double wall_ms_now(void) {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
@@ -318,6 +344,7 @@ static double wall_ms_now(void) {
  */
 int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
                    double *ms_each) {
+    MG_OK(g);
     if (!g || iters < 0 || warmup < 0 || (iters && !ms_each))
         return -EINVAL;
     int rc = 0;
@@ -332,33 +359,12 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
         const double t0 = wall_ms_now();
         for (int r = 0; r < g->n && !rc; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
-            double *yfrag = g->y[r] + (size_t)r * g->rows_per_gpu;
-            rc = g->is_hll
-                     ? spmv_hll_launch(g->hll[r], kernel, NULL, g->x[r], yfrag,
-                                       g->stream[r])
-                     : spmv_csr_launch(g->csr[r], kernel, NULL, g->x[r], yfrag,
-                                       g->stream[r]);
+            rc = launch_shard(g, r, kernel);
         }
+        if (!rc)
+            rc = gather_y(g);
         if (rc)
             break;
-        if (g->n > 1) {
-            /* every call inside the group is checked, and the group is
-             * ALWAYS closed before an error leaves this function -- an open
-             * group would swallow the communicators' next operations */
-            NCCL_TRY(ncclGroupStart());
-            ncclResult_t first_bad = ncclSuccess;
-            for (int r = 0; r < g->n; ++r) {
-                const ncclResult_t e = ncclAllGather(
-                    g->y[r] + (size_t)r * g->rows_per_gpu, g->y[r],
-                    (size_t)g->rows_per_gpu, ncclDouble, g->comm[r],
-                    g->stream[r]);
-                if (e != ncclSuccess && first_bad == ncclSuccess)
-                    first_bad = e;
-            }
-            const ncclResult_t closed = ncclGroupEnd();
-            NCCL_TRY(first_bad);
-            NCCL_TRY(closed);
-        }
         for (int r = 0; r < g->n; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
             HIP_TRY(hipStreamSynchronize(g->stream[r]));
@@ -370,8 +376,174 @@ fail:
     return rc;
 }
 
+static int launch_shard(spmv_mgpu *g, int r, int kernel) {
+    double *yfrag = g->y[r] + (size_t)r * g->rows_per_gpu;
+    return g->is_hll ? spmv_hll_launch(g->hll[r], kernel, NULL, g->x[r], yfrag,
+                                       g->stream[r])
+                     : spmv_csr_launch(g->csr[r], kernel, NULL, g->x[r], yfrag,
+                                       g->stream[r]);
+}
+
+/* one grouped in-place all-gather of y over all devices (n > 1) */
+static int gather_y(spmv_mgpu *g) {
+    int rc = 0;
+    if (g->n < 2)
+        return 0;
+    /* every call inside the group is checked, and the group is ALWAYS closed
+     * before an error leaves this function */
+    NCCL_TRY(ncclGroupStart());
+    {
+        ncclResult_t first_bad = ncclSuccess;
+        for (int r = 0; r < g->n; ++r) {
+            const ncclResult_t e = ncclAllGather(
+                g->y[r] + (size_t)r * g->rows_per_gpu, g->y[r],
+                (size_t)g->rows_per_gpu, ncclDouble, g->comm[r], g->stream[r]);
+            if (e != ncclSuccess && first_bad == ncclSuccess)
+                first_bad = e;
+        }
+        const ncclResult_t closed = ncclGroupEnd();
+        NCCL_TRY(first_bad);
+        NCCL_TRY(closed);
+    }
+fail:
+    return rc;
+}
+
+static int sync_all(spmv_mgpu *g) {
+    int rc = 0;
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipStreamSynchronize(g->stream[r]));
+    }
+fail:
+    return rc;
+}
+
+int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
+                  double *wall_ms_total, double *kernel_ms_avg) {
+    MG_OK(g);
+    if (!g || steps < 1 || warmup < 0 || !wall_ms_total)
+        return -EINVAL;
+    int rc = 0;
+    device_guard keep;
+    if (kernel < 0)
+        kernel = g->is_hll ? 1 : 2;
+    /* one event pair per device and step */
+    std::vector<hipEvent_t> ev((size_t)g->n * steps * 2, NULL);
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        for (int k = 0; k < 2 * steps; ++k)
+            HIP_TRY(hipEventCreate(&ev[((size_t)r * steps) * 2 + k]));
+    }
+    for (int it = -warmup; it < steps && !rc; ++it) {
+        if (it == 0) {
+            rc = sync_all(g);
+            if (rc)
+                break;
+            *wall_ms_total = wall_ms_now();
+        }
+        for (int r = 0; r < g->n && !rc; ++r) {
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            if (it >= 0)
+                HIP_TRY(hipEventRecord(ev[((size_t)r * steps + it) * 2],
+                                       g->stream[r]));
+            rc = launch_shard(g, r, kernel);
+            if (!rc && it >= 0)
+                HIP_TRY(hipEventRecord(ev[((size_t)r * steps + it) * 2 + 1],
+                                       g->stream[r]));
+        }
+        if (!rc)
+            rc = gather_y(g);
+    }
+    if (!rc)
+        rc = sync_all(g);
+    if (!rc) {
+        *wall_ms_total = wall_ms_now() - *wall_ms_total;
+        for (int r = 0; r < g->n && kernel_ms_avg; ++r) {
+            double acc = 0.0;
+            for (int it = 0; it < steps; ++it) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(
+                    &ms, ev[((size_t)r * steps + it) * 2],
+                    ev[((size_t)r * steps + it) * 2 + 1]));
+                acc += ms;
+            }
+            kernel_ms_avg[r] = acc / steps;
+        }
+    }
+fail:
+    for (size_t k = 0; k < ev.size(); ++k)
+        if (ev[k])
+            (void)hipEventDestroy(ev[k]);
+    return rc;
+}
+
+int spmv_mgpu_exchange_only(spmv_mgpu *g, int iters, double *ms_avg) {
+    MG_OK(g);
+    if (!g || iters < 1 || !ms_avg)
+        return -EINVAL;
+    device_guard keep;
+    *ms_avg = 0.0;
+    if (g->n < 2)
+        return 0;
+    int rc = gather_y(g); /* warm */
+    if (!rc)
+        rc = sync_all(g);
+    const double t0 = wall_ms_now();
+    for (int it = 0; it < iters && !rc; ++it)
+        rc = gather_y(g);
+    if (!rc)
+        rc = sync_all(g);
+    if (!rc)
+        *ms_avg = (wall_ms_now() - t0) / iters;
+    return rc;
+}
+
+int spmv_mgpu_rccl_version(void) {
+    int v = 0;
+    return ncclGetVersion(&v) == ncclSuccess ? v : -EIO;
+}
+
+int spmv_mgpu_comm_ranks(const spmv_mgpu *g) {
+    MG_OK(g);
+    if (!g || g->comm.empty() || !g->comm[0])
+        return -EINVAL;
+    int n = 0;
+    return ncclCommCount(g->comm[0], &n) == ncclSuccess ? n : -EIO;
+}
+
+int spmv_mgpu_device_bus_id(const spmv_mgpu *g, int rank, char *buf,
+                            size_t len) {
+    MG_OK(g);
+    if (!g || rank < 0 || rank >= g->n)
+        return -EINVAL;
+    return spmv_device_pci_bus_id(g->dev[rank], buf, len);
+}
+
+int spmv_mgpu_shard_info(const spmv_mgpu *g, int rank, int64_t *stored,
+                         int64_t *alg_bytes, char *layout, size_t len) {
+    MG_OK(g);
+    if (!g || rank < 0 || rank >= g->n || (!g->hll[rank] && !g->csr[rank]))
+        return -EINVAL;
+    if (stored)
+        *stored = g->hll[rank] ? g->hll[rank]->slots : g->csr[rank]->NZ;
+    if (alg_bytes)
+        *alg_bytes = g->hll[rank] ? spmv_hll_algorithmic_bytes(g->hll[rank])
+                                  : spmv_csr_algorithmic_bytes(g->csr[rank]);
+    if (layout && len) {
+        layout[0] = 0;
+        const int rc = g->hll[rank]
+                           ? spmv_hll_panels_describe(g->hll[rank], layout, len)
+                           : spmv_csr_panels_describe(g->csr[rank], layout, len);
+        if (rc && rc != -ENOENT)
+            return rc;
+    }
+    return 0;
+}
+
 /* the gathered y as device `rank` holds it (M doubles) */
 int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host) {
+    MG_OK(g);
     if (!g || rank < 0 || rank >= g->n || !y_host)
         return -EINVAL;
     device_guard keep;
@@ -383,6 +555,7 @@ int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host) {
 
 int spmv_mgpu_info(const spmv_mgpu *g, int *ngpus, int *rows_per_gpu,
                    int64_t *nnz_total, int64_t *bytes_per_gpu) {
+    MG_OK(g);
     if (!g)
         return -EINVAL;
     int64_t nz = 0, by = 0;

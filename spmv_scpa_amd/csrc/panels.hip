@@ -57,6 +57,8 @@
 #include <string.h>
 #include <vector>
 
+#include <time.h>
+
 #include "hip_common.h"
 
 #define TILE_ROWS_STEPS 4096 /* "steps" schedule default: 32 KiB of LDS */
@@ -510,6 +512,17 @@ static int bits_for(long long n) { /* smallest b with 2^b >= n */
     return b;
 }
 
+/* host-clock seconds of the last panels_build on this thread, by phase
+ * (allocations + keys, radix sort, bucket tables, gather into the copy):
+ * what spmv_*_autotune appends to its log */
+static thread_local char g_build_phases[160];
+const char *panels_last_build_phases(void) { return g_build_phases; }
+static double build_now_s(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
 static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                         int nb, const int *irp_or_null,
                         const int64_t *off_or_null, int col_major,
@@ -629,6 +642,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     int *span = NULL;                    /* per-tile first / last panel */
     const size_t n = (size_t)(slots > 0 ? slots : 1);
     int64_t total = 0;
+    double tp[5] = {build_now_s(), 0, 0, 0, 0};
+    g_build_phases[0] = 0;
 
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc((void **)&key[k], n * sizeof(uint64_t)));
@@ -648,6 +663,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                                pm_grid, (uint64_t)nbuckets, col_major,
                                off_or_null, ja, padmask, key[0], idx[0]);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        tp[1] = build_now_s();
         {
             hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
             hipcub::DoubleBuffer<unsigned> dv(idx[0], idx[1]);
@@ -666,6 +683,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             sidx = dv.Current();
         }
     }
+    tp[2] = build_now_s();
     {
         const int64_t buckets = nbuckets;
         const unsigned gb = (unsigned)((buckets + 256) / 256);
@@ -743,6 +761,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         goto fail;
     }
     P->total = total;
+    tp[3] = build_now_s();
     {
         const size_t m = (size_t)total + SWEEP_TAIL; /* zeros behind the data */
         HIP_TRY(hipMalloc((void **)&P->ent, m * sizeof(unsigned)));
@@ -775,6 +794,12 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                              CNT_STRIDE * sizeof(int);
         HIP_TRY(hipMalloc((void **)&P->phase_cnt, P->phase_cnt_bytes));
     }
+    tp[4] = build_now_s();
+    snprintf(g_build_phases, sizeof g_build_phases,
+             "%lld slots sorted: alloc+keys %.3f s, sort %.3f, bucket tables "
+             "%.3f, gather %.3f",
+             (long long)slots, tp[1] > 0 ? tp[1] - tp[0] : 0.0,
+             tp[1] > 0 ? tp[2] - tp[1] : 0.0, tp[3] - tp[2], tp[4] - tp[3]);
     *out = P;
     P = NULL;
 fail:

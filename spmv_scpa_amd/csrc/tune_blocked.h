@@ -26,7 +26,8 @@
  * overflow just drops the candidate.
  *
  * Ops (static members): free(P*), set_chain(P*, int), set_waves(P*, int),
- * set_order(P*, int), balanced_tile_rows(int M, int max_rows), now_s().
+ * set_order(P*, int), balanced_tile_rows(int M, int max_rows), now_s(),
+ * build_phases() (text: where the last build spent its time).
  * Build: int(int sched, int tile_rows, P **out) -- *out set only on success.
  * Time:  int(double *ms).   Log: void(const char *line).
  */
@@ -111,12 +112,13 @@ static int tune_blocked(P **slot, int M, double stream_ms, double *bms,
         *slot = original;
         last_m = err ? 1e300 : best_m;
         {
-            char line[160];
+            char line[400];
             snprintf(line, sizeof line,
-                     "blocked sched=%d tile_rows=%d: build %.3f s, %d timed "
-                     "configurations %.3f s, best %.4f ms%s",
-                     sched, tile_rows, t1 - t0, timed, Ops::now_s() - t1,
-                     err ? -1.0 : best_m, err ? " (error)" : "");
+                     "blocked sched=%d tile_rows=%d: build %.3f s (%s), %d "
+                     "timed configurations %.3f s, best %.4f ms%s",
+                     sched, tile_rows, t1 - t0, Ops::build_phases(), timed,
+                     Ops::now_s() - t1, err ? -1.0 : best_m,
+                     err ? " (error)" : "");
             log(line);
         }
         /* a later blocked candidate has to beat the kept one by 3 %: two

@@ -50,6 +50,7 @@ struct mock_ops {
         return max_rows / 32 * 32 - 32;
     }
     static double now_s(void) { return g_clock += 0.001; }
+    static const char *build_phases(void) { return "mock"; }
 };
 
 static mock_copy *new_copy(void) {

@@ -55,6 +55,16 @@ def test_two_ranks_share_one_gpu(extra):
     assert c["backend"].startswith("gloo REHEARSAL")
     assert j["rows_checked"] >= 258 + 3  # own rows + the other rank's
     assert c["rows_per_gpu"] == 320000 * (4 if strong else 1)
+    # the line says what joined and on which cards
+    rc = c["rccl"]
+    assert rc["nranks_joined"] == 2 and len(rc["devices"]) == 2
+    assert all(":" in d for d in rc["devices"]), rc  # PCI bus ids
+    assert rc["devices"][0] == rc["devices"][1]     # rehearsal: one card
+    assert rc["library_links"]                      # RCCL the product links
+    roof = j["roofline"]
+    assert len(roof["kernel_ms_per_rank"]) == 2
+    assert 0 < roof["kernel_ms_min_rank"] <= roof["kernel_ms_max_rank"]
+    assert "strong_speedup" in j  # top level; None without a 1-GPU denominator
     if strong:
         assert c["logical_shards_per_gpu"] == 4 and c["strong"] is None
         assert c["nnz_global"] == 8 * 320000 * 32 and c["exchange"] == "staged"
@@ -95,6 +105,8 @@ def test_four_ranks_share_one_gpu():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     c = j["config"]
     assert j["n_gpus"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+    assert c["rccl"]["nranks_joined"] == 4 and len(c["rccl"]["devices"]) == 4
+    assert len(j["roofline"]["kernel_ms_per_rank"]) == 4
     assert j["rows_checked"] >= 258 + 9  # own rows + 3 of each other rank
     assert c["nnz_global"] == 4 * 320000 * 32
     assert "exchange after the kernel" in c["exchange_arrangement"]

@@ -67,10 +67,12 @@ elif mode == "double":         # explicit release, then finalisers again
     dH, d_x, d_y = build()
     h = dH.h
     dH.release()
-    S._lib.spmv_hll_release(h)         # ignored by the library (live_take)
+    assert S.ignored_releases() == 0
+    S._lib.spmv_hll_release(h)         # ignored by the library, and counted
+    assert S.ignored_releases() == 1
     assert S._lib.spmv_live_handles() == 0
     dH2 = S.HllDevice.__new__(S.HllDevice)
-    dH2.h = h                          # a second wrapper of a dead handle
+    dH2.h, dH2.gen = h, 1              # a second wrapper of a dead handle
     assert S._lib.spmv_hll_launch(h, 1, None, d_x.ptr, d_y.ptr, None) == -9
 elif mode == "mgpu":           # communicator + shards left alive
     g = S.MultiGpu(1)
@@ -105,16 +107,85 @@ def test_exit_with_live_device_objects_is_clean(mode, tmp_path):
 
 def test_release_is_idempotent_and_counted():
     """in-process: a handle released explicitly is gone from the library's
-    live set, a second release (wrapper or raw) changes nothing"""
+    live set; a second release (raw) changes nothing and is COUNTED; every
+    entry point answers -EBADF for the dead handle before touching it"""
+    import ctypes as C
     before = S._lib.spmv_live_handles()
+    ign = S.ignored_releases()
     dA = S.CsrDevice.generate(S.SYNTH_BANDED, 50_000, 50_000, 16, 0, 0, 42)
     dH = dA.to_hll(True)
     assert S._lib.spmv_live_handles() == before + 2
+    assert 0 < dA.gen < dH.gen  # generations only grow
     raw = dH.h
     dH.release()
-    dH.release()
+    dH.release()            # the wrapper forgot the handle: not a library call
+    assert S.ignored_releases() == ign
     S._lib.spmv_hll_release(raw)
+    assert S.ignored_releases() == ign + 1
     assert S._lib.spmv_live_handles() == before + 1
+    EBADF = -9
+    buf = C.create_string_buffer(64)
+    k, ms = C.c_int(), C.c_double()
+    o = S._panel_opts()
+    for rc in (S._lib.spmv_hll_shape(raw, None, None, None, None, None, None),
+               S._lib.spmv_hll_algorithmic_bytes(raw),
+               S._lib.spmv_hll_build_panels(raw, 0),
+               S._lib.spmv_hll_build_panels_opts(raw, C.byref(o)),
+               S._lib.spmv_hll_build_panels_as(raw, 0, 2, 0),
+               S._lib.spmv_hll_build_panels_like(raw, raw),
+               S._lib.spmv_hll_panels_info(raw, None, None, None, None),
+               S._lib.spmv_hll_panels_schedule(raw),
+               S._lib.spmv_hll_panels_tile_rows(raw),
+               S._lib.spmv_hll_panels_describe(raw, buf, 64),
+               S._lib.spmv_hll_release_source(raw),
+               S._lib.spmv_hll_tune_log(raw, buf, 64),
+               S._lib.spmv_hll_time(raw, 1, None, None, None, 0, 1, 1 << 30,
+                                    C.byref(ms), None),
+               S._lib.spmv_hll_autotune(raw, None, None, 1, C.byref(k),
+                                        C.byref(ms))):
+        assert rc == EBADF, rc
+    assert S._lib.spmv_handle_generation(raw) == 0
     dA.release()
     assert S._lib.spmv_live_handles() == before
     assert dA not in S.live_objects() and dH not in S.live_objects()
+
+
+def test_stale_wrapper_cannot_release_a_newer_handle_at_the_same_address():
+    """the allocator may hand a released handle's address out again: the
+    checked release acts only on the generation the wrapper was created with"""
+    first = S.CsrDevice.generate(S.SYNTH_BANDED, 4_096, 4_096, 4, 0, 0, 42)
+    addr, gen = first.h.value, first.gen
+    first.release()
+    # create handles until one lands on the old address (calloc of one size
+    # class: usually the very next one)
+    made, twin = [], None
+    for _ in range(64):
+        d = S.CsrDevice.generate(S.SYNTH_BANDED, 4_096, 4_096, 4, 0, 0, 42)
+        made.append(d)
+        if d.h.value == addr:
+            twin = d
+            break
+    try:
+        if twin is None:
+            pytest.skip("the allocator did not reuse the address")
+        assert twin.gen != gen
+        ign = S.ignored_releases()
+        S._lib.spmv_csr_release_checked(addr, gen)   # the stale wrapper
+        assert S.ignored_releases() == ign + 1
+        d_x, d_y = S.DevBuffer(4_096 * 8), S.DevBuffer(4_096 * 8)
+        twin.launch(2, d_x.ptr, d_y.ptr)             # still alive
+        S.stream_sync()
+    finally:
+        for d in made:
+            d.release()
+
+
+def test_waves_per_block_zero_restores_the_size_based_default():
+    S._lib.set_csr_waves_per_block(2)
+    S._lib.set_csr_waves_per_block(0)   # back to auto (was: clamped to 1)
+    S._lib.set_hll_waves_per_block(0)
+    dA = S.CsrDevice.generate(S.SYNTH_BANDED, 50_000, 50_000, 16, 0, 0, 42)
+    d_x, d_y = S.DevBuffer(50_000 * 8), S.DevBuffer(50_000 * 8)
+    dA.launch(2, d_x.ptr, d_y.ptr)
+    S.stream_sync()
+    dA.release()

@@ -94,3 +94,72 @@ def test_driver_multi_gpu_flag(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "all-gather" in r.stdout
+
+
+def test_native_leg_of_bench_prints_the_same_line_shape():
+    """bench.py --native-mgpu: the library's own multi-GPU entry points
+    (spmv_mgpu_run: shard kernels + grouped ncclAllGather) measured in the
+    bench shape, printed with the keys of the torch.distributed line."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(
+        [sys.executable, os.path.join(S.ROOT, "bench.py"), "--native-mgpu",
+         "--gpus", "1", "--rows-per-gpu", "640000", "--steps", "3",
+         "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+        capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "strong_speedup"):
+        assert key in j, key
+    c = j["config"]
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 0
+    assert c["backend"].startswith("native")
+    assert c["rccl"]["nranks_joined"] == 1 and len(c["rccl"]["devices"]) == 1
+    assert ":" in c["rccl"]["devices"][0] and c["rccl"]["version"]
+    assert c["nnz_global"] == 640000 * 32 and j["rows_checked"] >= 258
+    assert len(j["roofline"]["kernel_ms_per_rank"]) == 1
+    assert j["roofline"]["kernel_ms_avg"] <= j["ms_per_step"] * 1.05
+
+
+def test_native_path_and_dist_path_give_the_same_y_on_one_shard():
+    """the two N > 1 implementations (mgpu.hip and spmv_scpa_amd/dist.py) run
+    the same shard with the same kernel: their y must agree bit for bit"""
+    import torch
+    from spmv_scpa_amd import dist as D
+    rows, K, W = 320_000, 32, 1 << 30
+    g = S.MultiGpu(1)
+    g.generate(S.SYNTH_RANDOM, rows, K, W, 42, as_hll=True)
+    g.fill_x(7)
+    wall, kms = g.run(1, 1, 2)  # thread-per-row col-major kernel
+    assert wall > 0 and len(kms) == 1 and kms[0] > 0
+    assert g.comm_ranks() == 1 and len(g.bus_ids()) == 1
+    stored, alg, layout = g.shard_info(0)
+    assert stored == rows * K and alg > 12 * stored and layout == ""
+    y_native = g.get_y(0)
+    raw = g.h
+    g.destroy()
+    # a destroyed handle is refused (-EBADF), not dereferenced
+    assert S._lib.spmv_mgpu_fill_x(raw, 7) == -9
+
+    dev = torch.device("cuda", 0)
+    x = torch.empty(rows, dtype=torch.float64, device=dev)
+    y = torch.zeros(rows, dtype=torch.float64, device=dev)
+    S.dev_fill_synth(x.data_ptr(), rows, 7, 0,
+                     torch.cuda.current_stream().cuda_stream)
+    dA = S.CsrDevice.generate(S.SYNTH_RANDOM, rows, rows, K, W, 0, 42)
+    dH = dA.to_hll(True)
+    dA.release()
+    sh = D.ShardedSpmv(dH, 1, 0, 1, rows, x, y)
+    sh.step()
+    torch.cuda.synchronize()
+    y_dist = y.cpu().numpy()
+    dH.release()
+    assert np.array_equal(y_native.view(np.uint64), y_dist.view(np.uint64))
+    for grow in (0, 12345, rows - 1):
+        want, sc = O.synth_row_dot(S.SYNTH_RANDOM, rows, rows, K, W, 0, 42, 7,
+                                   grow)
+        assert abs(y_native[grow] - want) <= 1e-12 * sc

@@ -31,7 +31,20 @@ CASES = [  # (label, family, rows, K, window; 0 = columns anywhere)
     ("stencil 27-point 203^3", "stencil", 203 ** 3, 27, 0),
     ("kkt skewed rows 8.3M", "kkt", 8_345_600, 16, 1 << 16),
 ]
-KIND = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3, "stencil": 4}
+# the reference's irregular classes (scripts/download-matrices.py:7-38):
+# webbase-1M / amazon0302 / roadNet-PA (mean 2-5 entries per row, power-law
+# tail) and dc1 (one row and one column far heavier than the rest)
+IRREGULAR = [
+    ("powerlaw K=3 1M anywhere", "powerlaw", 1_000_000, 3, 0),
+    ("powerlaw K=3 4M anywhere", "powerlaw", 4_000_000, 3, 0),
+    ("powerlaw K=3 4M W=4096", "powerlaw", 4_000_000, 3, 4096),
+    ("powerlaw K=8 2M anywhere", "powerlaw", 2_000_000, 8, 0),
+    ("hub K=6 1M W=4096", "hub", 1_000_000, 6, 4096),
+    ("hub K=3 4M anywhere", "hub", 4_000_000, 3, 0),
+    ("hub K=6 117K W=512 (dc1 size)", "hub", 116_835, 6, 512),
+]
+KIND = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3, "stencil": 4,
+        "powerlaw": 5, "hub": 6}
 
 
 def main():
@@ -40,15 +53,20 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--rows", type=int, default=0,
                     help="replace the 10M-row cases by this many rows")
+    ap.add_argument("--irregular", action="store_true",
+                    help="the power-law / hub families instead of the default list")
     a = ap.parse_args()
-    cases = CASES
+    cases = IRREGULAR if a.irregular else CASES
     if a.rows:
         cases = [(lab.replace("10M", "%gM" % (a.rows / 1e6)), fam, a.rows, K, W)
                  for lab, fam, M, K, W in CASES if M == 10_000_000]
     lines = ["# spmv_*_autotune picks, one MI355X (%s), %s"
              % (S.device_info(0)[0], time.strftime("%Y-%m-%d")),
              "# workload | format | pick | ms | GFLOP/s | %% of 8 TB/s | "
-             "tune s | layout of the blocked copy"]
+             "tune s | layout of the blocked copy",
+             "#   + per-kernel medians of the selector (ms; '-' = not a "
+             "candidate for this matrix); HLL: stored slots / nnz",
+             "#   + the selector's phase log when it took more than 1 s"]
     for label, fam, M, K, W in cases:
         if a.only and a.only not in label:
             continue
@@ -73,6 +91,21 @@ def main():
                             2 * m.NZ / ms / 1e6, 100 * b / ms / 1e6 / 8000,
                             tune, m.panels_describe() if best == pid else "-"))
             print(lines[-1], flush=True)
+            tm = m.tune_times()
+            detail = "    selector ms: " + "  ".join(
+                "%s %s" % (labels[k], ("%.4f" % tm[k]) if tm[k] > 0 else "-")
+                for k in range(len(tm)))
+            if fmt == "HLL":
+                detail += "   | slots / nnz = %.2f" % (m.slots / max(m.NZ, 1))
+            else:
+                detail += "   | rows %d, nnz %d, mean %.2f" % (
+                    m.M, m.NZ, m.NZ / max(m.M, 1))
+            lines.append(detail)
+            print(detail, flush=True)
+            if tune > 1.0:
+                for ln in (m.tune_log() or "").splitlines():
+                    lines.append("    log: " + ln)
+                    print(lines[-1], flush=True)
         dH.release()
         dA.release()
         d_x.free()
