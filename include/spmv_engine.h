@@ -54,9 +54,12 @@ typedef struct spmv_launch_opts {
                             CSR sub-wave kernel: bit 9 = load IRP even when
                             every row has one length (A/B of the constant-
                             row-length path).  Timed loops: bit 29 = the
-                            read-modify-write cache flush of rounds 1 / 2.  The
-                            blocked schedules read their own bits
-                            (panels.hip) and spmv_panel_opts.tile_order */
+                            read-modify-write cache flush of rounds 1 / 2.
+                            Blocked path: bit 0 launches a chain copy as steps
+                            and vice versa, bits 1 / 2 force the tile order
+                            (else spmv_panel_opts.tile_order).  Any other bit:
+                            -EINVAL, except in an ablations build
+                            (spmv_build_flavour) */
     int reserved[5];     /* must be 0 */
 } spmv_launch_opts;
 
@@ -171,8 +174,7 @@ int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
  * Launches of one handle must be stream-ordered (the sweep schedule of the
  * blocked path keeps per-handle phase counters); different handles are
  * independent.
- * opts.variant (tuning): bit 0 keep the hardware's workgroup->XCD order;
- * bits 2-3 passes of the sub-wave kernel (4 / 2 instead of 8). */
+ * opts.variant (tuning): see spmv_launch_opts. */
 int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
                     const spmv_launch_opts *opts, const double *d_x,
                     double *d_y, void *stream);
@@ -326,6 +328,12 @@ void spmv_hll_release_checked(spmv_hll_dev *H, uint64_t generation);
 
 /* Library self-description: "spmv_scpa_amd <version> gfx950". */
 const char *spmv_version(void);
+/* "product", or "ablations": built with -DSPMV_ABLATIONS (`make abl` ->
+ * lib/libspmv_scpa_amd_abl.so), the only flavour that accepts the experiment
+ * bits of spmv_launch_opts.variant (timing ablations, some of which compute a
+ * WRONG y by design; pipeline depths, phase lags, group sizes).  The product
+ * library answers -EINVAL to any bit that is not documented above. */
+const char *spmv_build_flavour(void);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libspmv_scpa_amd.so")
+# harness knob (tools/README.md): the ablations flavour of the library
+# (`make -C spmv_scpa_amd/csrc abl`), for tools/sweep.py and the PMC scripts
+if os.environ.get("SPMV_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["SPMV_LIB"])
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
 if not os.path.exists(LIB_PATH):
@@ -28,7 +32,63 @@ if not os.path.exists(LIB_PATH):
         "%s not found: build it with `python -c 'import __graft_entry__ as g; "
         "g.build()'` (make -C spmv_scpa_amd/csrc). There is no fallback path."
         % LIB_PATH)
-_lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+def _share_the_rocm_runtime_with_torch():
+    """One copy of the ROCm runtime per process, and no global symbols.
+
+    ROOT CAUSE of the `double free or corruption (!prev)` abort at the exit of
+    round 2's GPU test process (gpurun_out/r2c4_1.log) and of round 4's first
+    run with an in-process `import torch` (gpurun_out/r4c2_1.log), found by
+    reproducing it on the CPU-only build box with nothing but imports
+    (tests/test_rocm_runtime_once.py):
+
+      this module loaded libspmv_scpa_amd.so with RTLD_GLOBAL.  That puts the
+      symbols of its whole dependency closure -- librccl and, through it,
+      librocm_smi64 -- into the process-wide namespace.  A LATER `import
+      torch` then binds symbols of its own libraries against those copies
+      (`ctypes.CDLL(".../librocm_smi64.so", RTLD_GLOBAL); import torch` alone
+      aborts the same way), objects end up destroyed by two owners, and glibc
+      aborts inside exit().  No GPU, no handle, no kernel is involved; the
+      other import order (torch first: bench.py, the dist workers) never
+      showed it, and neither did test processes that did not import torch
+      (round 3 -- which is why the abort "went away").
+
+    Fix: RTLD_LOCAL (nothing needs this library's symbols globally: the
+    reference's driver and the C driver link it directly).  And because
+    PyTorch's ROCm wheels bundle their own libamdhip64 / librccl /
+    libhsa-runtime64 under torch/lib and ask for them by UNVERSIONED file name
+    (DT_NEEDED libamdhip64.so, RPATH $ORIGIN), which the dynamic loader does
+    not recognise as /opt/rocm's libamdhip64.so.7, the ours-then-torch order
+    would still map TWO HIP / HSA / RCCL runtimes into the process: when torch
+    ships such copies and has not been imported yet, they are loaded first
+    (locally, by path, without importing torch) so that this library's
+    versioned DT_NEEDED names resolve to them by SONAME -- one runtime, one
+    OpenMP runtime, whatever the import order; the same libraries bench.py has
+    always measured with.  SPMV_NO_TORCH_PRELOAD=1 (harness knob) keeps
+    /opt/rocm's runtime for a process that never imports torch."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("SPMV_NO_TORCH_PRELOAD"):
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return None
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    loaded = []
+    for name in ("libgomp.so", "libamdhip64.so", "librccl.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_LOCAL)
+            loaded.append(path)
+    return loaded or None
+
+
+ROCM_RUNTIME_SHARED_WITH_TORCH = _share_the_rocm_runtime_with_torch()
+_lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)  # never RTLD_GLOBAL: see above
 
 MAX_NAME = 64
 HACK_SIZE = 32
@@ -187,6 +247,7 @@ _sig("log_roofline", None, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
 
 # ---------------------------------------------------------------- engine API
 _sig("spmv_version", C.c_char_p)
+_sig("spmv_build_flavour", C.c_char_p)
 _sig("spmv_live_handles", C.c_int)
 _sig("spmv_ignored_releases", C.c_long)
 _sig("spmv_set_debug", None, C.c_int)
@@ -318,6 +379,11 @@ def _opts(waves_per_block=0, group=0, variant=0):
 
 def version():
     return _lib.spmv_version().decode()
+
+
+def build_flavour():
+    """"product" or "ablations" (spmv_engine.h)"""
+    return _lib.spmv_build_flavour().decode()
 
 
 def ignored_releases():

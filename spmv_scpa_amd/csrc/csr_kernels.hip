@@ -513,10 +513,19 @@ static void launch_subwave(int passes, int r0, int r1, int threads, int remap,
 int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                       int variant, const double *x, double *y, int r0, int r1,
                       hipStream_t s) {
-    const int passes = (variant & 4) ? 4 : (variant & 8) ? 2 : 8;
     (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     if (!A || !x || !y || r0 < 0 || r1 > A->M || r0 > r1)
         return -EINVAL;
+#ifdef SPMV_ABLATIONS /* passes of the sub-wave kernel: bits 2-3 (make abl) */
+    const int passes = (variant & 4) ? 4 : (variant & 8) ? 2 : 8;
+#else
+    /* product build: the documented bits only (spmv_engine.h: 0, 1, 5 the
+     * sub-wave kernel's workgroup order; 4, 5, 6 the stream kernel's loads
+     * and order; 9 keeps the IRP loads) */
+    if (variant & ~(1 | 2 | 16 | 32 | 64 | 512 | SPMV_VARIANT_TIMING_BITS))
+        return -EINVAL;
+    const int passes = 8;
+#endif
     /* workgroup order of the sub-wave kernel: variant bit 0 hardware, bit 1
      * XCD-contiguous ranges, bit 5 grouped runs; none: the handle's
      * (0 / 1 / 2, spmv_csr_autotune) */

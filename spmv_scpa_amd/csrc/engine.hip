@@ -144,6 +144,16 @@ extern "C" {
  * field), spmv_*_release_checked, handle checks on every entry point */
 const char *spmv_version(void) { return "spmv_scpa_amd 0.4 gfx950"; }
 
+/* "product", or "ablations" for a -DSPMV_ABLATIONS build (make abl): only
+ * that flavour understands the experiment bits of spmv_launch_opts.variant */
+const char *spmv_build_flavour(void) {
+#ifdef SPMV_ABLATIONS
+    return "ablations";
+#else
+    return "product";
+#endif
+}
+
 int spmv_live_handles(void) {
     std::lock_guard<std::mutex> g(live().mu);
     return (int)live().handles.size();

@@ -55,6 +55,9 @@ static inline int hip_errno(hipError_t e) {
             return hip_errno(e_);                                             \
     } while (0)
 
+/* variant bits the launchers ignore (they belong to the timed loops) */
+#define SPMV_VARIANT_TIMING_BITS (1 << 29)
+
 /* nnz budget of one workgroup of the CSR stream kernel */
 #define STREAM_NNZ 2048
 #define STREAM_THREADS 256

@@ -355,6 +355,14 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         return -EINVAL;
     if ((kernel == 0 || kernel == 3) == (H->col_major != 0))
         return -EINVAL; /* layout of the handle does not fit the kernel */
+#ifndef SPMV_ABLATIONS
+    /* product build: only the documented bits (spmv_engine.h: 0, 1, 2 the
+     * workgroup orders; 29 belongs to the timed loops).  The ablation arms
+     * (bits 4-6: pipeline depths, an arm whose result is wrong by design) are
+     * compiled only with -DSPMV_ABLATIONS (make abl) */
+    if (variant & ~(1 | 2 | 4 | SPMV_VARIANT_TIMING_BITS))
+        return -EINVAL;
+#endif
     if (b0 == b1)
         return 0;
     /* workgroup order: variant bit 0 hardware, bit 1 XCD ranges, bit 2
@@ -417,6 +425,7 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         /* REMAP grid: 8 x (workgroups of the longest XCD range) */
         const unsigned xgrid =
             NUM_XCD * (unsigned)(((long long)xmax * HACK + threads - 1) / threads);
+#ifdef SPMV_ABLATIONS /* experiment arms: `make abl` builds them */
         if (variant & 32) { /* tuning: 4 columns per pipeline stage */
             hipLaunchKernelGGL((k_hll_col_direct<4, 1>), dim3(xgrid),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
@@ -429,12 +438,13 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
                                H->ja, H->as, x, y);
             break;
         }
-        if (variant & 16) {
+        if (variant & 16) { /* ABL 1: every gather reads x[0..1]: WRONG y */
             hipLaunchKernelGGL((k_hll_col_direct<8, 1, 1>), dim3(xgrid),
                                dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
+#endif
         const unsigned hwgrid = (unsigned)((lanes + threads - 1) / threads);
         if (order == 1)
             hipLaunchKernelGGL((k_hll_col_direct<8, 1>), dim3(xgrid),

@@ -1370,6 +1370,16 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         return -EINVAL;
     if (M == 0)
         return 0;
+#ifndef SPMV_ABLATIONS
+    /* product build: bit 0 flips chain <-> steps, bits 1 / 2 force a tile
+     * order (spmv_engine.h).  Everything else this function understands --
+     * lag override (4-6), no phase wait (7), the ABL arms whose result is
+     * WRONG by design (8-10), group counts (11), staggered panels (12),
+     * group sizes (14-15) -- exists only in a -DSPMV_ABLATIONS build
+     * (`make abl`; tools/sweep.py, tools/pmc.sh load that flavour) */
+    if (variant & ~(1 | 2 | 4 | SPMV_VARIANT_TIMING_BITS))
+        return -EINVAL;
+#endif
     (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     size_t lds = (size_t)P->tile_rows * sizeof(double);
     if (waves <= 0)
@@ -1399,14 +1409,19 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                            P->bptr, P->blen, P->ent, P->val, x, y,             \
                            P->phase_cnt);                                      \
     } while (0)
-        const int abl = (variant >> 8) & 7;
         const int two = !((variant >> 11) & 1); /* 2 groups of 4 per lane */
+#ifdef SPMV_ABLATIONS /* timing ablations (results WRONG by design for 2, 3,
+                         7): compiled only by `make abl` */
+        const int abl = (variant >> 8) & 7;
         if (abl == 1) { SW(256, 1, 1); }
         else if (abl == 2) { SW(256, 1, 2); }
         else if (abl == 3) { SW(256, 1, 3); }
         else if (abl == 4) { SW(256, 1, 4); }
         else if (abl == 7) { SW(256, 1, 7); }
-        else if (P->wgs_per_cu == 1) {
+        else
+#endif
+        if (P->wgs_per_cu == 1) {
+            /* 512 lanes x 2 groups measured best        else if (P->wgs_per_cu == 1) {
             /* 512 lanes x 2 groups measured best with the 160 KiB tile
              * (1.53 ms on config 3; 1024 x 1: 1.60); bit 11 flips the groups */
             if (waves > 8) { if (variant & 2048) SW(1024, 2, 0); else SW(1024, 1, 0); }

@@ -437,16 +437,22 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
     assert info["entries"] == int(IRP[-1]) and dA.panels_schedule() == sched
     assert ((info["steps"] == 1) if sched != "steps"
             else (info["steps"] <= info["panels"]))
-    # sweep tuning bits (panels.hip): 16 = workgroups at most one panel
-    # apart, 128 = no phase wait at all, 2048 = one group of 4 per lane;
-    # steps layout: bit 0 flips between step launches and the chain launch
-    for variant, waves in (((0, 8), (0, 4), (16, 8), (128, 4), (2048, 8))
-                           if sweep else
-                           # bit 1: tiles in hardware order, bit 2: XCD ranges
-                           # bits 14-15: group size of the grouped order
-                           ((0, 8), (0, 4), (1, 0), (1, 16), (2048, 8), (2, 8),
-                            (4, 0), (3, 4), (16384, 8), (32768 + 1, 4),
-                            (49152, 0))):
+    # public bits: steps layout bit 0 flips between step launches and the
+    # chain launch, bit 1 tiles in hardware order, bit 2 XCD ranges.  The
+    # experiment bits (sweep: 16 = workgroups at most one panel apart, 128 =
+    # no phase wait at all, 2048 = the other group count; 14-15: group size of
+    # the grouped order) exist only in the ablations flavour (`make abl`)
+    abl = S.build_flavour() == "ablations"
+    cases = ([(0, 8), (0, 4)] + ([(16, 8), (128, 4), (2048, 8)] if abl else [])
+             if sweep else
+             [(0, 8), (0, 4), (1, 0), (1, 16), (2, 8), (4, 0), (3, 4)]
+             + ([(2048, 8), (16384, 8), (32768 + 1, 4), (49152, 0)]
+                if abl else []))
+    if not abl:  # the product library refuses what it does not document
+        for bad in (16, 128, 256, 512, 2048, 4096, 16384):
+            with pytest.raises(OSError):
+                dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=bad)
+    for variant, waves in cases:
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         for _ in range(2):  # repeated launches must not accumulate
             dA.launch(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, variant=variant,
