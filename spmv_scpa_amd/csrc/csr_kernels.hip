@@ -251,9 +251,12 @@ __device__ __forceinline__ void stream_rows(int tid, int rows, const int *rowptr
                                             const int *s_ja, const double *s_val,
                                             const double *__restrict__ x,
                                             double *__restrict__ y_range) {
-    const int r = tid / T, sub = tid % T;
+    const int sub = tid % T;
+    /* STREAM_THREADS / T lane teams; a range of more rows than that (short
+     * rows: up to STREAM_ROWS of them, T = 1) gives every team several rows */
+    for (int r = tid / T; r < rows; r += STREAM_THREADS / T) {
     double acc = 0.0;
-    if (r < rows) {
+    {
         const int rz = rowptr[r + 1];
         int k = rowptr[r] + sub;
         for (; k + 3 * T < rz; k += 4 * T) {
@@ -271,9 +274,10 @@ __device__ __forceinline__ void stream_rows(int tid, int rows, const int *rowptr
         for (; k < rz; k += T)
             acc += s_val[TSKEW(k)] * x[s_ja[TSKEW(k)]];
     }
-    acc = group_sum<T>(acc); /* teams are aligned: idle lanes add 0 */
-    if (r < rows && sub == 0)
+    acc = group_sum<T>(acc); /* a team's lanes run the same trip count */
+    if (sub == 0)
         y_range[r] = acc;
+    }
 }
 
 typedef int s_v4i __attribute__((ext_vector_type(4)));
@@ -291,11 +295,11 @@ __global__ void __launch_bounds__(STREAM_THREADS)
                  const unsigned char *__restrict__ mode,
                  const int *__restrict__ irp, const int *__restrict__ ja,
                  const double *__restrict__ as, const double *__restrict__ x,
-                 double *__restrict__ y) {
+                 double *__restrict__ y, double *seg_partial, int *seg_count) {
     __shared__ double s_val[STREAM_LDS]; /* AS (transposed) or products */
     __shared__ int s_ja[STREAM_LDS];
     __shared__ double part[STREAM_THREADS / WAVE];
-    __shared__ int rowptr[STREAM_THREADS + 1]; /* this range's slice of IRP */
+    __shared__ int rowptr[STREAM_ROWS + 1]; /* this range's slice of IRP */
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     /* Which range a workgroup runs (workgroups are dealt to the XCDs
@@ -315,8 +319,12 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     const int cnt = end - beg;
     const int rows = row_b - row_a;
 
-    if (cnt > STREAM_NNZ) {
-        /* one long row: every lane strides it, block-wide reduction */
+    const int md = mode[rb];
+    if (md == 2 || cnt > STREAM_NNZ) {
+        /* one long row (up to STREAM_LONG_ROW entries), or one SEGMENT of a
+         * longer one (mode 2: entries [beg, end) of row row_a, cut at
+         * multiples of STREAM_SEG): every lane strides the entries,
+         * block-wide reduction */
         double acc = 0.0;
         for (int k = beg + tid; k < end; k += STREAM_THREADS)
             acc += ld_stream(as + k) * x[ld_stream(ja + k)];
@@ -328,20 +336,47 @@ __global__ void __launch_bounds__(STREAM_THREADS)
             double t = 0.0;
             for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
                 t += part[w];
-            y[row_a] = t;
+            if (md != 2) {
+                y[row_a] = t;
+            } else {
+                /* The row's segments are consecutive ranges rb0 .. rb0 +
+                 * nseg - 1.  Each leaves its partial sum, the LAST to arrive
+                 * (counter at the row's first range) adds them up in segment
+                 * order -- the same order whatever the arrival order, so the
+                 * result is deterministic -- writes y and re-arms the counter
+                 * for the next launch.  Agent-scope atomics: the segments
+                 * run on different XCDs, whose L2s are not coherent for plain
+                 * loads and stores. */
+                const int b0 = irp[row_a];
+                const int nseg = (irp[row_a + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
+                const int rb0 = rb - (beg - b0) / STREAM_SEG;
+                __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                const int seen = __hip_atomic_fetch_add(
+                    seg_count + rb0, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen == nseg - 1) {
+                    double sum = 0.0;
+                    for (int j = 0; j < nseg; ++j)
+                        sum += __hip_atomic_load(seg_partial + rb0 + j,
+                                                 __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    y[row_a] = sum;
+                    __hip_atomic_store(seg_count + rb0, 0, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         return;
     }
 
-    const int md = mode[rb];
     if (WIDE && md == 0 && cnt + (beg & 3) <= STREAM_NNZ) {
         const int d = beg & 3; /* entries between the 16-B boundary and beg */
         const int *ja_al = ja + (beg - d);
         const double *as_al = as + (beg - d);
         s_v4i cj[2];
         s_v2d ca[4];
-        if (tid < rows)
-            rowptr[tid] = irp[row_a + tid] - beg;
+        for (int r = tid; r < rows; r += STREAM_THREADS)
+            rowptr[r] = irp[row_a + r] - beg;
         if (tid == 0)
             rowptr[rows] = cnt;
 #pragma unroll
@@ -381,8 +416,8 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     constexpr int E = STREAM_NNZ / STREAM_THREADS;
     int c[E];
     double a[E];
-    if (tid < rows) /* at most STREAM_THREADS rows per range */
-        rowptr[tid] = irp[row_a + tid] - beg;
+    for (int r = tid; r < rows; r += STREAM_THREADS) /* <= STREAM_ROWS rows */
+        rowptr[r] = irp[row_a + r] - beg;
     if (tid == 0)
         rowptr[rows] = cnt;
 #pragma unroll
@@ -634,12 +669,14 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                 hipLaunchKernelGGL(k_csr_stream<false>, dim3(grid),
                                    dim3(STREAM_THREADS), 0, s, A->n_rowblk, grp,
                                    (const int2 *)A->rowblk, A->rowblk_mode,
-                                   A->irp, A->ja, A->as, x, y);
+                                   A->irp, A->ja, A->as, x, y, A->seg_partial,
+                                   A->seg_count);
             else
                 hipLaunchKernelGGL(k_csr_stream<true>, dim3(grid),
                                    dim3(STREAM_THREADS), 0, s, A->n_rowblk, grp,
                                    (const int2 *)A->rowblk, A->rowblk_mode,
-                                   A->irp, A->ja, A->as, x, y);
+                                   A->irp, A->ja, A->as, x, y, A->seg_partial,
+                                   A->seg_count);
         }
         break;
     }

@@ -385,46 +385,69 @@ __global__ void k_flush_ro(const double *buf, size_t n, double *sink) {
 /* row-block table of the CSR stream kernel (host, O(M))                */
 /* ------------------------------------------------------------------ */
 static void build_rowblk(const int *irp, int M, int nnz_budget, int row_budget,
-                         std::vector<int> &tab,
-                         std::vector<unsigned char> &mode, int *max_len) {
+                         std::vector<int> &tab, std::vector<int> &ent,
+                         std::vector<unsigned char> &mode, int *max_len,
+                         bool *has_segments) {
+    /* tab[k] / ent[k]: first row / first entry of range k; the closing pair
+     * (M, NZ) ends the table.  A row of more than STREAM_LONG_ROW entries
+     * becomes ceil(len / STREAM_SEG) consecutive ranges of mode 2 that all
+     * name the same row and cut its entries at multiples of STREAM_SEG. */
     tab.clear();
+    ent.clear();
     mode.clear();
-    tab.push_back(0);
+    *has_segments = false;
     int start = 0, longest = 0, range_longest = 0;
+    auto close_range = [&](int r) { /* rows [start, r) */
+        tab.push_back(start);
+        ent.push_back(irp[start]);
+        mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
+        start = r;
+        range_longest = 0;
+    };
     for (int r = 0; r < M; ++r) {
-        int len = irp[r + 1] - irp[r];
+        const int len = irp[r + 1] - irp[r];
         longest = std::max(longest, len);
-        int have = irp[r] - irp[start];
-        bool full = (have + len > nnz_budget) || (r - start >= row_budget);
-        if (full && r > start) {
-            tab.push_back(r); /* close [start, r) */
-            mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
-            start = r;
+        if (len > STREAM_LONG_ROW) {
+            if (r > start)
+                close_range(r);
+            for (int b = irp[r]; b < irp[r + 1]; b += STREAM_SEG) {
+                tab.push_back(r);
+                ent.push_back(b);
+                mode.push_back(2);
+            }
+            *has_segments = true;
+            start = r + 1;
             range_longest = 0;
+            continue;
         }
+        const int have = irp[r] - irp[start];
+        const bool full = (have + len > nnz_budget) || (r - start >= row_budget);
+        if (full && r > start)
+            close_range(r);
         range_longest = std::max(range_longest, len);
     }
-    if (M > start) {
-        tab.push_back(M);
-        mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
-    }
+    if (M > start)
+        close_range(M);
+    tab.push_back(M);
+    ent.push_back(irp[M]);
     mode.push_back(0);
     *max_len = longest;
 }
 
 static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     int rc = 0;
-    std::vector<int> tab;
+    std::vector<int> tab, ent;
     std::vector<unsigned char> mode;
     std::vector<int> tmp;
+    bool segs = false;
     if (!host_irp) {
         tmp.resize((size_t)d->M + 1);
         HIP_TRY(hipMemcpy(tmp.data(), d->irp, ((size_t)d->M + 1) * sizeof(int),
                           hipMemcpyDeviceToHost));
         host_irp = tmp.data();
     }
-    build_rowblk(host_irp, d->M, STREAM_NNZ, STREAM_THREADS, tab, mode,
-                 &d->max_row_len);
+    build_rowblk(host_irp, d->M, STREAM_NNZ, STREAM_ROWS, tab, ent, mode,
+                 &d->max_row_len, &segs);
     {
         /* constant row length?  (O(M) over the host copy of IRP) */
         /* (IRP[r] = r * len is what the kernel then computes: only for an
@@ -442,7 +465,7 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
         std::vector<int> tab2(tab.size() * 2);
         for (size_t k = 0; k < tab.size(); ++k) {
             tab2[2 * k] = tab[k];
-            tab2[2 * k + 1] = host_irp[tab[k]];
+            tab2[2 * k + 1] = ent[k];
         }
         HIP_TRY(hipMalloc((void **)&d->rowblk, tab2.size() * sizeof(int)));
         HIP_TRY(hipMemcpy(d->rowblk, tab2.data(), tab2.size() * sizeof(int),
@@ -451,6 +474,13 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
     HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
                       hipMemcpyHostToDevice));
+    if (segs) { /* partial sums + arrival counters of the long rows' ranges */
+        const size_t n = (size_t)d->n_rowblk + 1;
+        HIP_TRY(hipMalloc((void **)&d->seg_partial, n * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&d->seg_count, n * sizeof(int)));
+        HIP_TRY(hipMemset(d->seg_partial, 0, n * sizeof(double)));
+        HIP_TRY(hipMemset(d->seg_count, 0, n * sizeof(int)));
+    }
 fail:
     return rc;
 }
@@ -476,6 +506,8 @@ static void csr_teardown(spmv_csr_dev *d) {
     (void)hipFree(d->as);
     (void)hipFree(d->rowblk);
     (void)hipFree(d->rowblk_mode);
+    (void)hipFree(d->seg_partial);
+    (void)hipFree(d->seg_count);
     panels_free(d->panels);
     free(d->tune_log);
     free(d);
@@ -1266,6 +1298,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
     if (allow_panels) {
         const double stream_ms =
             (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
+        panels_pool_begin(); /* candidates reuse each other's blocks */
         rc = tune_blocked<spmv_panels, panels_ops>(
             &H->panels, H->M, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
@@ -1282,6 +1315,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
                 return r;
             },
             [&](const char *l) { log(l); }); /* by reference */
+        panels_pool_end();
         if (rc < 0)
             return rc;
         if (rc > 0) {
@@ -1404,6 +1438,7 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
     log(line);
     if (allow_panels) {
         const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
+        panels_pool_begin(); /* candidates reuse each other's blocks */
         rc = tune_blocked<spmv_panels, panels_ops>(
             &A->panels, A->M, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
@@ -1420,6 +1455,7 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
                 return r;
             },
             [&](const char *l) { log(l); }); /* by reference */
+        panels_pool_end();
         if (rc < 0)
             return rc;
         if (rc > 0) {

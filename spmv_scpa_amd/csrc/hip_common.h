@@ -61,8 +61,16 @@ static inline int hip_errno(hipError_t e) {
 /* nnz budget of one workgroup of the CSR stream kernel */
 #define STREAM_NNZ 2048
 #define STREAM_THREADS 256
+/* rows a range may hold: matrices with 2-5 entries per row (web / road /
+ * co-purchase graphs) fill the entry budget only with several rows per lane */
+#define STREAM_ROWS 1024
 /* ranges whose longest row is at most this use the transposed form */
 #define STREAM_ROW_T 48
+/* a row beyond STREAM_LONG_ROW entries is cut into segments of
+ * STREAM_SEG entries, one workgroup each (one lane team walking a row of
+ * 10^5 entries is the whole launch otherwise: dc1-class matrices) */
+#define STREAM_LONG_ROW 8192
+#define STREAM_SEG 4096
 
 struct spmv_panels; /* panels.hip */
 
@@ -87,7 +95,11 @@ struct spmv_csr_dev {
      * entries [rowblk[2k+1], rowblk[2k+3]) */
     int *rowblk;
     int n_rowblk;
-    unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative */
+    unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative,
+                                   2 segment of a long row */
+    double *seg_partial; /* [n_rowblk] partial sum of a segment's range */
+    int *seg_count;      /* [n_rowblk] arrivals, at a long row's first range;
+                            both NULL when no row is that long */
     int max_row_len;
     int uniform_len; /* > 0: EVERY row holds exactly this many entries (banded
                         and fixed-degree matrices: IRP[r] = r * uniform_len),
@@ -178,6 +190,8 @@ int panels_tiles(const spmv_panels *P);
 int panels_balanced_tile_rows(int M, int max_rows);
 int panels_describe(const spmv_panels *P, char *buf, size_t len);
 const char *panels_last_build_phases(void);
+void panels_pool_begin(void); /* block reuse across the builds of one */
+void panels_pool_end(void);   /* selector run (panels.hip, build_pool)  */
 
 extern int g_csr_waves; /* process defaults behind set_*_waves_per_block */
 extern int g_hll_waves;

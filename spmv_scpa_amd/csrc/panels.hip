@@ -117,11 +117,13 @@ struct spmv_panels {
     size_t phase_cnt_bytes;
 };
 
+static void big_free(void *p); /* block pool of a selector run, below */
+
 void panels_free(spmv_panels *p) {
     if (!p)
         return;
-    (void)hipFree(p->ent);
-    (void)hipFree(p->val);
+    big_free(p->ent);
+    big_free(p->val);
     (void)hipFree(p->cpanel);
     (void)hipFree(p->phase_cnt);
     (void)hipFree(p->bptr);
@@ -512,6 +514,83 @@ static int bits_for(long long n) { /* smallest b with 2^b >= n */
     return b;
 }
 
+/*
+ * Block pool of one selector run.  spmv_*_autotune builds four or five
+ * candidates of ONE matrix; each build needs ~11 GB of sort temporaries and
+ * 3.8 GB for the copy at config-3 size, and the losers are freed again.  With
+ * plain hipMalloc / hipFree every build returns its memory to the driver and
+ * takes fresh memory back -- usually in milliseconds, but one allocation in
+ * ten or so took 1.3-1.6 s (round 3's unexplained 4.2-4.6 s selector runs;
+ * round 4's phase log pins it on the allocations: "alloc+keys 1.536 s" /
+ * "gather 1.329 s" = the hipMalloc of the copy, `profiles/r04_selector_phases.txt`).
+ * Inside panels_pool_begin() .. panels_pool_end() the big blocks of builds and
+ * of freed candidates are parked and handed to the next build instead (a
+ * block is reused for a request of 89-100 % of its size); outside a selector
+ * run nothing is pooled.
+ */
+struct build_pool {
+    struct blk {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<blk> parked; /* free, reusable */
+    std::vector<blk> out;    /* handed out (size remembered for parking) */
+};
+static thread_local build_pool *g_pool = NULL;
+
+void panels_pool_begin(void) {
+    if (!g_pool)
+        g_pool = new build_pool();
+}
+
+void panels_pool_end(void) {
+    if (!g_pool)
+        return;
+    for (size_t i = 0; i < g_pool->parked.size(); ++i)
+        (void)hipFree(g_pool->parked[i].p);
+    delete g_pool; /* blocks still out belong to the kept copy: plain memory */
+    g_pool = NULL;
+}
+
+static hipError_t big_malloc(void **p, size_t bytes) {
+    if (g_pool) {
+        for (size_t i = 0; i < g_pool->parked.size(); ++i) {
+            const size_t have = g_pool->parked[i].bytes;
+            if (have >= bytes && have - bytes <= have / 9) {
+                *p = g_pool->parked[i].p;
+                g_pool->out.push_back(g_pool->parked[i]);
+                g_pool->parked.erase(g_pool->parked.begin() + (long)i);
+                return hipSuccess;
+            }
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && g_pool && !g_pool->parked.empty()) {
+        /* out of memory with blocks parked: give them back and retry */
+        for (size_t i = 0; i < g_pool->parked.size(); ++i)
+            (void)hipFree(g_pool->parked[i].p);
+        g_pool->parked.clear();
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && g_pool)
+        g_pool->out.push_back({*p, bytes});
+    return e;
+}
+
+static void big_free(void *p) {
+    if (!p)
+        return;
+    if (g_pool)
+        for (size_t i = 0; i < g_pool->out.size(); ++i)
+            if (g_pool->out[i].p == p) {
+                g_pool->parked.push_back(g_pool->out[i]);
+                g_pool->out.erase(g_pool->out.begin() + (long)i);
+                return;
+            }
+    (void)hipFree(p);
+}
+
 /* host-clock seconds of the last panels_build on this thread, by phase
  * (allocations + keys, radix sort, bucket tables, gather into the copy):
  * what spmv_*_autotune appends to its log */
@@ -646,8 +725,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     g_build_phases[0] = 0;
 
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMalloc((void **)&key[k], n * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void **)&idx[k], n * sizeof(unsigned)));
+        HIP_TRY(big_malloc((void **)&key[k], n * sizeof(uint64_t)));
+        HIP_TRY(big_malloc((void **)&idx[k], n * sizeof(unsigned)));
     }
     skey = key[0];
     sidx = idx[0];
@@ -675,7 +754,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                 ++end_bit;
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
                 NULL, tmp_bytes, dk, dv, (int)slots, 0, end_bit, 0));
-            HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+            HIP_TRY(big_malloc(&tmp, tmp_bytes ? tmp_bytes : 16));
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
                 tmp, tmp_bytes, dk, dv, (int)slots, 0, end_bit, 0));
             HIP_TRY(hipDeviceSynchronize());
@@ -764,8 +843,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     tp[3] = build_now_s();
     {
         const size_t m = (size_t)total + SWEEP_TAIL; /* zeros behind the data */
-        HIP_TRY(hipMalloc((void **)&P->ent, m * sizeof(unsigned)));
-        HIP_TRY(hipMalloc((void **)&P->val, m * sizeof(double)));
+        HIP_TRY(big_malloc((void **)&P->ent, m * sizeof(unsigned)));
+        HIP_TRY(big_malloc((void **)&P->val, m * sizeof(double)));
         HIP_TRY(hipMemset(P->ent, 0, m * sizeof(unsigned)));
         HIP_TRY(hipMemset(P->val, 0, m * sizeof(double)));
     }
@@ -804,10 +883,10 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P = NULL;
 fail:
     for (int k = 0; k < 2; ++k) {
-        (void)hipFree(key[k]);
-        (void)hipFree(idx[k]);
+        big_free(key[k]);
+        big_free(idx[k]);
     }
-    (void)hipFree(tmp);
+    big_free(tmp);
     (void)hipFree(raw);
     (void)hipFree(padded);
     (void)hipFree(span);
@@ -1421,7 +1500,6 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
         else
 #endif
         if (P->wgs_per_cu == 1) {
-            /* 512 lanes x 2 groups measured best        else if (P->wgs_per_cu == 1) {
             /* 512 lanes x 2 groups measured best with the 160 KiB tile
              * (1.53 ms on config 3; 1024 x 1: 1.60); bit 11 flips the groups */
             if (waves > 8) { if (variant & 2048) SW(1024, 2, 0); else SW(1024, 1, 0); }
