@@ -1266,6 +1266,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
     int rc = scratch.reserve(flush);
     if (rc)
         return rc;
+    int iters = 5;
     for (int k = 0; k < 2; ++k)
         for (int order = 0; order < 3; ++order) { /* the workgroup orders */
             if (!H->col_major && order > 0)
@@ -1273,12 +1274,17 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
             spmv_launch_opts o;
             memset(&o, 0, sizeof o);
             o.variant = 1 << order; /* bit 0 hardware, 1 ranges, 2 grouped */
+            /* 5 launches each -- 1 once a launch has run beyond 10 ms (a hack
+             * block as wide as a hub row of 10^5 entries: 40-60 ms per
+             * launch, 1.8 s for the six combinations otherwise) */
             rc = timed_loop(
                 [&]() { return spmv_hll_launch(H, cand[k], &o, d_x, d_y, NULL); },
-                1, 5, flush, ms.data(), NULL, false, &scratch);
+                1, iters, flush, ms.data(), NULL, false, &scratch);
             if (rc)
                 return rc;
-            double m = median_of(ms);
+            double m = median_of(std::vector<double>(ms.begin(), ms.begin() + iters));
+            if (m > 10.0)
+                iters = 1;
             if (H->tune_ms[cand[k]] == 0.0 || m < H->tune_ms[cand[k]])
                 H->tune_ms[cand[k]] = m;
             /* another order has to win by 2 % over hardware order */
@@ -1300,7 +1306,8 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
             (double)spmv_hll_algorithmic_bytes(H) / 7.0e9; /* at 7 TB/s */
         panels_pool_begin(); /* candidates reuse each other's blocks */
         rc = tune_blocked<spmv_panels, panels_ops>(
-            &H->panels, H->M, stream_ms, &bms,
+            &H->panels, H->M, H->M > 0 ? (double)H->NZ / H->M : 0.0, stream_ms,
+            &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
                 return panels_from_hll(H, 0, sched, tile_rows, out);
             },
@@ -1440,7 +1447,7 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
         const double stream_ms = (double)spmv_csr_algorithmic_bytes(A) / 7.0e9;
         panels_pool_begin(); /* candidates reuse each other's blocks */
         rc = tune_blocked<spmv_panels, panels_ops>(
-            &A->panels, A->M, stream_ms, &bms,
+            &A->panels, A->M, mean, stream_ms, &bms,
             [&](int sched, int tile_rows, spmv_panels **out) {
                 return panels_from_csr(A, 0, sched, tile_rows, out);
             },

@@ -51,7 +51,9 @@
  * are reproducible to rounding (tests hold them to 1e-12 of the row scale),
  * not bitwise.
  */
+#include <algorithm>
 #include <atomic>
+#include <utility>
 #include <hipcub/hipcub.hpp>
 #include <stdio.h>
 #include <string.h>
@@ -115,7 +117,31 @@ struct spmv_panels {
                         0 grouped, 1 hardware order, 2 XCD-contiguous ranges */
     int *phase_cnt;  /* DEVICE sweep: [NUM_XCD][rounds*panels] arrival counters */
     size_t phase_cnt_bytes;
+    /* LONG ROWS BESIDE THE COPY (round 4).  A row of more than PANELS_LONG_ROW
+     * entries is left out of the buckets: its products would all land on ONE
+     * accumulator of its tile, and ds_add_f64 from 64 lanes to one address
+     * runs one lane at a time (a hub row of 131072 entries made its tile the
+     * whole launch: 0.18 ms for a matrix that streams in 0.02).  Such rows
+     * are kept as a small CSR of their own, cut into segments of
+     * PANELS_LONG_SEG entries, and a second launch on the same stream sums
+     * each segment with a workgroup (k_long_rows; deterministic last-arriver
+     * reduction, as the CSR stream kernel's mode 2) and overwrites y[row] --
+     * the tile kernels wrote 0 there. */
+    int nlong;        /* rows kept beside the copy */
+    int nlong_seg;    /* their segments = workgroups of the second launch */
+    int64_t long_nnz; /* their entries */
+    int *long_row;    /* DEVICE [nlong] row index, ascending */
+    int *long_ptr;    /* DEVICE [nlong+1] first entry of each in long_ja/as */
+    int *long_ja;     /* DEVICE [long_nnz] */
+    double *long_as;  /* DEVICE [long_nnz] */
+    int2 *long_seg;   /* DEVICE [nlong_seg] (index into long_row, first entry) */
+    int *long_seg0;   /* DEVICE [nlong] first segment of each row */
+    double *long_part; /* DEVICE [nlong_seg] partial sums */
+    int *long_cnt;    /* DEVICE [nlong] arrivals */
 };
+#define PANELS_LONG_ROW 8192
+#define PANELS_LONG_SEG 4096
+#define PANELS_LONG_MAX 4096 /* more such rows than this: keep them inside */
 
 static void big_free(void *p); /* block pool of a selector run, below */
 
@@ -130,6 +156,14 @@ void panels_free(spmv_panels *p) {
     (void)hipFree(p->blen);
     (void)hipFree(p->cb);
     (void)hipFree(p->nbk);
+    (void)hipFree(p->long_row);
+    (void)hipFree(p->long_ptr);
+    (void)hipFree(p->long_ja);
+    (void)hipFree(p->long_as);
+    (void)hipFree(p->long_seg);
+    (void)hipFree(p->long_seg0);
+    (void)hipFree(p->long_part);
+    (void)hipFree(p->long_cnt);
     free(p);
 }
 
@@ -149,8 +183,23 @@ __host__ __device__ __forceinline__ uint64_t bucket_id(uint64_t tile,
                    : tile * panels + panel;
 }
 
+/* is `row` one of the ascending `rows[0..n)`?  (the long rows: a handful) */
+__device__ __forceinline__ bool in_sorted(const int *__restrict__ rows, int n,
+                                          int row) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (rows[mid] < row)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < n && rows[lo] == row;
+}
+
 __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
-                                int pm_grid,
+                                int pm_grid, uint64_t nbuckets,
+                                const int *__restrict__ long_row, int nlong,
                                 const int *__restrict__ irp,
                                 const int *__restrict__ ja, uint64_t *key,
                                 unsigned *idx) {
@@ -161,16 +210,21 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
         return;
     const uint64_t tile = (uint64_t)(row / tile_rows);
     const unsigned low = (1u << shift) - 1u;
+    /* a long row's entries live beside the copy: dropped from the buckets */
+    const bool out = nlong > 0 && in_sorted(long_row, nlong, (int)row);
+    const uint64_t dropped = nbuckets << shift;
     for (int k = irp[row] + sub, e = irp[row + 1]; k < e; k += 8) {
         const unsigned c = (unsigned)ja[k];
-        key[k] = (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
-                 (c & low);
+        key[k] = out ? dropped
+                     : (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
+                           (c & low);
         idx[k] = (unsigned)k;
     }
 }
 
 __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
                                 int pm_grid, uint64_t nbuckets,
+                                const int *__restrict__ long_row, int nlong,
                                 int col_major, const int64_t *__restrict__ off,
                                 const int *__restrict__ ja,
                                 const unsigned *__restrict__ padmask,
@@ -185,13 +239,15 @@ __global__ void k_keys_from_hll(int M, int tile_rows, int panels, int shift,
     const uint64_t tile = (uint64_t)(row / tile_rows);
     const uint64_t dropped = nbuckets << shift;
     const unsigned low = (1u << shift) - 1u;
+    const bool out = nlong > 0 && in_sorted(long_row, nlong, row);
     for (int j = 0; j < w; ++j) {
         int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
         /* only PAD slots are dropped (bitmap written when the pads were
          * rewritten, hll_kernels.hip); an explicit zero is an entry like any
-         * other, exactly as from a CSR source */
+         * other, exactly as from a CSR source -- and the slots of a long row,
+         * which is kept beside the copy */
         const unsigned c = (unsigned)ja[t];
-        const bool pad = (padmask[t >> 5] >> (t & 31)) & 1u;
+        const bool pad = out || ((padmask[t >> 5] >> (t & 31)) & 1u);
         key[t] = !pad ? (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
                             (c & low)
                       : dropped;
@@ -514,6 +570,234 @@ static int bits_for(long long n) { /* smallest b with 2^b >= n */
     return b;
 }
 
+/* ------------------------------------------------------------------ */
+/* long rows beside the copy (struct spmv_panels, "LONG ROWS")           */
+/* ------------------------------------------------------------------ */
+/* rows of more than `limit` entries -> list[1 + 2k] = row, [2 + 2k] = length;
+ * list[0] counts them (may exceed `cap`: the host then gives up) */
+__global__ void k_long_rows_csr(int M, int limit, int cap,
+                                const int *__restrict__ irp, int *list) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M)
+        return;
+    const int len = irp[row + 1] - irp[row];
+    if (len > limit) {
+        const int k = atomicAdd(list, 1);
+        if (k < cap) {
+            list[1 + 2 * k] = row;
+            list[2 + 2 * k] = len;
+        }
+    }
+}
+
+/* HLL: only a hack block wider than `limit` can hold such a row; its real
+ * length is the number of non-pad slots */
+__global__ void k_long_rows_hll(int M, int limit, int cap, int col_major,
+                                const int64_t *__restrict__ off,
+                                const unsigned *__restrict__ padmask, int *list) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M)
+        return;
+    const int b = row >> 5, i = row & 31;
+    const int rows = min(32, M - b * 32);
+    const int64_t o = off[b];
+    const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    if (w <= limit)
+        return;
+    int len = 0;
+    for (int j = 0; j < w; ++j) {
+        const int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
+        len += !((padmask[t >> 5] >> (t & 31)) & 1u);
+    }
+    if (len > limit) {
+        const int k = atomicAdd(list, 1);
+        if (k < cap) {
+            list[1 + 2 * k] = row;
+            list[2 + 2 * k] = len;
+        }
+    }
+}
+
+/* one workgroup per long row copies its entries, in row order */
+__global__ void k_long_copy_csr(const int *__restrict__ long_row,
+                                const int *__restrict__ long_ptr,
+                                const int *__restrict__ irp,
+                                const int *__restrict__ ja,
+                                const double *__restrict__ as, int *lja,
+                                double *las) {
+    const int h = blockIdx.x, row = long_row[h];
+    const int src = irp[row], dst = long_ptr[h], len = long_ptr[h + 1] - dst;
+    for (int k = threadIdx.x; k < len; k += blockDim.x) {
+        lja[dst + k] = ja[src + k];
+        las[dst + k] = as[src + k];
+    }
+}
+
+/* ... HLL: one WAVEFRONT per long row walks its slots 64 at a time and
+ * compacts the non-pad ones (ballot + prefix count), keeping their order */
+__global__ void k_long_copy_hll(int M, int col_major,
+                                const int *__restrict__ long_row,
+                                const int *__restrict__ long_ptr,
+                                const int64_t *__restrict__ off,
+                                const int *__restrict__ ja,
+                                const double *__restrict__ as,
+                                const unsigned *__restrict__ padmask, int *lja,
+                                double *las) {
+    const int h = blockIdx.x, row = long_row[h], lane = threadIdx.x;
+    const int b = row >> 5, i = row & 31;
+    const int rows = min(32, M - b * 32);
+    const int64_t o = off[b];
+    const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    int dst = long_ptr[h];
+    for (int j0 = 0; j0 < w; j0 += WAVE) {
+        const int j = j0 + lane;
+        bool keep = false;
+        int64_t t = 0;
+        if (j < w) {
+            t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
+            keep = !((padmask[t >> 5] >> (t & 31)) & 1u);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int at = dst + __popcll(m & ((1ull << lane) - 1ull));
+            lja[at] = ja[t];
+            las[at] = as[t];
+        }
+        dst += __popcll(m);
+    }
+}
+
+/* the second launch: workgroup g sums segment g (entries [beg, end) of long
+ * row seg[g].x); the last segment of a row to arrive adds the row's partial
+ * sums in segment order and OVERWRITES y[row] (the tile kernels wrote 0) */
+__global__ void __launch_bounds__(256)
+    k_long_rows(const int2 *__restrict__ seg, int nseg,
+                const int *__restrict__ long_row,
+                const int *__restrict__ long_ptr,
+                const int *__restrict__ seg0, const int *__restrict__ lja,
+                const double *__restrict__ las, const double *__restrict__ x,
+                double *__restrict__ y, double *part, int *cnt) {
+    __shared__ double wsum[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int h = seg[g].x, beg = seg[g].y;
+    const int row_end = long_ptr[h + 1];
+    const int end = min(beg + PANELS_LONG_SEG, row_end);
+    double acc = 0.0;
+    for (int k = beg + tid; k < end; k += 256)
+        acc += __builtin_nontemporal_load(las + k) *
+               x[__builtin_nontemporal_load(lja + k)];
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1)
+        acc += __shfl_down(acc, d, WAVE);
+    if ((tid & (WAVE - 1)) == 0)
+        wsum[tid / WAVE] = acc;
+    __syncthreads();
+    if (tid != 0)
+        return;
+    const double t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int g0 = seg0[h];
+    const int n = (row_end - long_ptr[h] + PANELS_LONG_SEG - 1) / PANELS_LONG_SEG;
+    __hip_atomic_store(part + g, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int seen = __hip_atomic_fetch_add(cnt + h, 1, __ATOMIC_ACQ_REL,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == n - 1) {
+        double sum = 0.0;
+        for (int j = 0; j < n; ++j)
+            sum += __hip_atomic_load(part + g0 + j, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+        y[long_row[h]] = sum;
+        __hip_atomic_store(cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+/* find the long rows of the source and copy them beside the (future) copy;
+ * P->nlong stays 0 when there are none (or absurdly many: then they stay in
+ * the buckets).  Called before the keys are made. */
+static int long_rows_extract(spmv_panels *P, int M, int nb,
+                             const int *irp_or_null, const int64_t *off_or_null,
+                             int col_major, const int *ja, const double *as,
+                             const unsigned *padmask) {
+    int rc = 0;
+    int *d_list = NULL;
+    std::vector<int> list((size_t)2 * PANELS_LONG_MAX + 1, 0);
+    std::vector<std::pair<int, int>> rows; /* (row, length) */
+    std::vector<int> h_row, h_ptr, h_seg0;
+    std::vector<int2> h_seg;
+    (void)nb;
+    if (M <= 0)
+        return 0;
+    HIP_TRY(hipMalloc((void **)&d_list, list.size() * sizeof(int)));
+    HIP_TRY(hipMemset(d_list, 0, sizeof(int)));
+    if (irp_or_null)
+        hipLaunchKernelGGL(k_long_rows_csr, dim3((M + 255) / 256), dim3(256), 0,
+                           0, M, PANELS_LONG_ROW, PANELS_LONG_MAX, irp_or_null,
+                           d_list);
+    else
+        hipLaunchKernelGGL(k_long_rows_hll, dim3((M + 255) / 256), dim3(256), 0,
+                           0, M, PANELS_LONG_ROW, PANELS_LONG_MAX, col_major,
+                           off_or_null, padmask, d_list);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(list.data(), d_list, list.size() * sizeof(int),
+                      hipMemcpyDeviceToHost));
+    if (list[0] <= 0 || list[0] > PANELS_LONG_MAX)
+        goto fail; /* none / too many: nothing beside the copy */
+    for (int k = 0; k < list[0]; ++k)
+        rows.push_back({list[1 + 2 * k], list[2 + 2 * k]});
+    std::sort(rows.begin(), rows.end());
+    {
+        int64_t at = 0;
+        for (size_t h = 0; h < rows.size(); ++h) {
+            h_row.push_back(rows[h].first);
+            h_ptr.push_back((int)at);
+            h_seg0.push_back((int)h_seg.size());
+            for (int b = 0; b < rows[h].second; b += PANELS_LONG_SEG)
+                h_seg.push_back(make_int2((int)h, (int)at + b));
+            at += rows[h].second;
+            if (at > (int64_t)INT32_MAX)
+                goto fail; /* keep them inside */
+        }
+        h_ptr.push_back((int)at);
+        P->long_nnz = at;
+    }
+    P->nlong = (int)rows.size();
+    P->nlong_seg = (int)h_seg.size();
+    HIP_TRY(hipMalloc((void **)&P->long_row, h_row.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&P->long_ptr, h_ptr.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&P->long_seg0, h_seg0.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&P->long_seg, h_seg.size() * sizeof(int2)));
+    HIP_TRY(hipMalloc((void **)&P->long_ja, (size_t)P->long_nnz * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&P->long_as, (size_t)P->long_nnz * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&P->long_part, h_seg.size() * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&P->long_cnt, h_row.size() * sizeof(int)));
+    HIP_TRY(hipMemset(P->long_part, 0, h_seg.size() * sizeof(double)));
+    HIP_TRY(hipMemset(P->long_cnt, 0, h_row.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(P->long_row, h_row.data(), h_row.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->long_ptr, h_ptr.data(), h_ptr.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->long_seg0, h_seg0.data(), h_seg0.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->long_seg, h_seg.data(), h_seg.size() * sizeof(int2),
+                      hipMemcpyHostToDevice));
+    if (irp_or_null)
+        hipLaunchKernelGGL(k_long_copy_csr, dim3(P->nlong), dim3(256), 0, 0,
+                           P->long_row, P->long_ptr, irp_or_null, ja, as,
+                           P->long_ja, P->long_as);
+    else
+        hipLaunchKernelGGL(k_long_copy_hll, dim3(P->nlong), dim3(WAVE), 0, 0, M,
+                           col_major, P->long_row, P->long_ptr, off_or_null, ja,
+                           as, padmask, P->long_ja, P->long_as);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+fail:
+    (void)hipFree(d_list);
+    if (rc) {
+        P->nlong = P->nlong_seg = 0;
+        P->long_nnz = 0;
+    }
+    return rc;
+}
+
 /*
  * Block pool of one selector run.  spmv_*_autotune builds four or five
  * candidates of ONE matrix; each build needs ~11 GB of sort temporaries and
@@ -724,6 +1008,10 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     double tp[5] = {build_now_s(), 0, 0, 0, 0};
     g_build_phases[0] = 0;
 
+    rc = long_rows_extract(P, M, nb, irp_or_null, off_or_null, col_major, ja,
+                           as, padmask);
+    if (rc)
+        goto fail;
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(big_malloc((void **)&key[k], n * sizeof(uint64_t)));
         HIP_TRY(big_malloc((void **)&idx[k], n * sizeof(unsigned)));
@@ -735,12 +1023,14 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             hipLaunchKernelGGL(k_keys_from_csr,
                                dim3((unsigned)(((long long)M * 8 + 255) / 256)),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
-                               pm_grid, irp_or_null, ja, key[0], idx[0]);
+                               pm_grid, (uint64_t)nbuckets, P->long_row,
+                               P->nlong, irp_or_null, ja, key[0], idx[0]);
         else
             hipLaunchKernelGGL(k_keys_from_hll, dim3((M + 255) / 256),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
-                               pm_grid, (uint64_t)nbuckets, col_major,
-                               off_or_null, ja, padmask, key[0], idx[0]);
+                               pm_grid, (uint64_t)nbuckets, P->long_row,
+                               P->nlong, col_major, off_or_null, ja, padmask,
+                               key[0], idx[0]);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         tp[1] = build_now_s();
@@ -1443,8 +1733,27 @@ template <auto Kernel> static int allow_big_lds(void) {
     return 0;
 }
 
+static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
+                               int variant, const double *x, double *y,
+                               hipStream_t s);
+
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,
                   const double *x, double *y, hipStream_t s) {
+    const int rc = panels_launch_tiles(P, M, waves, variant, x, y, s);
+    if (rc || !P->nlong)
+        return rc;
+    /* the rows kept beside the copy, on the same stream: the tile kernels
+     * have written 0 for them, this launch overwrites */
+    hipLaunchKernelGGL(k_long_rows, dim3(P->nlong_seg), dim3(256), 0, s,
+                       P->long_seg, P->nlong_seg, P->long_row, P->long_ptr,
+                       P->long_seg0, P->long_ja, P->long_as, x, y, P->long_part,
+                       P->long_cnt);
+    return hip_errno(hipGetLastError());
+}
+
+static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
+                               int variant, const double *x, double *y,
+                               hipStream_t s) {
     if (!P)
         return -EINVAL;
     if (M == 0)
@@ -1691,6 +2000,12 @@ int panels_describe(const spmv_panels *P, char *buf, size_t len) {
                  P->panels, P->shift, P->max_nbk, P->span,
                  P->residue ? "residue" : "ascending", P->order,
                  P->waves_hint);
+    if (P->nlong) {
+        const size_t at = strlen(buf);
+        snprintf(buf + at, len - at,
+                 "; %d long row(s) beside the copy (%lld entries, %d segments)",
+                 P->nlong, (long long)P->long_nnz, P->nlong_seg);
+    }
     return 0;
 }
 
@@ -1711,7 +2026,10 @@ void panels_set_waves(spmv_panels *P, int waves) {
 }
 int panels_tile_rows(const spmv_panels *P) { return P ? P->tile_rows : 0; }
 
-int64_t panels_nnz(const spmv_panels *P) { return P ? P->nnz : 0; }
+/* entries the copy stands for: in the buckets + in the long rows beside it */
+int64_t panels_nnz(const spmv_panels *P) {
+    return P ? P->nnz + P->long_nnz : 0;
+}
 int panels_count(const spmv_panels *P) { return P ? P->panels : 0; }
 int panels_steps(const spmv_panels *P) {
     return P ? (P->sweep || P->chain ? 1 : P->max_nbk) : 0;

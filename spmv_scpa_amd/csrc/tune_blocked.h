@@ -10,7 +10,7 @@
  * tests/test_tune_blocked_asan.py).  engine.hip instantiates it with the real
  * operations of panels.hip.
  *
- * `*bms` is the best direct kernel's time on entry.  Near the stream rate
+ * `*bms` is the best direct kernel's time on entry, nnz_per_row the mean row.  Near the stream rate
  * (within 1.2x of it at 7 TB/s) nothing is built.  Otherwise the steps layout
  * is built at up to four tile heights (8192 rows and the two tall heights
  * balanced over whole rounds of the chip for 10M rows, lower for smaller
@@ -38,8 +38,8 @@
 #include <stdio.h>
 
 template <class P, class Ops, class Build, class Time, class Log>
-static int tune_blocked(P **slot, int M, double stream_ms, double *bms,
-                        Build build, Time time_it, Log log) {
+static int tune_blocked(P **slot, int M, double nnz_per_row, double stream_ms,
+                        double *bms, Build build, Time time_it, Log log) {
     if (*bms <= 1.2 * stream_ms)
         return 0;
     P *const original = *slot; /* caller-built copy, if any */
@@ -140,7 +140,13 @@ static int tune_blocked(P **slot, int M, double stream_ms, double *bms,
      * launch wants a few hundred of them (1M rows: 4096 rows 0.073 ms, 8192
      * rows 0.109; 3M rows: 0.233 vs 0.267; 10M rows: 8192 or 16384) */
     int t1 = 8192, t2 = 16384;
-    if (M < 4900000) {
+    /* ... unless the rows are short (web / road graphs: 2-8 entries): a tile
+     * of 8192 rows then holds only ~25k entries, six wavefront chunks, and its
+     * fixed cost (zeroing and writing the slice of y) dominates -- power-law
+     * 4M x 3, columns anywhere: 0.216 ms at 4096 rows, 0.177 at 8192, 0.155
+     * with the sweep schedule's 15648-row tiles.  Such matrices get the tall
+     * ladder from 1.5M rows up */
+    if (M < 4900000 && !(nnz_per_row < 12.0 && M >= 1500000)) {
         t1 = 4096;
         t2 = 8192;
     }

@@ -86,7 +86,7 @@ static int scenario(uint64_t seed, int verbose) {
     const int fail_time_at = rnd() % 5 == 0 ? (int)(rnd() % 24) : -1;
     int builds = 0, times = 0, lines = 0;
     int rc = tune_blocked<mock_copy, mock_ops>(
-        &slot, M, stream_ms, &bms,
+        &slot, M, (rnd() & 1) ? 3.0 : 32.0, stream_ms, &bms,
         [&](int sched, int tile_rows, mock_copy **out) {
             (void)sched;
             (void)tile_rows;

@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--rows", type=int, default=0,
                     help="replace the 10M-row cases by this many rows")
+    ap.add_argument("--logs", action="store_true",
+                    help="print the selector's phase log for every row")
     ap.add_argument("--irregular", action="store_true",
                     help="the power-law / hub families instead of the default list")
     a = ap.parse_args()
@@ -102,7 +104,7 @@ def main():
                     m.M, m.NZ, m.NZ / max(m.M, 1))
             lines.append(detail)
             print(detail, flush=True)
-            if tune > 1.0:
+            if tune > 1.0 or a.logs:
                 for ln in (m.tune_log() or "").splitlines():
                     lines.append("    log: " + ln)
                     print(lines[-1], flush=True)
