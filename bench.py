@@ -99,7 +99,8 @@ FLUSH_BYTES = 1 << 30
 ROWS_PER_GPU = 10_000_000
 NNZ_PER_ROW = 32
 MATRIX_SEED, X_SEED = 42, 7
-FAMILIES = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3, "stencil": 4}
+FAMILIES = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3, "stencil": 4,
+            "powerlaw": 5, "hub": 6}
 # the reference's thread ladder (src/main.c:176-180) + serial + all cores
 REF_LADDER = (2, 4, 8, 16, 32, 40)
 METRIC = ("fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), "

@@ -333,8 +333,8 @@ static void run_multi_gpu(void) {
 
 static int synth_kind(const char *s) {
     static const char *names[] = {"banded", "random", "ragged", "kkt",
-                                  "stencil"};
-    for (int k = 0; k < 5; ++k)
+                                  "stencil", "powerlaw", "hub"};
+    for (int k = 0; k < 7; ++k)
         if (!strcmp(s, names[k]))
             return k;
     return -1;

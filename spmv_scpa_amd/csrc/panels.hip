@@ -118,7 +118,7 @@ struct spmv_panels {
     int *phase_cnt;  /* DEVICE sweep: [NUM_XCD][rounds*panels] arrival counters */
     size_t phase_cnt_bytes;
     /* LONG ROWS BESIDE THE COPY (round 4).  A row of more than PANELS_LONG_ROW
-     * entries is left out of the buckets: its products would all land on ONE
+     * (16384) entries is left out of the buckets: its products would all land on ONE
      * accumulator of its tile, and ds_add_f64 from 64 lanes to one address
      * runs one lane at a time (a hub row of 131072 entries made its tile the
      * whole launch: 0.18 ms for a matrix that streams in 0.02).  Such rows
@@ -139,7 +139,11 @@ struct spmv_panels {
     double *long_part; /* DEVICE [nlong_seg] partial sums */
     int *long_cnt;    /* DEVICE [nlong] arrivals */
 };
-#define PANELS_LONG_ROW 8192
+/* threshold: the second launch costs ~8 us; a row inside the copy costs its
+ * tile ~1.3 ns per entry of serialised accumulation -- power-law 1M x 3 with
+ * one row of 8291 entries: 0.043 ms inside, 0.052 beside; a row of 30 000+
+ * entries is worth the launch (4M rows: 0.155 -> 0.127 ms) */
+#define PANELS_LONG_ROW 16384
 #define PANELS_LONG_SEG 4096
 #define PANELS_LONG_MAX 4096 /* more such rows than this: keep them inside */
 

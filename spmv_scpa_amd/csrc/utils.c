@@ -47,7 +47,8 @@ void log_prog_usage(const char *prog) {
     fprintf(stderr,
             "Usage: %s (-m <matrix.mtx> | -s <family>) -o <out-dir> [options]\n"
             "  -m, --matrix <file>     Matrix Market file to process\n"
-            "  -s, --synthetic <kind>  banded | random | ragged | kkt | stencil\n"
+            "  -s, --synthetic <kind>  banded | random | ragged | kkt | stencil |\n"
+            "                          powerlaw | hub\n"
             "      --rows <M> --nnz-row <K> --window <W>   synthetic shape\n"
             "  -o, --out <dir>         directory for serial.csv omp.csv cuda.csv\n"
             "  -d, --debug             validate every result against serial CSR\n"

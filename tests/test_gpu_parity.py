@@ -403,7 +403,7 @@ PANEL_CASES = [
     ("more_tiles_than_groups", S.SYNTH_RANDOM, 40_000, 50_000, 8, 1 << 30, 4096),
     ("empty_rows_banded", S.SYNTH_STENCIL, 27_000, 27_000, 7, 30, 128),
     ("tiny", S.SYNTH_RANDOM, 3, 64, 5, 64, 16),
-    # rows kept BESIDE the copy (> 8192 entries: panels.hip "LONG ROWS"): the
+    # rows kept BESIDE the copy (> 16384 entries: panels.hip "LONG ROWS"): the
     # hub row (30 000 / 131 072 entries) and the power law's tail
     ("hub_long_row_beside", S.SYNTH_HUB, 30_000, 30_000, 6, 512, 0),
     ("hub_131072_row", S.SYNTH_HUB, 50_000, 200_000, 4, 1 << 30, 4096),
@@ -441,7 +441,7 @@ def test_column_panel_path(tag, kind, M, N, K, W, pc, sched,
     info = dA.panels_info()
     assert info["entries"] == int(IRP[-1]) and dA.panels_schedule() == sched
     longest = int(np.max(np.diff(IRP))) if M else 0
-    assert ("long row(s) beside" in dA.panels_describe()) == (longest > 8192)
+    assert ("long row(s) beside" in dA.panels_describe()) == (longest > 16384)
     assert ((info["steps"] == 1) if sched != "steps"
             else (info["steps"] <= info["panels"]))
     # public bits: steps layout bit 0 flips between step launches and the

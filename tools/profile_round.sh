@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # All rocprofv3 evidence of a round in one gpurun call (run on the GPU box):
-#   tools/profile_round.sh r03
+#   tools/profile_round.sh r04 [all|passes|rest]
 # For each workload three passes of the same bench.py command (tools/profile.sh:
 # kernel trace + stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE; counters never share
 # a pass with the hip/hsa trace domains), summarised into
@@ -9,7 +9,8 @@
 # bench lines and the 1-GPU run of the fixed 80M x 80M problem that N > 1
 # lines use as their speed-up denominator.  Stops at the first failing step.
 set -uo pipefail
-round="${1:-r03}"
+round="${1:-r04}"
+part="${2:-all}"   # all | passes | rest  (two gpurun calls when one is too long)
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$root"
 mkdir -p gpurun_out profiles
@@ -21,12 +22,18 @@ prof() {  # prof <tag> <bench args...>
         "profiles/${round}_$tag.md" > /dev/null
     echo "-- profiles/${round}_$tag.md written"
 }
+if [ "$part" != "rest" ]; then
 prof wn_hll_tile_panels
 prof w20 --window 1048576
 prof w17 --window 131072
 prof c2_banded1M_csr --config 2
 prof c4_kkt_csr --config 4
 prof banded10M_hll --family banded --kernel 1
+fi
+if [ "$part" = "passes" ]; then
+    mkdir -p gpurun_out/profiles_${round} && cp -f profiles/${round}_* gpurun_out/profiles_${round}/
+    echo "== passes done"; exit 0
+fi
 step tools/pmc.sh "${round}_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
     bench.py --no-extras --no-cpu-baseline --steps 20
 step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_l2req" \

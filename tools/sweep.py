@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3,
-            "stencil": 4}[a.family]
+            "stencil": 4, "powerlaw": 5, "hub": 6}[a.family]
     M = a.rows
     N = a.cols or a.rows
     d_x = S.DevBuffer(N * 8)
