@@ -1361,7 +1361,7 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
     if (!best_kernel)
         return -EINVAL;
     const double mean = A->M > 0 ? (double)A->NZ / A->M : 0.0;
-    const int cand[5] = {2, 4, 1, 0, 3};
+    const int cand[5] = {4, 2, 1, 0, 3}; /* stream first: it is never the slow one */
     int best = -1;
     double bms = 1e300;
     std::vector<double> ms(5);
@@ -1374,14 +1374,21 @@ int spmv_csr_autotune(spmv_csr_dev *A, const double *d_x, double *d_y,
     int rc = scratch.reserve(flush);
     if (rc)
         return rc;
+    /* 5 launches per configuration -- 1 once any launch has run beyond 10 ms
+     * (a hub row of 10^5 entries under the sub-wave kernel: 46 ms x 3 orders
+     * x 6 launches was most of a 1.2 s selector run) */
+    int iters_cap = 5;
     auto time_k = [&](int kernel, int variant, int iters, double *m) {
         spmv_launch_opts o;
         memset(&o, 0, sizeof o);
         o.variant = variant;
+        iters = std::min(iters, iters_cap);
         int r = timed_loop(
             [&]() { return spmv_csr_launch(A, kernel, &o, d_x, d_y, NULL); }, 1,
             iters, flush, ms.data(), NULL, false, &scratch);
         *m = median_of(std::vector<double>(ms.begin(), ms.begin() + iters));
+        if (*m > 10.0)
+            iters_cap = 1;
         return r;
     };
     for (int k = 0; k < 5; ++k) {
