@@ -43,6 +43,24 @@ def main():
         else:
             out.copy_(res)
 
+    if mode == "describe":
+        # what every N > 1 line of bench.py says about the job (config.rccl,
+        # per-rank kernel times): the collective calls, on the gloo backend
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "bench", os.path.join(os.path.dirname(HERE), "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        import spmv_scpa_amd as S
+        rccl, per_rank = bench.describe_job(
+            S, torch, dist, torch.device("cpu"), rank, world, "gloo",
+            [float(rank + 1), float(rank + 1)])
+        assert rccl["nranks_joined"] == world and len(rccl["devices"]) == world
+        assert rccl["backend"] == "gloo" and rccl["library_links"]
+        assert per_rank == [float(r + 1) for r in range(world)]
+        print("rank %d ok" % rank)
+        dist.destroy_process_group()
+        return
     if mode == "pick":
         # bench.py's kernel / schedule / tile-height agreement with a FAKE
         # compute: every rank "tunes" something different, all must end up

@@ -63,6 +63,9 @@ def run_world(world, mode, chunks, rows):
                                                # the node's real widths
                                                (4, "staged", 4),
                                                (8, "staged", 4),
+                                               # config.rccl / per-rank times
+                                               (2, "describe", 1),
+                                               (3, "describe", 1),
                                                (3, "halo", 64),
                                                (3, "halo", 960),
                                                (2, "halo", 32)])

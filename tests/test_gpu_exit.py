@@ -155,7 +155,15 @@ def test_stale_wrapper_cannot_release_a_newer_handle_at_the_same_address():
     checked release acts only on the generation the wrapper was created with"""
     first = S.CsrDevice.generate(S.SYNTH_BANDED, 4_096, 4_096, 4, 0, 0, 42)
     addr, gen = first.h.value, first.gen
+    # the same situation without relying on the allocator: a LIVE handle at
+    # this address, released with a generation that is not its own
+    ign = S.ignored_releases()
+    S._lib.spmv_csr_release_checked(addr, gen + 1000)
+    S._lib.spmv_csr_release_checked(addr, 0)       # 0 never matches
+    assert S.ignored_releases() == ign + 1          # (0 is refused up front)
+    assert S._lib.spmv_handle_generation(addr) == gen   # still alive
     first.release()
+    assert S._lib.spmv_handle_generation(addr) == 0
     # create handles until one lands on the old address (calloc of one size
     # class: usually the very next one)
     made, twin = [], None
