@@ -800,6 +800,67 @@ def test_stream_kernel_on_long_empty_and_ragged_rows():
     S.csr_free(A)
 
 
+def test_long_rows_at_every_threshold_stream_segments_and_blocked_side_path():
+    """Rows around the two long-row thresholds: the CSR stream kernel cuts a
+    row of more than 8192 entries into 4096-entry segments (mode 2: last
+    arriver sums the partials in order), the blocked copy keeps a row of more
+    than 16384 entries beside itself (k_long_rows).  Lengths at and next to
+    every boundary, long rows first / last / adjacent / between empty rows,
+    ranges of up to 1024 short rows; launched three times each (the arrival
+    counters must be re-armed), the direct kernels bit-identical every time."""
+    rng = np.random.default_rng(11)
+    special = [8192, 8193, 12_288, 12_289, 4096 * 5 - 1, 16_384, 16_385,
+               20_000, 40_960, 0, 0, 70_001, 1, 8191, 4096, 4097]
+    lens = np.concatenate([
+        [16_385],                              # a long row FIRST
+        rng.integers(1, 4, 3_000),             # 1-3 entries: 1024-row ranges
+        special,                               # adjacent long rows, empties
+        rng.integers(0, 12, 5_000),
+        [8193, 16_385],                        # ... and LAST
+    ]).astype(np.int64)
+    M, N = len(lens), 90_000
+    IRP = np.zeros(M + 1, dtype=np.int32)
+    IRP[1:] = np.cumsum(lens)
+    JA = rng.integers(0, N, IRP[-1]).astype(np.int32)
+    AS = rng.uniform(-1, 1, IRP[-1])
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("thresholds", M, N, IRP, JA, AS)
+    dA = S.CsrDevice.upload(A)
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+    for k in (0, 1, 2, 3, 4):
+        first = None
+        for rep in range(3):
+            S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+            dA.launch(k, d_x.ptr, d_y.ptr)
+            S.stream_sync()
+            y = d_y.to_numpy(np.float64, M)
+            assert_parity(y, y_ref, scale, ("thresholds csr", k, rep))
+            first = y if first is None else first
+            assert np.array_equal(y, first), ("not deterministic", k, rep)
+    n_beside = int(np.sum(lens > 16_384))
+    for sched in ("chain", "steps", "sweep"):
+        for src in ("csr", "hll_col", "hll_row"):
+            if src == "csr":
+                m, blocked = dA, S.CSR_KERNEL_PANELS
+            else:
+                m, blocked = dA.to_hll(src == "hll_col"), S.HLL_KERNEL_PANELS
+            m.build_panels(4096, sched, tile_rows=1024)
+            assert "%d long row(s) beside" % n_beside in m.panels_describe()
+            assert m.panels_info()["entries"] == int(IRP[-1])
+            for rep in range(3):
+                S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                m.launch(blocked, d_x.ptr, d_y.ptr)
+                S.stream_sync()
+                assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                              ("thresholds blocked", sched, src, rep))
+            if src != "csr":
+                m.release()
+    dA.release()
+    S.csr_free(A)
+
+
 def test_config3_ragged_variant_full_size():
     """SURVEY 8d, secondary variant of config 3: row lengths uniform in
     [24, 40] (mean 32) so that the HLL form carries pads (S > nnz).  10M x 10M,
