@@ -569,6 +569,19 @@ def extra_measurements(S, torch, mat, x, y, Mloc, Nglob, K):
         best, _ = dB.autotune(dx, dy, True)
         row("config2 autotuned csr_%s flushed" % S.CSR_KERNEL_LABELS[best],
             dB, dB.time(best, dx, dy, 2, 20, FLUSH_BYTES, 0, stream=st))
+        # the reference's seam as it is called (host arrays in, host y out:
+        # upload + ONE launch + download per call, cuda_csr.cu:210-234): the
+        # PCIe-inclusive rate of the drop-in, never `value`
+        hA = dB.download()
+        xh = S.vec_synth(1_000_000, X_SEED)
+        S.csr_spmv_hip(hA, xh, kernel=4)  # first call: allocations warm
+        t0 = time.perf_counter()
+        _, kms = S.csr_spmv_hip(hA, xh, kernel=4)
+        wall = (time.perf_counter() - t0) * 1e3
+        out["config2 one-shot seam, host in/out (PCIe incl.)"] = [
+            round(wall, 2), round(2.0 * dB.NZ / (wall * 1e6), 1),
+            "kernel %.4f ms of it" % kms]
+        S.csr_free(hA)
         dB.release()
     except OSError as e:
         out["error"] = str(e)

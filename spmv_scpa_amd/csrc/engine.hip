@@ -1266,7 +1266,25 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
     int rc = scratch.reserve(flush);
     if (rc)
         return rc;
-    int iters = 5;
+    int iters = 5, warm = 1;
+    {
+        /* probe: ONE launch of the first candidate.  Beyond 10 ms (a hack
+         * block as wide as a hub row of 10^5 entries: 40-60 ms per launch)
+         * every configuration gets a single launch and no warm-up -- the
+         * blocked copy is what such a matrix will run anyway */
+        spmv_launch_opts o;
+        memset(&o, 0, sizeof o);
+        o.variant = 1;
+        rc = timed_loop(
+            [&]() { return spmv_hll_launch(H, cand[0], &o, d_x, d_y, NULL); }, 0,
+            1, flush, ms.data(), NULL, false, &scratch);
+        if (rc)
+            return rc;
+        if (ms[0] > 10.0) {
+            iters = 1;
+            warm = 0;
+        }
+    }
     for (int k = 0; k < 2; ++k)
         for (int order = 0; order < 3; ++order) { /* the workgroup orders */
             if (!H->col_major && order > 0)
@@ -1279,7 +1297,7 @@ int spmv_hll_autotune(spmv_hll_dev *H, const double *d_x, double *d_y,
              * launch, 1.8 s for the six combinations otherwise) */
             rc = timed_loop(
                 [&]() { return spmv_hll_launch(H, cand[k], &o, d_x, d_y, NULL); },
-                1, iters, flush, ms.data(), NULL, false, &scratch);
+                warm, iters, flush, ms.data(), NULL, false, &scratch);
             if (rc)
                 return rc;
             double m = median_of(std::vector<double>(ms.begin(), ms.begin() + iters));

@@ -75,3 +75,48 @@ def test_autotune_times_small_matrices_out_of_the_infinity_cache():
         dA.release()
         d_x.free()
         d_y.free()
+
+
+@pytest.mark.parametrize("kind,M,K,W", [
+    (S.SYNTH_POWERLAW, 2_000_000, 3, 1 << 30),   # webbase / amazon class
+    (S.SYNTH_HUB, 1_000_000, 6, 4096),           # dc1 class
+], ids=["powerlaw", "hub"])
+def test_selector_on_the_reference_s_irregular_classes(kind, M, K, W):
+    """on very short rows the selector MEASURES the
+    thread-per-row kernel (the reference's plots show it winning on roadNet /
+    amazon, cuda_csr.cu:19-31), and the block-per-row kernel when one row is
+    far longer than the rest -- and neither wins on wave64: the pick is the
+    stream kernel or the blocked copy, several times faster.  A hub row of
+    131 072 entries must not serialise the launch (stream kernel: segments;
+    blocked copy: the row beside it)."""
+    dA = S.CsrDevice.generate(kind, M, M, K, W, 0, 42)
+    d_x, d_y = S.DevBuffer(M * 8), S.DevBuffer(M * 8)
+    dH = None
+    try:
+        S.dev_fill_synth(d_x.ptr, M, 7)
+        best, ms = dA.autotune(d_x.ptr, d_y.ptr)
+        t = dA.tune_times()
+        assert best in (4, S.CSR_KERNEL_PANELS), (best, t)
+        assert t[4] > 0 and t[2] > 0          # always candidates
+        if dA.NZ / dA.M < 6:
+            assert t[0] > 0, t                # thread_row was measured ...
+            assert ms < 0.2 * t[0], (ms, t)   # ... and lost by > 5x
+        if kind == S.SYNTH_HUB:
+            assert t[3] > 0, t                # block_row measured, and lost
+            assert ms < 0.5 * t[3], (ms, t)
+            # the hub row (131 072 entries) is spread over workgroups: the
+            # stream kernel runs within 3x of the blocked pick, not 8x off
+            assert t[4] < 3.0 * ms + 0.02, (ms, t)
+            dH = dA.to_hll(True)
+            bh, mh = dH.autotune(d_x.ptr, d_y.ptr)
+            assert bh == S.HLL_KERNEL_PANELS     # the format pads 2.3x
+            assert "long row(s) beside" in dH.panels_describe()
+            assert mh < 2.0 * ms + 0.02, (mh, ms)   # was 4x the CSR time
+        log = dA.tune_log()
+        assert "direct kernels" in log and "total" in log
+    finally:
+        if dH is not None:
+            dH.release()
+        dA.release()
+        d_x.free()
+        d_y.free()
