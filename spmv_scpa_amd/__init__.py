@@ -696,14 +696,17 @@ def bench_hll_hip(H, x, kernel, waves_per_block=4):
 # MultiGpu is entered in `_live` (weak references).  Objects still alive when
 # the interpreter exits -- a failed test's traceback holds its locals until
 # then -- are NOT left to `__del__` during interpreter finalisation, where
-# module globals are being cleared in no particular order and the HIP / RCCL
-# runtimes may already be unloading (round 2: `double free or corruption` at
-# the exit of a GPU test process whose handles had not been released).  An
-# atexit hook releases them first, in dependency order (multi-GPU handles
-# with their communicators, then matrices, then raw buffers), while the
-# runtime is fully up; afterwards `_closed` is set and every finaliser is a
-# no-op.  The library ignores a second release of a handle (engine.hip,
-# live_take), so an explicit release() racing a finaliser is harmless too.
+# module globals are being cleared in no particular order: an atexit hook
+# releases them first, in dependency order (multi-GPU handles with their
+# communicators, then matrices, then raw buffers), while the runtime is fully
+# up; afterwards `_closed` is set and every finaliser is a no-op.  Handles are
+# released with the generation they were created with
+# (spmv_*_release_checked): a second release, or a stale wrapper whose
+# address the allocator reused, is ignored by the library and COUNTED
+# (ignored_releases()).  (This ordering was built in round 3 against the exit
+# abort of round 2; the abort's actual cause was the RTLD_GLOBAL load at the
+# top of this file -- the ordered release stays because it is the right
+# lifetime rule, not because it fixed that.)
 _live = weakref.WeakSet()
 _closed = False
 

@@ -1,5 +1,4 @@
-"""Process exit with device objects still alive ("double free or
-corruption" at the exit of a GPU test process after a failed test).
+"""Process exit with device objects still alive, and the dead-handle contract.
 
 A failed test's traceback keeps the test's locals -- an autotuned HllDevice
 carrying a blocked copy, two DevBuffers -- alive until the interpreter exits.
@@ -8,10 +7,15 @@ releasing anything; it must exit 0 and print nothing that smells of heap
 corruption.  The child runs with tools/abort_trace.c preloaded, so a native
 abort would name its stack in the assertion message.
 
-What makes the exit safe (spmv_scpa_amd/__init__.py, engine.hip): an atexit
-hook releases live objects in dependency order while the HIP runtime is up,
-finalisers are no-ops afterwards, and the library ignores a second release of
-a handle."""
+History: these cases were written in round 3 against the `double free or
+corruption` abort of round 2's GPU test process, whose cause was then
+unknown.  Round 4 found it -- the binding loaded the library RTLD_GLOBAL and a
+later in-process `import torch` collided with its dependency closure
+(tests/test_rocm_runtime_once.py reproduces that without a GPU) -- so what
+this file guards is the lifetime rule itself: an atexit hook releases live
+objects in dependency order while the HIP runtime is up, finalisers are no-ops
+afterwards, every entry point answers -EBADF for a dead handle, and a release
+the library ignores is counted (spmv_ignored_releases)."""
 import os
 import subprocess
 import sys
