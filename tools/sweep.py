@@ -15,6 +15,27 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def want_ablations(argv):
+    """experiment bits of --variants (anything beyond the documented order /
+    load bits) exist only in the -DSPMV_ABLATIONS flavour of the library: the
+    sweep builds it on demand (`make abl`) and loads it through SPMV_LIB"""
+    public = 1 | 2 | 4 | 16 | 32 | 64 | 512 | (1 << 29)
+    try:
+        vs = argv[argv.index("--variants") + 1]
+    except (ValueError, IndexError):
+        return False
+    return any(int(v) & ~public for v in vs.split(",") if v.strip())
+
+
+if want_ablations(sys.argv) and not os.environ.get("SPMV_LIB"):
+    import subprocess
+    abl = os.path.join(ROOT, "spmv_scpa_amd", "lib", "libspmv_scpa_amd_abl.so")
+    if not os.path.exists(abl):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "spmv_scpa_amd",
+                                                   "csrc"), "abl"], check=True)
+    os.environ["SPMV_LIB"] = abl
 import spmv_scpa_amd as S  # noqa: E402
 
 
@@ -37,6 +58,7 @@ def main():
     ap.add_argument("--flush", type=int, default=0)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    print("# library: %s (%s)" % (S.LIB_PATH, S.build_flavour()))
     kind = {"banded": 0, "random": 1, "ragged": 2, "kkt": 3,
             "stencil": 4, "powerlaw": 5, "hub": 6}[a.family]
     M = a.rows
