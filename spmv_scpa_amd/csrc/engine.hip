@@ -22,6 +22,7 @@
 #include "hip_csr.h"
 #include "hip_hll.h"
 #include "spmv_synth.h"
+#include "stream_table.h"
 #include "tune_blocked.h"
 
 /* Process defaults behind set_*_waves_per_block (the reference's seam sets
@@ -384,56 +385,6 @@ __global__ void k_flush_ro(const double *buf, size_t n, double *sink) {
 /* ------------------------------------------------------------------ */
 /* row-block table of the CSR stream kernel (host, O(M))                */
 /* ------------------------------------------------------------------ */
-static void build_rowblk(const int *irp, int M, int nnz_budget, int row_budget,
-                         std::vector<int> &tab, std::vector<int> &ent,
-                         std::vector<unsigned char> &mode, int *max_len,
-                         bool *has_segments) {
-    /* tab[k] / ent[k]: first row / first entry of range k; the closing pair
-     * (M, NZ) ends the table.  A row of more than STREAM_LONG_ROW entries
-     * becomes ceil(len / STREAM_SEG) consecutive ranges of mode 2 that all
-     * name the same row and cut its entries at multiples of STREAM_SEG. */
-    tab.clear();
-    ent.clear();
-    mode.clear();
-    *has_segments = false;
-    int start = 0, longest = 0, range_longest = 0;
-    auto close_range = [&](int r) { /* rows [start, r) */
-        tab.push_back(start);
-        ent.push_back(irp[start]);
-        mode.push_back(range_longest > STREAM_ROW_T ? 1 : 0);
-        start = r;
-        range_longest = 0;
-    };
-    for (int r = 0; r < M; ++r) {
-        const int len = irp[r + 1] - irp[r];
-        longest = std::max(longest, len);
-        if (len > STREAM_LONG_ROW) {
-            if (r > start)
-                close_range(r);
-            for (int b = irp[r]; b < irp[r + 1]; b += STREAM_SEG) {
-                tab.push_back(r);
-                ent.push_back(b);
-                mode.push_back(2);
-            }
-            *has_segments = true;
-            start = r + 1;
-            range_longest = 0;
-            continue;
-        }
-        const int have = irp[r] - irp[start];
-        const bool full = (have + len > nnz_budget) || (r - start >= row_budget);
-        if (full && r > start)
-            close_range(r);
-        range_longest = std::max(range_longest, len);
-    }
-    if (M > start)
-        close_range(M);
-    tab.push_back(M);
-    ent.push_back(irp[M]);
-    mode.push_back(0);
-    *max_len = longest;
-}
-
 static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     int rc = 0;
     std::vector<int> tab, ent;
@@ -446,8 +397,9 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
                           hipMemcpyDeviceToHost));
         host_irp = tmp.data();
     }
-    build_rowblk(host_irp, d->M, STREAM_NNZ, STREAM_ROWS, tab, ent, mode,
-                 &d->max_row_len, &segs);
+    stream_table_build(host_irp, d->M, STREAM_NNZ, STREAM_ROWS, STREAM_ROW_T,
+                       STREAM_LONG_ROW, STREAM_SEG, tab, ent, mode,
+                       &d->max_row_len, &segs);
     {
         /* constant row length?  (O(M) over the host copy of IRP) */
         /* (IRP[r] = r * len is what the kernel then computes: only for an

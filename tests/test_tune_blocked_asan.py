@@ -25,3 +25,22 @@ def test_tune_blocked_ownership_under_asan(tmp_path):
     sys.stdout.write(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "books balance" in r.stdout and "ERROR" not in r.stderr
+
+
+def test_stream_table_invariants_under_asan(tmp_path):
+    """the CSR stream kernel's row-block table (stream_table.h: ranges of up
+    to 2048 entries / 1024 rows, rows beyond 8192 entries cut into 4096-entry
+    segments): 600 seeded row-length vectors, every entry covered by exactly
+    one range, every row written exactly once, segment arithmetic as the
+    kernel restates it"""
+    exe = str(tmp_path / "stream_table_asan")
+    subprocess.run(
+        ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined",
+         "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+         "-I", os.path.join(ROOT, "spmv_scpa_amd", "csrc"),
+         os.path.join(ROOT, "tests", "asan", "stream_table_asan.cc"),
+         "-o", exe], check=True)
+    r = subprocess.run([exe, "600"], capture_output=True, text=True)
+    sys.stdout.write(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "every entry covered once" in r.stdout and "ERROR" not in r.stderr
