@@ -6,7 +6,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 MTX_CASES = ["gen", "sym", "pat", "cage4_like", "tail40", "ragged100", "sym70",
-             "skew", "herm", "patgen", "freeform"]
+             "skew", "herm", "patgen", "freeform", "hub96"]
 SYNTH_CASES = ["synth_banded", "synth_random", "synth_random_wide",
                "synth_ragged", "synth_kkt", "synth_stencil27",
                "synth_stencil7", "synth_powerlaw", "synth_powerlaw_k8",

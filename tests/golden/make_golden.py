@@ -102,6 +102,27 @@ def make_inputs():
     files["sym70.mtx"] = (banner(sym="symmetric") + "70 70 %d\n" % len(ent)
                           + coo_text(ent))
 
+    # dc1 class in miniature (reference scripts/download-matrices.py:7-38):
+    # 96 x 96 (3 hack blocks), one row holding EVERY column, one column
+    # present in most rows, short rows otherwise, empty rows, file order
+    # shuffled, a repeated coordinate
+    ent = []
+    for i in range(1, 97):
+        if i in (5, 64, 65, 66):
+            continue                      # empty rows
+        if i == 41:
+            for j in range(1, 97):        # the hub row
+                ent.append((i, j, round(rng.uniform(-1, 1), 5)))
+            continue
+        for _ in range(rng.randint(1, 4)):
+            ent.append((i, rng.randint(1, 96), round(rng.uniform(-2, 2), 5)))
+        if i % 10 != 3:
+            ent.append((i, 8, round(rng.uniform(-1, 1), 5)))   # the hub column
+    ent.append((41, 17, 0.5))             # repeated coordinate in the hub row
+    rng.shuffle(ent)
+    files["hub96.mtx"] = (banner() + "% hub row 41, hub column 8\n"
+                          + "96 96 %d\n" % len(ent) + coo_text(ent))
+
     # skew-symmetric / hermitian are NOT mirrored by the reference loader
     files["skew.mtx"] = banner(sym="skew-symmetric") + "3 3 2\n" + coo_text(
         [(2, 1, 1.5), (3, 1, -2.5)])
