@@ -19,7 +19,7 @@ DROPIN = os.path.join(S.ROOT, "oracle", "_ref", "ref_dropin")
 
 
 @pytest.mark.parametrize("name", ["gen", "cage4_like", "ragged100", "sym70",
-                                  "tail40"])
+                                  "tail40", "hub96"])
 def test_reference_driver_runs_on_mi355x_kernels(name, tmp_path):
     if not os.path.exists(DROPIN):
         pytest.skip("oracle/_ref/ref_dropin not built (needs /root/reference "
