@@ -627,6 +627,25 @@ def extra_measurements(S, torch, mat, x, y, Mloc, Nglob, K):
     except OSError as e:
         out["config5 error"] = str(e)
     out["configs_4_5_s"] = [round(t1 - t0, 1), round(time.time() - t1, 1)]
+    # ---- the reference's irregular classes (scripts/download-matrices.py:
+    # 7-38), autotuned CSR: power-law rows of mean 3 (webbase / amazon /
+    # roadNet) and a dc1-like hub row of 131072 entries + hub column
+    try:
+        for tag, fam, M2, K2, W2 in (
+                ("powerlaw 4Mx3 anywhere", "powerlaw", 4_000_000, 3, 8_000_000),
+                ("hub 1Mx6 W=4096", "hub", 1_000_000, 6, 4096)):
+            if M2 > Nglob:
+                continue  # x / y of this run are too short (--rows-per-gpu)
+            dA = S.CsrDevice.generate(FAMILIES[fam], M2, M2, K2, W2, 0,
+                                      MATRIX_SEED)
+            best, _ = dA.autotune(dx, dy)
+            fl = FLUSH_BYTES if dA.algorithmic_bytes < (512 << 20) else 0
+            row("%s csr_%s%s" % (tag, S.CSR_KERNEL_LABELS[best],
+                                 " flushed" if fl else ""),
+                dA, dA.time(best, dx, dy, 2, 10, fl, 0, stream=st))
+            dA.release()
+    except OSError as e:
+        out["irregular error"] = str(e)
     return out
 
 
