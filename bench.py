@@ -1480,6 +1480,10 @@ def native_mgpu_bench(args, argv, omp_team):
     g = S.MultiGpu(n)
     g.generate(kind, Mloc, K, W, MATRIX_SEED, as_hll=args.format == "hll")
     g.fill_x(X_SEED)
+    # exchange: chunked + overlapped for the direct kernels (like the torch
+    # path's "staged" mode), after the kernel for the blocked path
+    chunks = args.chunks if args.chunks > 0 else (4 if n > 1 else 1)
+    g.set_exchange(chunks, args.force_exchange)
     labels, prefix = ((S.HLL_KERNEL_LABELS, "hll_") if args.format == "hll"
                       else (S.CSR_KERNEL_LABELS, "csr_"))
     t_tune = None
@@ -1542,7 +1546,12 @@ def native_mgpu_bench(args, argv, omp_team):
             "stored_slots_per_gpu": stored,
             "partition": "contiguous row ranges, x replicated, in-place "
                          "all-gather(y) over RCCL" if n > 1 else "single GPU",
-            "exchange": "allgather (after the kernels; one group)",
+            "chunks": chunks,
+            "exchange": ("staged: %d chunks, all-gather of chunk c under the "
+                         "kernel of c+1" % chunks)
+            if chunks > 1 and labels[kernel] != "tile_panels"
+            and Mloc % (chunks * 32) == 0 and (n > 1 or args.force_exchange)
+            else "allgather (after the kernels; one group)",
             "exchange_ms_alone": round(exch, 5) if exch else None,
             "rccl": {"backend": "RCCL as linked by libspmv_scpa_amd.so",
                      "version": S.rccl_version(),

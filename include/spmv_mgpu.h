@@ -58,6 +58,17 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
 int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
                   double *wall_ms_total, double *kernel_ms_avg);
 
+/* How the fragments of y travel.  chunks = 1 (default): one grouped in-place
+ * ncclAllGather after the shard kernels.  chunks = 2..16: the shard's rows in
+ * that many equal pieces; chunk c of every device is all-gathered on a second
+ * stream (chunk-major staging buffer, one strided copy back at the end) while
+ * the kernel of chunk c+1 runs -- direct kernels only; the blocked path runs
+ * whole shards and keeps chunks = 1, as does a shard whose rows do not split
+ * into chunks of whole hack blocks.  Call after load / generate (it sizes the
+ * staging buffer).  force != 0 runs the collective with ONE device too (a
+ * 1-rank all-gather): the staging logic can then be tested on a 1-GPU box. */
+int spmv_mgpu_set_exchange(spmv_mgpu *g, int chunks, int force);
+
 /* the all-gather of y by itself, `iters` times; *ms_avg per exchange (0 with
  * one device: there is no exchange) */
 int spmv_mgpu_exchange_only(spmv_mgpu *g, int iters, double *ms_avg);

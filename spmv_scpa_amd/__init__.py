@@ -1109,6 +1109,7 @@ _sig("spmv_mgpu_spmv", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp)
 _sig("spmv_mgpu_autotune", C.c_int, C.c_void_p, _ip)
 _sig("spmv_mgpu_run", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp)
 _sig("spmv_mgpu_exchange_only", C.c_int, C.c_void_p, C.c_int, _dp)
+_sig("spmv_mgpu_set_exchange", C.c_int, C.c_void_p, C.c_int, C.c_int)
 _sig("spmv_mgpu_rccl_version", C.c_int)
 _sig("spmv_mgpu_comm_ranks", C.c_int, C.c_void_p)
 _sig("spmv_mgpu_device_bus_id", C.c_int, C.c_void_p, C.c_int, C.c_char_p,
@@ -1179,6 +1180,12 @@ class MultiGpu:
                                   C.byref(wall), kms.ctypes.data_as(_dp)),
                "spmv_mgpu_run")
         return wall.value, kms
+
+    def set_exchange(self, chunks=1, force=False):
+        """chunks > 1: staged all-gathers overlapped with the next chunk's
+        kernel (direct kernels); force: run the collective with one device"""
+        _check(_lib.spmv_mgpu_set_exchange(self.h, chunks, int(force)),
+               "spmv_mgpu_set_exchange")
 
     def exchange_only(self, iters=10):
         ms = C.c_double()

@@ -33,7 +33,17 @@ struct spmv_mgpu {
     std::vector<spmv_csr_dev *> csr;
     std::vector<spmv_hll_dev *> hll;
     std::vector<double *> x, y;
+    /* overlapped exchange (spmv_mgpu_set_exchange): the shard's rows in
+     * `chunks` equal pieces; chunk c of every device is written into the
+     * chunk-major staging buffer stage[c][device][:] and all-gathered in
+     * place on a second stream while the kernel of chunk c+1 runs; one
+     * strided copy puts y back into row order */
+    int chunks, force_exchange;
+    std::vector<hipStream_t> xstream;
+    std::vector<double *> stage;
+    std::vector<hipEvent_t> ev_k, ev_x; /* [device * MG_MAX_CHUNKS + chunk] */
 };
+#define MG_MAX_CHUNKS 16
 
 /* live multi-GPU handles: a second destroy of one handle is ignored (same
  * contract as spmv_*_release, engine.hip); never destroyed objects */
@@ -111,9 +121,10 @@ static void drop_shards(spmv_mgpu *g) {
             spmv_hll_release(g->hll[r]);
         (void)hipFree(g->x[r]);
         (void)hipFree(g->y[r]);
+        (void)hipFree(g->stage[r]);
         g->csr[r] = NULL;
         g->hll[r] = NULL;
-        g->x[r] = g->y[r] = NULL;
+        g->x[r] = g->y[r] = g->stage[r] = NULL;
     }
     g->rows_per_gpu = g->M = g->N = 0;
 }
@@ -131,6 +142,14 @@ void spmv_mgpu_destroy(spmv_mgpu *g) {
             ncclCommDestroy(g->comm[r]);
         if (g->stream[r])
             (void)hipStreamDestroy(g->stream[r]);
+        if (g->xstream[r])
+            (void)hipStreamDestroy(g->xstream[r]);
+        for (int c = 0; c < MG_MAX_CHUNKS; ++c) {
+            if (g->ev_k[(size_t)r * MG_MAX_CHUNKS + c])
+                (void)hipEventDestroy(g->ev_k[(size_t)r * MG_MAX_CHUNKS + c]);
+            if (g->ev_x[(size_t)r * MG_MAX_CHUNKS + c])
+                (void)hipEventDestroy(g->ev_x[(size_t)r * MG_MAX_CHUNKS + c]);
+        }
     }
     delete g;
 }
@@ -157,12 +176,25 @@ int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
     g->hll.assign(ngpus, NULL);
     g->x.assign(ngpus, NULL);
     g->y.assign(ngpus, NULL);
+    g->stage.assign(ngpus, NULL);
+    g->xstream.assign(ngpus, NULL);
+    g->ev_k.assign((size_t)ngpus * MG_MAX_CHUNKS, NULL);
+    g->ev_x.assign((size_t)ngpus * MG_MAX_CHUNKS, NULL);
+    g->chunks = 1;
+    g->force_exchange = 0;
     for (int r = 0; r < ngpus; ++r)
         g->dev[r] = r;
     NCCL_TRY(ncclCommInitAll(g->comm.data(), ngpus, g->dev.data()));
     for (int r = 0; r < ngpus; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         HIP_TRY(hipStreamCreate(&g->stream[r]));
+        HIP_TRY(hipStreamCreate(&g->xstream[r]));
+        for (int c = 0; c < MG_MAX_CHUNKS; ++c) {
+            HIP_TRY(hipEventCreateWithFlags(
+                &g->ev_k[(size_t)r * MG_MAX_CHUNKS + c], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(
+                &g->ev_x[(size_t)r * MG_MAX_CHUNKS + c], hipEventDisableTiming));
+        }
     }
     *out = g;
     return 0;
@@ -180,6 +212,8 @@ static int alloc_vectors(spmv_mgpu *g) {
                           (size_t)(g->N > 0 ? g->N : 1) * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&g->y[r], (ny ? ny : 1) * sizeof(double)));
         HIP_TRY(hipMemset(g->y[r], 0, (ny ? ny : 1) * sizeof(double)));
+        if (g->chunks > 1 && ny > 0) /* a reload keeps the exchange setting */
+            HIP_TRY(hipMalloc((void **)&g->stage[r], ny * sizeof(double)));
     }
 fail:
     return rc;
@@ -330,6 +364,8 @@ fail:
 
 static int launch_shard(spmv_mgpu *g, int r, int kernel);
 static int gather_y(spmv_mgpu *g);
+static bool staged(const spmv_mgpu *g, int kernel);
+static int step_staged(spmv_mgpu *g, int kernel);
 
 static double wall_ms_now(void) {
     struct timespec t;
@@ -357,12 +393,16 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
             HIP_TRY(hipStreamSynchronize(g->stream[r]));
         }
         const double t0 = wall_ms_now();
-        for (int r = 0; r < g->n && !rc; ++r) {
-            HIP_TRY(hipSetDevice(g->dev[r]));
-            rc = launch_shard(g, r, kernel);
+        if (staged(g, kernel)) {
+            rc = step_staged(g, kernel);
+        } else {
+            for (int r = 0; r < g->n && !rc; ++r) {
+                HIP_TRY(hipSetDevice(g->dev[r]));
+                rc = launch_shard(g, r, kernel);
+            }
+            if (!rc)
+                rc = gather_y(g);
         }
-        if (!rc)
-            rc = gather_y(g);
         if (rc)
             break;
         for (int r = 0; r < g->n; ++r) {
@@ -371,6 +411,86 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
         }
         if (it >= 0)
             ms_each[it] = wall_ms_now() - t0;
+    }
+fail:
+    return rc;
+}
+
+/* stage[c][src][i] -> y[src * rows + c * ch + i] */
+__global__ void k_unstage(int world, int k, int ch, const double *stage,
+                          double *y) {
+    const size_t n = (size_t)world * k * ch;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t % ch);
+        const size_t q = t / ch;
+        const int src = (int)(q % world), c = (int)(q / world);
+        y[((size_t)src * k + c) * ch + i] = stage[t];
+    }
+}
+
+/* does this launch use the staged pipeline?  direct kernels only (the blocked
+ * path runs whole shards), rows divisible into chunks of whole hack blocks */
+static bool staged(const spmv_mgpu *g, int kernel) {
+    const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
+    return g->chunks > 1 && kernel != blocked && (g->n > 1 || g->force_exchange) &&
+           g->rows_per_gpu % (g->chunks * HACK_SIZE) == 0 && g->stage[0] != NULL;
+}
+
+/* one step with the overlapped exchange: every device's chunk-c kernel, then
+ * (second stream, after that kernel) the grouped all-gather of chunk c, while
+ * the compute streams go on with chunk c+1; at the end the compute streams
+ * wait for the last gathers and un-stage */
+static int step_staged(spmv_mgpu *g, int kernel) {
+    int rc = 0;
+    const int k = g->chunks, ch = g->rows_per_gpu / k;
+    for (int c = 0; c < k && !rc; ++c) {
+        for (int r = 0; r < g->n && !rc; ++r) {
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            /* chunk c of device r goes to stage[c][r][0 .. ch): the launch
+             * indexes y from local row 0, so hand it (slot - first row) */
+            double *slot = g->stage[r] + ((size_t)c * g->n + r) * ch;
+            double *ybase = slot - (size_t)c * ch;
+            rc = g->is_hll
+                     ? spmv_hll_launch_blocks(g->hll[r], kernel, NULL, g->x[r],
+                                              ybase, c * ch / HACK_SIZE,
+                                              (c + 1) * ch / HACK_SIZE,
+                                              g->stream[r])
+                     : spmv_csr_launch_rows(g->csr[r], kernel, NULL, g->x[r],
+                                            ybase, c * ch, (c + 1) * ch,
+                                            g->stream[r]);
+            if (rc)
+                break;
+            hipEvent_t e = g->ev_k[(size_t)r * MG_MAX_CHUNKS + c];
+            HIP_TRY(hipEventRecord(e, g->stream[r]));
+            HIP_TRY(hipStreamWaitEvent(g->xstream[r], e, 0));
+        }
+        if (rc)
+            break;
+        NCCL_TRY(ncclGroupStart());
+        {
+            ncclResult_t first_bad = ncclSuccess;
+            for (int r = 0; r < g->n; ++r) {
+                double *blk = g->stage[r] + (size_t)c * g->n * ch;
+                const ncclResult_t e = ncclAllGather(
+                    blk + (size_t)r * ch, blk, (size_t)ch, ncclDouble,
+                    g->comm[r], g->xstream[r]);
+                if (e != ncclSuccess && first_bad == ncclSuccess)
+                    first_bad = e;
+            }
+            const ncclResult_t closed = ncclGroupEnd();
+            NCCL_TRY(first_bad);
+            NCCL_TRY(closed);
+        }
+    }
+    for (int r = 0; r < g->n && !rc; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        hipEvent_t e = g->ev_x[(size_t)r * MG_MAX_CHUNKS];
+        HIP_TRY(hipEventRecord(e, g->xstream[r]));
+        HIP_TRY(hipStreamWaitEvent(g->stream[r], e, 0));
+        hipLaunchKernelGGL(k_unstage, dim3(2048), dim3(256), 0, g->stream[r],
+                           g->n, k, ch, g->stage[r], g->y[r]);
+        HIP_TRY(hipGetLastError());
     }
 fail:
     return rc;
@@ -387,7 +507,7 @@ static int launch_shard(spmv_mgpu *g, int r, int kernel) {
 /* one grouped in-place all-gather of y over all devices (n > 1) */
 static int gather_y(spmv_mgpu *g) {
     int rc = 0;
-    if (g->n < 2)
+    if (g->n < 2 && !g->force_exchange)
         return 0;
     /* every call inside the group is checked, and the group is ALWAYS closed
      * before an error leaves this function */
@@ -414,6 +534,32 @@ static int sync_all(spmv_mgpu *g) {
     for (int r = 0; r < g->n; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         HIP_TRY(hipStreamSynchronize(g->stream[r]));
+        HIP_TRY(hipStreamSynchronize(g->xstream[r]));
+    }
+fail:
+    return rc;
+}
+
+/* chunks: 1 = the all-gather follows the kernels (in place); 2..16 = staged,
+ * overlapped (direct kernels only; rows per device must split into chunks of
+ * whole hack blocks, else the launch falls back to 1).  force != 0: run the
+ * collective even with ONE device (a 1-rank all-gather: lets the staging and
+ * un-staging logic run on a 1-GPU box). */
+int spmv_mgpu_set_exchange(spmv_mgpu *g, int chunks, int force) {
+    MG_OK(g);
+    if (chunks < 1 || chunks > MG_MAX_CHUNKS)
+        return -EINVAL;
+    int rc = 0;
+    device_guard keep;
+    g->chunks = chunks;
+    g->force_exchange = force != 0;
+    const size_t ny = (size_t)g->rows_per_gpu * g->n;
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        (void)hipFree(g->stage[r]);
+        g->stage[r] = NULL;
+        if (chunks > 1 && ny > 0)
+            HIP_TRY(hipMalloc((void **)&g->stage[r], ny * sizeof(double)));
     }
 fail:
     return rc;
@@ -441,6 +587,22 @@ int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
             if (rc)
                 break;
             *wall_ms_total = wall_ms_now();
+        }
+        if (staged(g, kernel)) {
+            /* events around the whole step of a device's compute stream: the
+             * chunk kernels and the un-staging copy (the gathers overlap) */
+            for (int r = 0; r < g->n && it >= 0; ++r) {
+                HIP_TRY(hipSetDevice(g->dev[r]));
+                HIP_TRY(hipEventRecord(ev[((size_t)r * steps + it) * 2],
+                                       g->stream[r]));
+            }
+            rc = step_staged(g, kernel);
+            for (int r = 0; r < g->n && it >= 0 && !rc; ++r) {
+                HIP_TRY(hipSetDevice(g->dev[r]));
+                HIP_TRY(hipEventRecord(ev[((size_t)r * steps + it) * 2 + 1],
+                                       g->stream[r]));
+            }
+            continue;
         }
         for (int r = 0; r < g->n && !rc; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));

@@ -163,3 +163,45 @@ def test_native_path_and_dist_path_give_the_same_y_on_one_shard():
         want, sc = O.synth_row_dot(S.SYNTH_RANDOM, rows, rows, K, W, 0, 42, 7,
                                    grow)
         assert abs(y_native[grow] - want) <= 1e-12 * sc
+
+
+@pytest.mark.parametrize("as_hll,kernel", [(True, 1), (True, 2), (False, 2)])
+@pytest.mark.parametrize("chunks", [2, 4, 5])
+def test_native_staged_exchange_runs_on_one_gpu(as_hll, kernel, chunks):
+    """spmv_mgpu_set_exchange(chunks, force): the overlapped pipeline of the
+    native path -- chunk kernels writing into the chunk-major staging buffer,
+    the (here 1-rank) ncclAllGather of chunk c on a second stream under the
+    kernel of chunk c+1, the strided copy back -- executed on the 1-GPU box,
+    several steps in a row (the staging buffer is reused), against the oracle.
+    5 chunks do not divide the rows into whole hack blocks: the launch must
+    fall back to the in-place all-gather and still be right."""
+    n = min(S.device_count(), 8)
+    rows = 64_000                    # per device; 64 000 / (4 x 32) = 500
+    g = S.MultiGpu(n)
+    g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, as_hll=as_hll)
+    g.fill_x(7)
+    g.set_exchange(chunks, force=True)
+    ms = g.spmv(kernel=kernel, warmup=1, iters=3)
+    assert len(ms) == 3 and np.all(ms > 0)
+    M = rows * n
+    y = g.get_y(n - 1)
+    probe = [0, 31, 32, rows // chunks - 1, rows // chunks, rows - 1, M - 1]
+    for grow in probe:
+        want, sc = O.synth_row_dot(S.SYNTH_RAGGED, M, M, 24, 4096, 0, 42, 7, grow)
+        assert abs(y[grow] - want) <= 1e-12 * sc, (grow, y[grow], want)
+    # the bench shape goes through the same pipeline
+    wall, kms = g.run(kernel, 1, 3)
+    assert wall > 0 and np.all(kms > 0)
+    y2 = g.get_y(0)
+    assert np.array_equal(y, y2)
+    # a reload keeps the exchange setting and re-sizes the staging buffer
+    g.generate(S.SYNTH_RANDOM, 32_000, 16, 2048, 42, as_hll=as_hll)
+    g.fill_x(7)
+    g.spmv(kernel=kernel, warmup=0, iters=2)
+    y3 = g.get_y(0)
+    want, sc = O.synth_row_dot(S.SYNTH_RANDOM, 32_000 * n, 32_000 * n, 16, 2048,
+                               0, 42, 7, 12_345)
+    assert abs(y3[12_345] - want) <= 1e-12 * sc
+    with pytest.raises(OSError):
+        g.set_exchange(17)
+    g.destroy()
