@@ -11,9 +11,12 @@
  * handle may be loaded / generated again (the previous shards are freed).
  *
  * STATUS: UNMEASURED with more than one device -- the boxes this was built
- * on have one GPU (tests run it with n = 1 and through `-g 1`); the grouped
- * all-gather, its error handling and the n > 1 timings have not run on
- * hardware yet.
+ * on have one GPU.  What HAS run there: everything with n = 1 (`-g 1`,
+ * bench.py --native-mgpu --gpus 1), and with spmv_mgpu_set_exchange(chunks,
+ * force = 1) the whole overlapped pipeline -- chunk kernels into the staging
+ * buffer, the grouped ncclAllGather per chunk on the second stream (a 1-rank
+ * collective), the copy back -- against the oracle (tests/test_gpu_mgpu.py).
+ * The n > 1 timings and RCCL's behaviour across devices have not run yet.
  */
 #ifndef SPMV_MGPU_H
 #define SPMV_MGPU_H
