@@ -295,6 +295,8 @@ static void run_multi_gpu(void) {
                 break;
         }
         rc = spmv_mgpu_load_csr(g, A, fmt);
+        if (!rc) /* direct kernels: all-gather of chunk c under chunk c+1 */
+            rc = spmv_mgpu_set_exchange(g, opt.gpus > 1 ? 4 : 1, 0);
         if (!rc)
             rc = spmv_mgpu_set_x(g, x.data);
         int kernel = -1;

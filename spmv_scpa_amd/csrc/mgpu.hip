@@ -39,6 +39,8 @@ struct spmv_mgpu {
      * place on a second stream while the kernel of chunk c+1 runs; one
      * strided copy puts y back into row order */
     int chunks, force_exchange;
+    int even; /* every shard holds exactly rows_per_gpu rows (no padded last
+                 shard): the chunk launches of the staged pipeline need it */
     std::vector<hipStream_t> xstream;
     std::vector<double *> stage;
     std::vector<hipEvent_t> ev_k, ev_x; /* [device * MG_MAX_CHUNKS + chunk] */
@@ -182,6 +184,7 @@ int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
     g->ev_x.assign((size_t)ngpus * MG_MAX_CHUNKS, NULL);
     g->chunks = 1;
     g->force_exchange = 0;
+    g->even = 0;
     for (int r = 0; r < ngpus; ++r)
         g->dev[r] = r;
     NCCL_TRY(ncclCommInitAll(g->comm.data(), ngpus, g->dev.data()));
@@ -236,6 +239,7 @@ int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
     g->rows_per_gpu = g->n > 0 ? starts[1] - starts[0] : 0;
     if (g->n == 1)
         g->rows_per_gpu = A->M;
+    g->even = (long long)g->rows_per_gpu * g->n == (long long)A->M;
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         sparse_csr *S = csr_row_slice(A, starts[r], starts[r + 1]);
@@ -268,6 +272,7 @@ int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
     device_guard keep;
     drop_shards(g);
     g->rows_per_gpu = rows_per_gpu;
+    g->even = 1;
     g->M = g->N = rows_per_gpu * g->n;
     g->is_hll = as_hll != 0;
     for (int r = 0; r < g->n && !rc; ++r) {
@@ -433,7 +438,8 @@ __global__ void k_unstage(int world, int k, int ch, const double *stage,
  * path runs whole shards), rows divisible into chunks of whole hack blocks */
 static bool staged(const spmv_mgpu *g, int kernel) {
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
-    return g->chunks > 1 && kernel != blocked && (g->n > 1 || g->force_exchange) &&
+    return g->chunks > 1 && g->even && kernel != blocked &&
+           (g->n > 1 || g->force_exchange) &&
            g->rows_per_gpu % (g->chunks * HACK_SIZE) == 0 && g->stage[0] != NULL;
 }
 

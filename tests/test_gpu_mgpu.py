@@ -205,3 +205,27 @@ def test_native_staged_exchange_runs_on_one_gpu(as_hll, kernel, chunks):
     with pytest.raises(OSError):
         g.set_exchange(17)
     g.destroy()
+
+
+@pytest.mark.parametrize("M", [128_000, 100_003])
+def test_native_staged_exchange_on_a_host_matrix(M):
+    """load_csr + set_exchange(4, force): staged when the rows split into
+    chunks of whole hack blocks on every device (128 000), the in-place
+    all-gather after the kernel otherwise (100 003: last shard padded)"""
+    n = min(S.device_count(), 8)
+    IRP, JA, AS = O.synth_csr(S.SYNTH_RAGGED, M, M, 24, 5000, 42)
+    x = O.synth_x(7, 0, M)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("mgx", M, M, IRP, JA, AS)
+    for as_hll, kernel in ((True, 1), (False, 2)):
+        g = S.MultiGpu(n)
+        g.load_csr(A, as_hll)
+        g.set_exchange(4, force=True)
+        g.set_x(x)
+        g.spmv(kernel=kernel, warmup=1, iters=2)
+        for r in range(n):
+            y = g.get_y(r)
+            assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
+        g.destroy()
+    S.csr_free(A)
