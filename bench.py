@@ -1088,9 +1088,11 @@ def main(argv=None):
     torch.cuda.synchronize()
 
     chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
-    if blocked or L > 1:
+    if blocked or L > 1 or (args.format == "csr" and kernel == 4):
         chunks = 1  # the blocked path runs whole shards only; with logical
-        #             shards the shard is the unit of overlap
+        #             shards the shard is the unit of overlap; the CSR stream
+        #             kernel's row-block table covers the whole shard (a row
+        #             sub-range would fall back to the sub-wave kernel)
     halo = 0
     if args.exchange == "halo":
         halo = args.halo_rows
@@ -1549,7 +1551,7 @@ def native_mgpu_bench(args, argv, omp_team):
             "chunks": chunks,
             "exchange": ("staged: %d chunks, all-gather of chunk c under the "
                          "kernel of c+1" % chunks)
-            if chunks > 1 and labels[kernel] != "tile_panels"
+            if chunks > 1 and labels[kernel] not in ("tile_panels", "stream")
             and Mloc % (chunks * 32) == 0 and (n > 1 or args.force_exchange)
             else "allgather (after the kernels; one group)",
             "exchange_ms_alone": round(exch, 5) if exch else None,

@@ -438,6 +438,11 @@ __global__ void k_unstage(int world, int k, int ch, const double *stage,
  * path runs whole shards), rows divisible into chunks of whole hack blocks */
 static bool staged(const spmv_mgpu *g, int kernel) {
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
+    /* the CSR stream kernel (4) owns a row-block table of the whole shard: a
+     * row sub-range would fall back to the sub-wave kernel (spmv_engine.h),
+     * which a long row makes 100x slower -- whole-shard launches instead */
+    if (!g->is_hll && kernel == 4)
+        return false;
     return g->chunks > 1 && g->even && kernel != blocked &&
            (g->n > 1 || g->force_exchange) &&
            g->rows_per_gpu % (g->chunks * HACK_SIZE) == 0 && g->stage[0] != NULL;
