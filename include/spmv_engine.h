@@ -178,7 +178,11 @@ int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
 int spmv_csr_launch(const spmv_csr_dev *A, int kernel,
                     const spmv_launch_opts *opts, const double *d_x,
                     double *d_y, void *stream);
-/* rows [row_begin, row_end) only; d_y still indexed from row 0 */
+/* rows [row_begin, row_end) only; d_y still indexed from row 0.  The stream
+ * kernel (4) owns a row-block table of the WHOLE matrix: on a proper sub-range
+ * the sub-wave kernel (2) runs instead -- correct, but without the stream
+ * kernel's long-row handling; callers that chunk a shard (dist.py, mgpu.hip)
+ * therefore launch whole shards when the pick is kernel 4 */
 int spmv_csr_launch_rows(const spmv_csr_dev *A, int kernel,
                          const spmv_launch_opts *opts, const double *d_x,
                          double *d_y, int row_begin, int row_end,
