@@ -65,7 +65,12 @@ template <int G> __device__ __forceinline__ double group_sum(double v) {
 }
 
 /* ------------------------------------------------------------------ */
-__global__ void k_csr_thread_row(int r0, int r1, const int *__restrict__ irp,
+/* `lrow` > 0 (kernels 0-3): the matrix has rows of more than `lrow` entries;
+ * they are left to k_csr_long_seg, launched right after on the same stream
+ * (one lane / wavefront / workgroup walking a hub row of 10^5 entries was
+ * 6-130 ms of an otherwise 0.05-3 ms launch) */
+__global__ void k_csr_thread_row(int r0, int r1, int lrow,
+                                 const int *__restrict__ irp,
                                  const int *__restrict__ ja,
                                  const double *__restrict__ as,
                                  const double *__restrict__ x,
@@ -74,13 +79,17 @@ __global__ void k_csr_thread_row(int r0, int r1, const int *__restrict__ irp,
     if (row >= r1)
         return;
     double acc = 0.0;
-    for (int k = irp[row], e = irp[row + 1]; k < e; ++k)
+    const int b = irp[row], e = irp[row + 1];
+    if (lrow > 0 && e - b > lrow)
+        return;
+    for (int k = b; k < e; ++k)
         acc += ld_stream(as + k) * x[ld_stream(ja + k)];
     y[row] = acc;
 }
 
 /* ------------------------------------------------------------------ */
-__global__ void k_csr_wave_row(int r0, int r1, const int *__restrict__ irp,
+__global__ void k_csr_wave_row(int r0, int r1, int lrow,
+                               const int *__restrict__ irp,
                                const int *__restrict__ ja,
                                const double *__restrict__ as,
                                const double *__restrict__ x,
@@ -93,6 +102,8 @@ __global__ void k_csr_wave_row(int r0, int r1, const int *__restrict__ irp,
         return;
     double acc = 0.0;
     const int beg = irp[row], end = irp[row + 1];
+    if (lrow > 0 && end - beg > lrow)
+        return; /* wave-uniform: the whole wavefront leaves */
     for (int k = beg + lane; k < end; k += WAVE)
         acc += ld_stream(as + k) * x[ld_stream(ja + k)];
     acc = group_sum<WAVE>(acc);
@@ -131,7 +142,7 @@ __device__ __forceinline__ int xcd_grouped(int bid) {
  * flushed, 256-lane workgroups) 0.0494 -> 0.0447 ms; banded 10M x 32 0.872 ->
  * 0.859; no change beyond noise on matrices whose launch is long. */
 template <int G, int P, int ORDER, bool UNI>
-__global__ void k_csr_subwave_row(int r0, int r1, int ulen,
+__global__ void k_csr_subwave_row(int r0, int r1, int ulen, int lrow,
                                   const int *__restrict__ irp,
                                   const int *__restrict__ ja,
                                   const double *__restrict__ as,
@@ -150,6 +161,7 @@ __global__ void k_csr_subwave_row(int r0, int r1, int ulen,
     const long long rbase = (long long)r0 + wave_global * (P * RPP) + lane / G;
 
     int beg[P], end[P];
+    bool mine[P]; /* this launch writes the row (not beyond r1, not a long row) */
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const long long row = rbase + p * RPP;
@@ -160,6 +172,11 @@ __global__ void k_csr_subwave_row(int r0, int r1, int ulen,
         } else {
             beg[p] = live ? irp[row] : 0;
             end[p] = live ? irp[row + 1] : 0;
+        }
+        mine[p] = live;
+        if (lrow > 0 && end[p] - beg[p] > lrow) { /* k_csr_long_seg's row */
+            end[p] = beg[p];
+            mine[p] = false;
         }
     }
     int c[P];
@@ -182,13 +199,14 @@ __global__ void k_csr_subwave_row(int r0, int r1, int ulen,
     for (int p = 0; p < P; ++p) {
         acc[p] = group_sum<G>(acc[p]);
         const long long row = rbase + p * RPP;
-        if (sub == 0 && row < r1)
+        if (sub == 0 && mine[p])
             y[row] = acc[p];
     }
 }
 
 /* ------------------------------------------------------------------ */
-__global__ void k_csr_block_row(int r0, int r1, const int *__restrict__ irp,
+__global__ void k_csr_block_row(int r0, int r1, int lrow,
+                                const int *__restrict__ irp,
                                 const int *__restrict__ ja,
                                 const double *__restrict__ as,
                                 const double *__restrict__ x,
@@ -200,6 +218,8 @@ __global__ void k_csr_block_row(int r0, int r1, const int *__restrict__ irp,
     for (int row = r0 + blockIdx.x; row < r1; row += gridDim.x) {
         double acc = 0.0;
         const int beg = irp[row], end = irp[row + 1];
+        if (lrow > 0 && end - beg > lrow)
+            continue; /* block-uniform; no barrier was entered for this row */
         for (int k = beg + threadIdx.x; k < end; k += blockDim.x)
             acc += ld_stream(as + k) * x[ld_stream(ja + k)];
 #pragma unroll
@@ -479,6 +499,58 @@ __global__ void __launch_bounds__(STREAM_THREADS)
 }
 
 /* ------------------------------------------------------------------ */
+/*
+ * The long rows of kernels 0-3: workgroup g sums range long_rb[g] of the
+ * stream kernel's table -- a mode-2 range, i.e. one 4096-entry segment of a
+ * row of more than STREAM_LONG_ROW entries -- exactly as k_csr_stream does
+ * (same partial sums, same arrival counters, same segment order: the two
+ * kernels give the same bits for such a row).  Rows outside [r0, r1) belong
+ * to another launch of a chunked exchange.
+ */
+__global__ void __launch_bounds__(STREAM_THREADS)
+    k_csr_long_seg(int r0, int r1, const int *__restrict__ long_rb,
+                   const int2 *__restrict__ rowblk, const int *__restrict__ irp,
+                   const int *__restrict__ ja, const double *__restrict__ as,
+                   const double *__restrict__ x, double *__restrict__ y,
+                   double *seg_partial, int *seg_count) {
+    __shared__ double part[STREAM_THREADS / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int rb = long_rb[blockIdx.x];
+    const int2 t_a = rowblk[rb], t_z = rowblk[rb + 1];
+    const int row = t_a.x, beg = t_a.y, end = t_z.y;
+    if (row < r0 || row >= r1)
+        return;
+    double acc = 0.0;
+    for (int k = beg + tid; k < end; k += STREAM_THREADS)
+        acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+    acc = group_sum<WAVE>(acc);
+    if (lane == 0)
+        part[tid / WAVE] = acc;
+    __syncthreads();
+    if (tid != 0)
+        return;
+    double t = 0.0;
+    for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
+        t += part[w];
+    const int b0 = irp[row];
+    const int nseg = (irp[row + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
+    const int rb0 = rb - (beg - b0) / STREAM_SEG;
+    __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    const int seen = __hip_atomic_fetch_add(seg_count + rb0, 1, __ATOMIC_ACQ_REL,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == nseg - 1) {
+        double sum = 0.0;
+        for (int j = 0; j < nseg; ++j)
+            sum += __hip_atomic_load(seg_partial + rb0 + j, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+        y[row] = sum;
+        __hip_atomic_store(seg_count + rb0, 0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 static int pick_group(const spmv_csr_dev *A, int group) {
     if (group >= 2 && group <= 32 && (group & (group - 1)) == 0)
         return group;
@@ -498,20 +570,21 @@ static void launch_subwave_u(int r0, int r1, int threads, int order,
     long long wpb = threads / WAVE;
     unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     const int ulen = A->uniform_len;
+    const int lrow = A->n_long_rb > 0 ? STREAM_LONG_ROW : 0;
     if (order == 1)
         hipLaunchKernelGGL((k_csr_subwave_row<G, P, 1, UNI>), dim3(grid),
-                           dim3(threads), 0, s, r0, r1, ulen, A->irp, A->ja,
-                           A->as, x, y);
+                           dim3(threads), 0, s, r0, r1, ulen, lrow, A->irp,
+                           A->ja, A->as, x, y);
     else if (order == 2)
         hipLaunchKernelGGL((k_csr_subwave_row<G, P, 2, UNI>),
                            dim3((grid + 8 * CSR_GROUP - 1) / (8 * CSR_GROUP) *
                                 8 * CSR_GROUP),
-                           dim3(threads), 0, s, r0, r1, ulen, A->irp, A->ja,
-                           A->as, x, y);
+                           dim3(threads), 0, s, r0, r1, ulen, lrow, A->irp,
+                           A->ja, A->as, x, y);
     else
         hipLaunchKernelGGL((k_csr_subwave_row<G, P, 0, UNI>), dim3(grid),
-                           dim3(threads), 0, s, r0, r1, ulen, A->irp, A->ja,
-                           A->as, x, y);
+                           dim3(threads), 0, s, r0, r1, ulen, lrow, A->irp,
+                           A->ja, A->as, x, y);
 }
 
 /* order bit 8 (0x100) set by the caller: the matrix has a constant row
@@ -574,6 +647,9 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
         return 0;
     const int threads = waves * WAVE;
     const int rows = r1 - r0;
+    /* rows beyond STREAM_LONG_ROW entries: kernels 0-3 skip them, a second
+     * launch sums their segments (k_csr_long_seg) */
+    const int lrow = A->n_long_rb > 0 ? STREAM_LONG_ROW : 0;
     /* the stream kernel's row-block table covers the whole matrix; a row
      * sub-range (chunked multi-GPU overlap) runs the sub-wave kernel */
     if (kernel == 4 && (r0 != 0 || r1 != A->M))
@@ -582,12 +658,12 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     case 0:
         hipLaunchKernelGGL(k_csr_thread_row,
                            dim3((rows + threads - 1) / threads), dim3(threads),
-                           0, s, r0, r1, A->irp, A->ja, A->as, x, y);
+                           0, s, r0, r1, lrow, A->irp, A->ja, A->as, x, y);
         break;
     case 1:
         hipLaunchKernelGGL(k_csr_wave_row, dim3((rows + waves - 1) / waves),
-                           dim3(threads), 0, s, r0, r1, A->irp, A->ja, A->as,
-                           x, y);
+                           dim3(threads), 0, s, r0, r1, lrow, A->irp, A->ja,
+                           A->as, x, y);
         break;
     case 2:
         switch (pick_group(A, group)) {
@@ -611,7 +687,7 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     case 3: {
         int grid = rows < 65536 * 16 ? rows : 65536 * 16;
         hipLaunchKernelGGL(k_csr_block_row, dim3(grid), dim3(threads), 0, s,
-                           r0, r1, A->irp, A->ja, A->as, x, y);
+                           r0, r1, lrow, A->irp, A->ja, A->as, x, y);
         break;
     }
     case 4: {
@@ -683,5 +759,10 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     default:
         return -EINVAL;
     }
+    if (kernel != 4 && lrow > 0)
+        hipLaunchKernelGGL(k_csr_long_seg, dim3(A->n_long_rb),
+                           dim3(STREAM_THREADS), 0, s, r0, r1, A->long_rb,
+                           (const int2 *)A->rowblk, A->irp, A->ja, A->as, x, y,
+                           A->seg_partial, A->seg_count);
     return hip_errno(hipGetLastError());
 }

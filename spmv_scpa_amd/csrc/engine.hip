@@ -428,6 +428,14 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
                       hipMemcpyHostToDevice));
     if (segs) { /* partial sums + arrival counters of the long rows' ranges */
         const size_t n = (size_t)d->n_rowblk + 1;
+        std::vector<int> lrb;
+        for (int k = 0; k < d->n_rowblk; ++k)
+            if (mode[(size_t)k] == 2)
+                lrb.push_back(k);
+        d->n_long_rb = (int)lrb.size();
+        HIP_TRY(hipMalloc((void **)&d->long_rb, lrb.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(d->long_rb, lrb.data(), lrb.size() * sizeof(int),
+                          hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&d->seg_partial, n * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&d->seg_count, n * sizeof(int)));
         HIP_TRY(hipMemset(d->seg_partial, 0, n * sizeof(double)));
@@ -460,6 +468,7 @@ static void csr_teardown(spmv_csr_dev *d) {
     (void)hipFree(d->rowblk_mode);
     (void)hipFree(d->seg_partial);
     (void)hipFree(d->seg_count);
+    (void)hipFree(d->long_rb);
     panels_free(d->panels);
     free(d->tune_log);
     free(d);
@@ -856,6 +865,9 @@ static void hll_teardown(spmv_hll_dev *d) {
     (void)hipFree(d->as);
     (void)hipFree(d->off);
     (void)hipFree(d->padmask);
+    (void)hipFree(d->wide_seg);
+    (void)hipFree(d->wide_part);
+    (void)hipFree(d->wide_cnt);
     panels_free(d->panels);
     free(d->tune_log);
     free(d);
@@ -919,6 +931,31 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
     }
     HIP_TRY(hipMemcpy(d->off, host_off, ((size_t)nb + 1) * sizeof(int64_t),
                       hipMemcpyHostToDevice));
+    {
+        /* segments of the wide blocks (hip_common.h, HLL_WIDE / HLL_WSEG) */
+        std::vector<int4> seg;
+        for (int b = 0; b < nb; ++b) {
+            const int rows = std::min(HACK_SIZE, M - b * HACK_SIZE);
+            const int64_t w = rows > 0 ? (host_off[b + 1] - host_off[b]) / rows : 0;
+            if (w <= HLL_WIDE)
+                continue;
+            const int nseg = (int)((w + HLL_WSEG - 1) / HLL_WSEG);
+            for (int k = 0; k < nseg; ++k)
+                seg.push_back(make_int4(b, k * HLL_WSEG, k, nseg));
+        }
+        d->n_wide_seg = (int)seg.size();
+        if (!seg.empty()) {
+            HIP_TRY(hipMalloc((void **)&d->wide_seg, seg.size() * sizeof(int4)));
+            HIP_TRY(hipMemcpy(d->wide_seg, seg.data(), seg.size() * sizeof(int4),
+                              hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&d->wide_part,
+                              seg.size() * HACK_SIZE * sizeof(double)));
+            HIP_TRY(hipMalloc((void **)&d->wide_cnt, seg.size() * sizeof(int)));
+            HIP_TRY(hipMemset(d->wide_part, 0,
+                              seg.size() * HACK_SIZE * sizeof(double)));
+            HIP_TRY(hipMemset(d->wide_cnt, 0, seg.size() * sizeof(int)));
+        }
+    }
     *out = d;
     return 0;
 fail:

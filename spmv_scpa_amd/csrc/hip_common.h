@@ -66,6 +66,10 @@ static inline int hip_errno(hipError_t e) {
 #define STREAM_ROWS 1024
 /* ranges whose longest row is at most this use the transposed form */
 #define STREAM_ROW_T 48
+/* hack blocks wider than HLL_WIDE columns go to k_hll_wide in segments of
+ * HLL_WSEG columns (hll_kernels.hip) */
+#define HLL_WIDE 4096
+#define HLL_WSEG 1024
 /* a row beyond STREAM_LONG_ROW entries is cut into segments of
  * STREAM_SEG entries, one workgroup each (one lane team walking a row of
  * 10^5 entries is the whole launch otherwise: dc1-class matrices) */
@@ -100,6 +104,10 @@ struct spmv_csr_dev {
     double *seg_partial; /* [n_rowblk] partial sum of a segment's range */
     int *seg_count;      /* [n_rowblk] arrivals, at a long row's first range;
                             both NULL when no row is that long */
+    int *long_rb;        /* [n_long_rb] indices of the mode-2 ranges: kernels
+                            0-3 leave rows beyond STREAM_LONG_ROW entries to a
+                            second launch over exactly these ranges */
+    int n_long_rb;
     int max_row_len;
     int uniform_len; /* > 0: EVERY row holds exactly this many entries (banded
                         and fixed-degree matrices: IRP[r] = r * uniform_len),
@@ -140,6 +148,15 @@ struct spmv_hll_dev {
                           before the rewrite; read only when the blocked copy
                           is built */
     spmv_panels *panels; /* optional column-panel copy (kernel 4) */
+    /* WIDE hack blocks (a block is as wide as its longest row: one hub row
+     * of 10^5 entries makes 32 lanes walk 10^5 columns, 10-60 ms).  Blocks
+     * wider than HLL_WIDE columns are skipped by kernels 0-3 and summed by a
+     * second launch, one workgroup per segment of HLL_WSEG columns
+     * (k_hll_wide; deterministic last-arriver reduction per block) */
+    int4 *wide_seg;    /* [n_wide_seg] (block, first column, segment, segments) */
+    int n_wide_seg;
+    double *wide_part; /* [n_wide_seg * 32] partial row sums */
+    int *wide_cnt;     /* [n_wide_seg] arrivals, at a block's first segment */
     double tune_ms[8];   /* last spmv_hll_autotune: best median per kernel id */
     char *tune_log;
 };

@@ -82,7 +82,10 @@ int hll_fix_pads_dev(spmv_hll_dev *H, hipStream_t s) {
 /* ------------------------------------------------------------------ */
 /* 0: lane per row, row-major                                           */
 /* ------------------------------------------------------------------ */
-__global__ void k_hll_row_major(int M, int b0, int b1,
+/* `wide` > 0 (kernels 0-3): the matrix has hack blocks of more than `wide`
+ * columns; they are left to k_hll_wide, launched right after on the same
+ * stream */
+__global__ void k_hll_row_major(int M, int b0, int b1, int wide,
                                 const int64_t *__restrict__ off,
                                 const int *__restrict__ ja,
                                 const double *__restrict__ as,
@@ -97,6 +100,8 @@ __global__ void k_hll_row_major(int M, int b0, int b1,
         return;
     int64_t o = off[b];
     int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    if (wide > 0 && w > wide)
+        return;
     const int *rj = ja + o + (int64_t)i * w;
     const double *ra = as + o + (int64_t)i * w;
     double acc = 0.0;
@@ -122,7 +127,7 @@ __global__ void k_hll_row_major(int M, int b0, int b1,
  * surplus ones of shorter ranges exit.
  */
 template <int U, int ORDER, int ABL = 0> /* ABL 1: all gathers read x[0] */
-__global__ void k_hll_col_direct(int M, int b0, int b1, xcd_ranges xr,
+__global__ void k_hll_col_direct(int M, int b0, int b1, int wide, xcd_ranges xr,
                                  const int64_t *__restrict__ off,
                                  const int *__restrict__ ja,
                                  const double *__restrict__ as,
@@ -156,6 +161,8 @@ __global__ void k_hll_col_direct(int M, int b0, int b1, xcd_ranges xr,
     const int64_t o = off[b];
     const unsigned len = (unsigned)(off[b + 1] - o);
     const int w = rows == HACK ? (int)(len >> 5) : (int)(len / (unsigned)rows);
+    if (wide > 0 && w > wide)
+        return;
     const int *cj = ja + o + i;
     const double *ca = as + o + i;
     double acc = 0.0;
@@ -228,7 +235,7 @@ __device__ __forceinline__ void hll_chunk_load(hll_chunk &c, int s0, int lane,
 }
 
 template <int ORDER>
-__global__ void k_hll_col_lds(int b0, int b1, xcd_ranges xr,
+__global__ void k_hll_col_lds(int b0, int b1, int wide, xcd_ranges xr,
                               const int64_t *__restrict__ off,
                               const int *__restrict__ ja,
                               const double *__restrict__ as,
@@ -260,8 +267,15 @@ __global__ void k_hll_col_lds(int b0, int b1, xcd_ranges xr,
         return;
     const bool hasB = bA + 1 < b1;
     const int64_t oA = off[bA], oB = off[bA + 1];
-    const int nA = (int)(oB - oA); /* slots of block A = 32 * wA */
-    const int nB = hasB ? (int)(off[bA + 2] - oB) : 0;
+    int nA = (int)(oB - oA); /* slots of block A = 32 * wA */
+    int nB = hasB ? (int)(off[bA + 2] - oB) : 0;
+    /* a wide block of the pair is k_hll_wide's: nothing read, nothing stored */
+    const bool skipA = wide > 0 && (nA >> 5) > wide;
+    const bool skipB = wide > 0 && (nB >> 5) > wide;
+    if (skipA)
+        nA = 0;
+    if (skipB)
+        nB = 0;
     const int half = lane >> 5, i = lane & 31;
     const int w = (half ? nB : nA) >> 5;
     const int nmax = nA > nB ? nA : nB;
@@ -309,14 +323,14 @@ __global__ void k_hll_col_lds(int b0, int b1, xcd_ranges xr,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (half == 0 || hasB)
+    if (half == 0 ? !skipA : (hasB && !skipB))
         __builtin_nontemporal_store(acc, y + (int64_t)(bA + half) * HACK + i);
 }
 
 /* ------------------------------------------------------------------ */
 /* 3: 16 lanes per row, row-major                                       */
 /* ------------------------------------------------------------------ */
-__global__ void k_hll_subwave_row(int M, int b0, int b1,
+__global__ void k_hll_subwave_row(int M, int b0, int b1, int wide,
                                   const int64_t *__restrict__ off,
                                   const int *__restrict__ ja,
                                   const double *__restrict__ as,
@@ -330,12 +344,12 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1,
     if (b < b1) {
         int rows = min(HACK, M - b * HACK);
         if (i < rows) {
-            live = true;
             int64_t o = off[b];
             int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+            live = !(wide > 0 && w > wide);
             const int *rj = ja + o + (int64_t)i * w;
             const double *ra = as + o + (int64_t)i * w;
-            for (int j = sub; j < w; j += 16)
+            for (int j = sub; live && j < w; j += 16)
                 acc += ld_stream(ra + j) * x[ld_stream(rj + j)];
         }
     }
@@ -344,6 +358,69 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1,
         acc += __shfl_down(acc, d, 16);
     if (live && sub == 0)
         y[(int64_t)b * HACK + i] = acc;
+}
+
+/* ------------------------------------------------------------------ */
+/* wide hack blocks (> HLL_WIDE columns): workgroup g sums columns        */
+/* [j0, j0 + HLL_WSEG) of block b for all its rows, either layout; the     */
+/* block's last segment to arrive adds the partial row sums in segment     */
+/* order (deterministic), writes y and re-arms the counter.                */
+/* ------------------------------------------------------------------ */
+__global__ void __launch_bounds__(256)
+    k_hll_wide(int M, int b0, int b1, int col_major,
+               const int4 *__restrict__ seg, const int64_t *__restrict__ off,
+               const int *__restrict__ ja, const double *__restrict__ as,
+               const double *__restrict__ x, double *__restrict__ y,
+               double *part, int *cnt) {
+    __shared__ double red[8][HACK];
+    __shared__ int s_seen;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int4 sg = seg[g];
+    const int b = sg.x, j0 = sg.y, kseg = sg.z, nseg = sg.w;
+    if (b < b0 || b >= b1)
+        return; /* another launch of a chunked exchange owns this block */
+    const int rows = min(HACK, M - b * HACK);
+    const int64_t o = off[b];
+    const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    const int j1 = min(j0 + HLL_WSEG, w);
+    /* col-major: a wavefront reads two columns x 32 rows, each 256 B
+     * contiguous; row-major: eight neighbouring columns of a row per 8 lanes */
+    const int i = col_major ? (tid & 31) : (tid >> 3);
+    const int cl = col_major ? (tid >> 5) : (tid & 7);
+    double acc = 0.0;
+    if (i < rows)
+        for (int j = j0 + cl; j < j1; j += 8) {
+            const int64_t t = o + (col_major ? (int64_t)j * rows + i
+                                             : (int64_t)i * w + j);
+            acc += ld_stream(as + t) * x[ld_stream(ja + t)];
+        }
+    red[cl][i] = acc;
+    __syncthreads();
+    if (tid < HACK) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            t += red[c][tid];
+        __hip_atomic_store(part + (size_t)g * HACK + tid, t, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int g0 = g - kseg;
+    if (tid == 0)
+        s_seen = __hip_atomic_fetch_add(cnt + g0, 1, __ATOMIC_ACQ_REL,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_seen != nseg - 1)
+        return;
+    if (tid < rows) {
+        double sum = 0.0;
+        for (int k = 0; k < nseg; ++k)
+            sum += __hip_atomic_load(part + (size_t)(g0 + k) * HACK + tid,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[(int64_t)b * HACK + tid] = sum;
+    }
+    if (tid == 0)
+        __hip_atomic_store(cnt + g0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* ------------------------------------------------------------------ */
@@ -371,6 +448,7 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
                                                         : H->order;
     const int threads = waves * WAVE;
     const long long lanes = (long long)(b1 - b0) * HACK;
+    const int wide = H->n_wide_seg > 0 ? HLL_WIDE : 0;
     /* XCD ranges of this launch: the handle's slot-balanced table for the
      * whole matrix, an even split for a block sub-range (multi-GPU chunks) */
     xcd_ranges xr = H->xcd_blk;
@@ -387,8 +465,8 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
     case 0:
         hipLaunchKernelGGL(k_hll_row_major,
                            dim3((unsigned)((lanes + threads - 1) / threads)),
-                           dim3(threads), 0, s, H->M, b0, b1, H->off, H->ja,
-                           H->as, x, y);
+                           dim3(threads), 0, s, H->M, b0, b1, wide, H->off,
+                           H->ja, H->as, x, y);
         break;
     case 1: {
         /* full blocks through LDS; a ragged last block goes direct */
@@ -403,22 +481,22 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
                 hipLaunchKernelGGL(k_hll_col_lds<1>,
                                    dim3(NUM_XCD * (((xmax + 1) / 2 + waves - 1) /
                                                    waves)),
-                                   dim3(threads), lds, s, b0, full_end, xr,
+                                   dim3(threads), lds, s, b0, full_end, wide, xr,
                                    H->off, H->ja, H->as, x, y);
             else if (order == 2)
                 hipLaunchKernelGGL(k_hll_col_lds<2>,
                                    dim3((nwg + NUM_XCD * HLL_GROUP - 1) /
                                         (NUM_XCD * HLL_GROUP) * NUM_XCD * HLL_GROUP),
-                                   dim3(threads), lds, s, b0, full_end, xr,
+                                   dim3(threads), lds, s, b0, full_end, wide, xr,
                                    H->off, H->ja, H->as, x, y);
             else
                 hipLaunchKernelGGL(k_hll_col_lds<0>, dim3(nwg), dim3(threads),
-                                   lds, s, b0, full_end, xr, H->off, H->ja,
+                                   lds, s, b0, full_end, wide, xr, H->off, H->ja,
                                    H->as, x, y);
         }
         if (full_end < b1)
             hipLaunchKernelGGL((k_hll_col_direct<8, 0>), dim3(1), dim3(WAVE), 0, s,
-                               H->M, full_end, b1, xr, H->off, H->ja, H->as, x, y);
+                               H->M, full_end, b1, wide, xr, H->off, H->ja, H->as, x, y);
         break;
     }
     case 2: {
@@ -428,19 +506,19 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
 #ifdef SPMV_ABLATIONS /* experiment arms: `make abl` builds them */
         if (variant & 32) { /* tuning: 4 columns per pipeline stage */
             hipLaunchKernelGGL((k_hll_col_direct<4, 1>), dim3(xgrid),
-                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, wide, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (variant & 64) { /* tuning: 16 columns per pipeline stage */
             hipLaunchKernelGGL((k_hll_col_direct<16, 1>), dim3(xgrid),
-                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, wide, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
         if (variant & 16) { /* ABL 1: every gather reads x[0..1]: WRONG y */
             hipLaunchKernelGGL((k_hll_col_direct<8, 1, 1>), dim3(xgrid),
-                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, wide, xr, H->off,
                                H->ja, H->as, x, y);
             break;
         }
@@ -448,17 +526,17 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         const unsigned hwgrid = (unsigned)((lanes + threads - 1) / threads);
         if (order == 1)
             hipLaunchKernelGGL((k_hll_col_direct<8, 1>), dim3(xgrid),
-                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, wide, xr, H->off,
                                H->ja, H->as, x, y);
         else if (order == 2)
             hipLaunchKernelGGL((k_hll_col_direct<8, 2>),
                                dim3((hwgrid + NUM_XCD * HLL_GROUP - 1) /
                                     (NUM_XCD * HLL_GROUP) * NUM_XCD * HLL_GROUP),
-                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, wide, xr, H->off,
                                H->ja, H->as, x, y);
         else
             hipLaunchKernelGGL((k_hll_col_direct<8, 0>), dim3(hwgrid),
-                               dim3(threads), 0, s, H->M, b0, b1, xr, H->off,
+                               dim3(threads), 0, s, H->M, b0, b1, wide, xr, H->off,
                                H->ja, H->as, x, y);
         break;
     }
@@ -466,10 +544,15 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
         hipLaunchKernelGGL(
             k_hll_subwave_row,
             dim3((unsigned)((lanes * 16 + threads - 1) / threads)),
-            dim3(threads), 0, s, H->M, b0, b1, H->off, H->ja, H->as, x, y);
+            dim3(threads), 0, s, H->M, b0, b1, wide, H->off, H->ja, H->as, x,
+            y);
         break;
     default:
         return -EINVAL;
     }
+    if (wide > 0)
+        hipLaunchKernelGGL(k_hll_wide, dim3(H->n_wide_seg), dim3(256), 0, s,
+                           H->M, b0, b1, H->col_major, H->wide_seg, H->off,
+                           H->ja, H->as, x, y, H->wide_part, H->wide_cnt);
     return hip_errno(hipGetLastError());
 }

@@ -839,6 +839,40 @@ def test_long_rows_at_every_threshold_stream_segments_and_blocked_side_path():
             assert_parity(y, y_ref, scale, ("thresholds csr", k, rep))
             first = y if first is None else first
             assert np.array_equal(y, first), ("not deterministic", k, rep)
+    # the direct HLL kernels: hack blocks wider than 4096 columns (here: most
+    # of the special rows' blocks, and the ragged TAIL block of 19 rows) are
+    # summed by k_hll_wide in 1024-column segments, the rest by the kernel
+    for cm in (True, False):
+        dH = dA.to_hll(cm)
+        for k in range(S.NUM_HLL_KERNELS):
+            if S.HLL_KERNEL_COL_MAJOR[k] != cm:
+                continue
+            first = None
+            for rep in range(3):
+                S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                dH.launch(k, d_x.ptr, d_y.ptr, waves_per_block=4)
+                S.stream_sync()
+                y = d_y.to_numpy(np.float64, M)
+                assert_parity(y, y_ref, scale, ("thresholds hll", cm, k, rep))
+                first = y if first is None else first
+                assert np.array_equal(y, first), ("not deterministic", cm, k)
+            # block sub-ranges (chunked exchanges): wide blocks only in theirs
+            S._lib.spmv_dev_memset(d_y.ptr, 0, M * 8, None)
+            nb = dH.num_blocks
+            for b0, b1 in ((0, 1), (1, nb // 2), (nb // 2, nb)):
+                dH.launch(k, d_x.ptr, d_y.ptr, blocks=(b0, b1))
+            S.stream_sync()
+            assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                          ("thresholds hll blocks", cm, k))
+        dH.release()
+    # CSR row sub-ranges with long rows (kernel 4 falls back to kernel 2 there)
+    for k in (0, 1, 2, 3, 4):
+        S._lib.spmv_dev_memset(d_y.ptr, 0, M * 8, None)
+        for r0, r1 in ((0, 1), (1, 3_010), (3_010, M)):
+            dA.launch(k, d_x.ptr, d_y.ptr, rows=(r0, r1))
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale,
+                      ("thresholds csr rows", k))
     n_beside = int(np.sum(lens > 16_384))
     for sched in ("chain", "steps", "sweep"):
         for src in ("csr", "hll_col", "hll_row"):
