@@ -65,7 +65,8 @@ template <int G> __device__ __forceinline__ double group_sum(double v) {
 }
 
 /* ------------------------------------------------------------------ */
-/* `lrow` > 0 (kernels 0-3): the matrix has rows of more than `lrow` entries;
+/* `lrow` > 0 (kernels 0-3): the matrix has rows of more than `lrow` (2048:
+ * the stream kernel's entry budget, i.e. rows that own a range) entries;
  * they are left to k_csr_long_seg, launched right after on the same stream
  * (one lane / wavefront / workgroup walking a hub row of 10^5 entries was
  * 6-130 ms of an otherwise 0.05-3 ms launch) */
@@ -501,15 +502,19 @@ __global__ void __launch_bounds__(STREAM_THREADS)
 /* ------------------------------------------------------------------ */
 /*
  * The long rows of kernels 0-3: workgroup g sums range long_rb[g] of the
- * stream kernel's table -- a mode-2 range, i.e. one 4096-entry segment of a
- * row of more than STREAM_LONG_ROW entries -- exactly as k_csr_stream does
- * (same partial sums, same arrival counters, same segment order: the two
- * kernels give the same bits for such a row).  Rows outside [r0, r1) belong
+ * stream kernel's table -- one whole row of 2049 .. STREAM_LONG_ROW entries,
+ * or (mode 2) one 4096-entry segment of a longer row -- exactly as
+ * k_csr_stream does (same strides, same partial sums, arrival counters and
+ * segment order: the two kernels give the same bits for such a row).  Even
+ * 2048 entries are 512 dependent steps for a 4-lane team (0.25 ms) -- the
+ * power-law matrices have hundreds of such rows.  Rows outside [r0, r1) belong
  * to another launch of a chunked exchange.
  */
 __global__ void __launch_bounds__(STREAM_THREADS)
     k_csr_long_seg(int r0, int r1, const int *__restrict__ long_rb,
-                   const int2 *__restrict__ rowblk, const int *__restrict__ irp,
+                   const int2 *__restrict__ rowblk,
+                   const unsigned char *__restrict__ mode,
+                   const int *__restrict__ irp,
                    const int *__restrict__ ja, const double *__restrict__ as,
                    const double *__restrict__ x, double *__restrict__ y,
                    double *seg_partial, int *seg_count) {
@@ -532,6 +537,10 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     double t = 0.0;
     for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
         t += part[w];
+    if (mode[rb] != 2) { /* a whole row of 2049 .. STREAM_LONG_ROW entries */
+        y[row] = t;
+        return;
+    }
     const int b0 = irp[row];
     const int nseg = (irp[row + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
     const int rb0 = rb - (beg - b0) / STREAM_SEG;
@@ -570,7 +579,7 @@ static void launch_subwave_u(int r0, int r1, int threads, int order,
     long long wpb = threads / WAVE;
     unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     const int ulen = A->uniform_len;
-    const int lrow = A->n_long_rb > 0 ? STREAM_LONG_ROW : 0;
+    const int lrow = A->n_long_rb > 0 ? STREAM_NNZ : 0;
     if (order == 1)
         hipLaunchKernelGGL((k_csr_subwave_row<G, P, 1, UNI>), dim3(grid),
                            dim3(threads), 0, s, r0, r1, ulen, lrow, A->irp,
@@ -647,9 +656,9 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
         return 0;
     const int threads = waves * WAVE;
     const int rows = r1 - r0;
-    /* rows beyond STREAM_LONG_ROW entries: kernels 0-3 skip them, a second
-     * launch sums their segments (k_csr_long_seg) */
-    const int lrow = A->n_long_rb > 0 ? STREAM_LONG_ROW : 0;
+    /* rows beyond STREAM_NNZ entries (they own a range of the stream table):
+     * kernels 0-3 skip them, a second launch sums them (k_csr_long_seg) */
+    const int lrow = A->n_long_rb > 0 ? STREAM_NNZ : 0;
     /* the stream kernel's row-block table covers the whole matrix; a row
      * sub-range (chunked multi-GPU overlap) runs the sub-wave kernel */
     if (kernel == 4 && (r0 != 0 || r1 != A->M))
@@ -762,7 +771,7 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
     if (kernel != 4 && lrow > 0)
         hipLaunchKernelGGL(k_csr_long_seg, dim3(A->n_long_rb),
                            dim3(STREAM_THREADS), 0, s, r0, r1, A->long_rb,
-                           (const int2 *)A->rowblk, A->irp, A->ja, A->as, x, y,
-                           A->seg_partial, A->seg_count);
+                           (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
+                           A->ja, A->as, x, y, A->seg_partial, A->seg_count);
     return hip_errno(hipGetLastError());
 }

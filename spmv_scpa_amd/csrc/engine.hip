@@ -426,16 +426,22 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     HIP_TRY(hipMalloc((void **)&d->rowblk_mode, mode.size()));
     HIP_TRY(hipMemcpy(d->rowblk_mode, mode.data(), mode.size(),
                       hipMemcpyHostToDevice));
-    if (segs) { /* partial sums + arrival counters of the long rows' ranges */
-        const size_t n = (size_t)d->n_rowblk + 1;
+    {
+        /* ranges holding (a segment of) one row of more than STREAM_NNZ
+         * entries: what kernels 0-3 leave to k_csr_long_seg */
         std::vector<int> lrb;
         for (int k = 0; k < d->n_rowblk; ++k)
-            if (mode[(size_t)k] == 2)
+            if (mode[(size_t)k] == 2 || ent[(size_t)k + 1] - ent[(size_t)k] > STREAM_NNZ)
                 lrb.push_back(k);
         d->n_long_rb = (int)lrb.size();
-        HIP_TRY(hipMalloc((void **)&d->long_rb, lrb.size() * sizeof(int)));
-        HIP_TRY(hipMemcpy(d->long_rb, lrb.data(), lrb.size() * sizeof(int),
-                          hipMemcpyHostToDevice));
+        if (!lrb.empty()) {
+            HIP_TRY(hipMalloc((void **)&d->long_rb, lrb.size() * sizeof(int)));
+            HIP_TRY(hipMemcpy(d->long_rb, lrb.data(), lrb.size() * sizeof(int),
+                              hipMemcpyHostToDevice));
+        }
+    }
+    if (segs) { /* partial sums + arrival counters of the long rows' ranges */
+        const size_t n = (size_t)d->n_rowblk + 1;
         HIP_TRY(hipMalloc((void **)&d->seg_partial, n * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&d->seg_count, n * sizeof(int)));
         HIP_TRY(hipMemset(d->seg_partial, 0, n * sizeof(double)));

@@ -68,8 +68,8 @@ static inline int hip_errno(hipError_t e) {
 #define STREAM_ROW_T 48
 /* hack blocks wider than HLL_WIDE columns go to k_hll_wide in segments of
  * HLL_WSEG columns (hll_kernels.hip) */
-#define HLL_WIDE 4096
-#define HLL_WSEG 1024
+#define HLL_WIDE 512
+#define HLL_WSEG 256
 /* a row beyond STREAM_LONG_ROW entries is cut into segments of
  * STREAM_SEG entries, one workgroup each (one lane team walking a row of
  * 10^5 entries is the whole launch otherwise: dc1-class matrices) */
@@ -104,9 +104,10 @@ struct spmv_csr_dev {
     double *seg_partial; /* [n_rowblk] partial sum of a segment's range */
     int *seg_count;      /* [n_rowblk] arrivals, at a long row's first range;
                             both NULL when no row is that long */
-    int *long_rb;        /* [n_long_rb] indices of the mode-2 ranges: kernels
-                            0-3 leave rows beyond STREAM_LONG_ROW entries to a
-                            second launch over exactly these ranges */
+    int *long_rb;        /* [n_long_rb] indices of the ranges that hold (a
+                            segment of) ONE row of more than STREAM_NNZ
+                            entries: kernels 0-3 leave such rows to a second
+                            launch over exactly these ranges */
     int n_long_rb;
     int max_row_len;
     int uniform_len; /* > 0: EVERY row holds exactly this many entries (banded
@@ -149,7 +150,8 @@ struct spmv_hll_dev {
                           is built */
     spmv_panels *panels; /* optional column-panel copy (kernel 4) */
     /* WIDE hack blocks (a block is as wide as its longest row: one hub row
-     * of 10^5 entries makes 32 lanes walk 10^5 columns, 10-60 ms).  Blocks
+     * of 10^5 entries makes 32 lanes walk 10^5 columns, 10-60 ms; even 4096
+     * columns are a 0.2-0.5 ms walk of dependent steps).  Blocks
      * wider than HLL_WIDE columns are skipped by kernels 0-3 and summed by a
      * second launch, one workgroup per segment of HLL_WSEG columns
      * (k_hll_wide; deterministic last-arriver reduction per block) */

@@ -818,6 +818,12 @@ def test_long_rows_at_every_threshold_stream_segments_and_blocked_side_path():
         rng.integers(0, 12, 5_000),
         [8193, 16_385],                        # ... and LAST
     ]).astype(np.int64)
+    # hack blocks at the HLL wide-block threshold (512 columns; segments of
+    # 256) and rows at the stream kernel's entry budget (2048: beyond it a row
+    # owns a range, and kernels 0-3 hand it to k_csr_long_seg)
+    for at, ln in ((100, 512), (400, 513), (700, 511), (1000, 768), (1300, 769),
+                   (1600, 2047), (1900, 2048), (2200, 2049), (2500, 1025)):
+        lens[at] = ln
     M, N = len(lens), 90_000
     IRP = np.zeros(M + 1, dtype=np.int32)
     IRP[1:] = np.cumsum(lens)
@@ -839,9 +845,9 @@ def test_long_rows_at_every_threshold_stream_segments_and_blocked_side_path():
             assert_parity(y, y_ref, scale, ("thresholds csr", k, rep))
             first = y if first is None else first
             assert np.array_equal(y, first), ("not deterministic", k, rep)
-    # the direct HLL kernels: hack blocks wider than 4096 columns (here: most
+    # the direct HLL kernels: hack blocks wider than 512 columns (here: most
     # of the special rows' blocks, and the ragged TAIL block of 19 rows) are
-    # summed by k_hll_wide in 1024-column segments, the rest by the kernel
+    # summed by k_hll_wide in 256-column segments, the rest by the kernel
     for cm in (True, False):
         dH = dA.to_hll(cm)
         for k in range(S.NUM_HLL_KERNELS):
