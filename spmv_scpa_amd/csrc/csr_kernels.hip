@@ -353,38 +353,42 @@ __global__ void __launch_bounds__(STREAM_THREADS)
         if (lane == 0)
             part[tid / WAVE] = acc;
         __syncthreads();
+        /* The row's segments are consecutive ranges rb0 .. rb0 + nseg - 1.
+         * Each leaves its partial sum; the LAST to arrive (counter at the
+         * row's first range) adds them up in a fixed order -- the same
+         * whatever the arrival order, so the result is deterministic -- writes
+         * y and re-arms the counter for the next launch.  Agent-scope
+         * atomics: the segments run on different XCDs, whose L2s are not
+         * coherent for plain loads and stores. */
+        __shared__ int s_last;
         if (tid == 0) {
             double t = 0.0;
             for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
                 t += part[w];
+            s_last = 0;
             if (md != 2) {
                 y[row_a] = t;
             } else {
-                /* The row's segments are consecutive ranges rb0 .. rb0 +
-                 * nseg - 1.  Each leaves its partial sum, the LAST to arrive
-                 * (counter at the row's first range) adds them up in segment
-                 * order -- the same order whatever the arrival order, so the
-                 * result is deterministic -- writes y and re-arms the counter
-                 * for the next launch.  Agent-scope atomics: the segments
-                 * run on different XCDs, whose L2s are not coherent for plain
-                 * loads and stores. */
                 const int b0 = irp[row_a];
-                const int nseg = (irp[row_a + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
+                const int nseg =
+                    (irp[row_a + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
                 const int rb0 = rb - (beg - b0) / STREAM_SEG;
                 __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
                 const int seen = __hip_atomic_fetch_add(
                     seg_count + rb0, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen == nseg - 1) {
-                    double sum = 0.0;
-                    for (int j = 0; j < nseg; ++j)
-                        sum += __hip_atomic_load(seg_partial + rb0 + j,
-                                                 __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-                    y[row_a] = sum;
-                    __hip_atomic_store(seg_count + rb0, 0, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
+                s_last = seen == nseg - 1 ? nseg : 0;
+            }
+        }
+        __syncthreads();
+        if (s_last && tid < WAVE) { /* one wavefront adds the partials */
+            const int n = s_last;
+            const int first = rb - (beg - irp[row_a]) / STREAM_SEG;
+            const double sum = wave_ordered_sum(seg_partial + first, n, lane);
+            if (lane == 0) {
+                y[row_a] = sum;
+                __hip_atomic_store(seg_count + first, 0, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -505,7 +509,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
  * stream kernel's table -- one whole row of 2049 .. STREAM_LONG_ROW entries,
  * or (mode 2) one 4096-entry segment of a longer row -- exactly as
  * k_csr_stream does (same strides, same partial sums, arrival counters and
- * segment order: the two kernels give the same bits for such a row).  Even
+ * summation order: the two kernels give the same bits for such a row).  Even
  * 2048 entries are 512 dependent steps for a 4-lane team (0.25 ms) -- the
  * power-law matrices have hundreds of such rows.  Rows outside [r0, r1) belong
  * to another launch of a chunked exchange.
@@ -532,30 +536,34 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     if (lane == 0)
         part[tid / WAVE] = acc;
     __syncthreads();
-    if (tid != 0)
-        return;
-    double t = 0.0;
-    for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
-        t += part[w];
-    if (mode[rb] != 2) { /* a whole row of 2049 .. STREAM_LONG_ROW entries */
-        y[row] = t;
-        return;
+    __shared__ int s_last;
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < STREAM_THREADS / WAVE; ++w)
+            t += part[w];
+        s_last = 0;
+        if (mode[rb] != 2) { /* a whole row of 2049 .. STREAM_LONG_ROW entries */
+            y[row] = t;
+        } else {
+            const int b0 = irp[row];
+            const int nseg = (irp[row + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
+            const int rb0 = rb - (beg - b0) / STREAM_SEG;
+            __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            const int seen = __hip_atomic_fetch_add(
+                seg_count + rb0, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = seen == nseg - 1 ? nseg : 0;
+        }
     }
-    const int b0 = irp[row];
-    const int nseg = (irp[row + 1] - b0 + STREAM_SEG - 1) / STREAM_SEG;
-    const int rb0 = rb - (beg - b0) / STREAM_SEG;
-    __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    const int seen = __hip_atomic_fetch_add(seg_count + rb0, 1, __ATOMIC_ACQ_REL,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-    if (seen == nseg - 1) {
-        double sum = 0.0;
-        for (int j = 0; j < nseg; ++j)
-            sum += __hip_atomic_load(seg_partial + rb0 + j, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-        y[row] = sum;
-        __hip_atomic_store(seg_count + rb0, 0, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_last && tid < WAVE) {
+        const int first = rb - (beg - irp[row]) / STREAM_SEG;
+        const double sum = wave_ordered_sum(seg_partial + first, s_last, lane);
+        if (lane == 0) {
+            y[row] = sum;
+            __hip_atomic_store(seg_count + first, 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

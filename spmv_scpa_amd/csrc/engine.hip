@@ -945,9 +945,14 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
             const int64_t w = rows > 0 ? (host_off[b + 1] - host_off[b]) / rows : 0;
             if (w <= HLL_WIDE)
                 continue;
-            const int nseg = (int)((w + HLL_WSEG - 1) / HLL_WSEG);
+            /* segments of HLL_WSEG columns, at most HLL_WSEG_MAX of them:
+             * wider ones then (multiples of 8 columns) */
+            int nseg = (int)std::min<int64_t>((w + HLL_WSEG - 1) / HLL_WSEG,
+                                              HLL_WSEG_MAX);
+            const int segw = (int)(((w + nseg - 1) / nseg + 7) / 8 * 8);
+            nseg = (int)((w + segw - 1) / segw);
             for (int k = 0; k < nseg; ++k)
-                seg.push_back(make_int4(b, k * HLL_WSEG, k, nseg));
+                seg.push_back(make_int4(b, segw, k, nseg));
         }
         d->n_wide_seg = (int)seg.size();
         if (!seg.empty()) {

@@ -69,7 +69,11 @@ static inline int hip_errno(hipError_t e) {
 /* hack blocks wider than HLL_WIDE columns go to k_hll_wide in segments of
  * HLL_WSEG columns (hll_kernels.hip) */
 #define HLL_WIDE 512
-#define HLL_WSEG 256
+#define HLL_WSEG 256      /* narrowest segment */
+#define HLL_WSEG_MAX 512  /* most segments per block: a hub block of 5 x 10^5
+                             columns is then cut into ~1000-column segments
+                             (the block's last segment adds up one partial
+                             sum per segment and row) */
 /* a row beyond STREAM_LONG_ROW entries is cut into segments of
  * STREAM_SEG entries, one workgroup each (one lane team walking a row of
  * 10^5 entries is the whole launch otherwise: dc1-class matrices) */
@@ -155,13 +159,32 @@ struct spmv_hll_dev {
      * wider than HLL_WIDE columns are skipped by kernels 0-3 and summed by a
      * second launch, one workgroup per segment of HLL_WSEG columns
      * (k_hll_wide; deterministic last-arriver reduction per block) */
-    int4 *wide_seg;    /* [n_wide_seg] (block, first column, segment, segments) */
+    int4 *wide_seg;    /* [n_wide_seg] (block, segment width, segment, segments) */
     int n_wide_seg;
     double *wide_part; /* [n_wide_seg * 32] partial row sums */
     int *wide_cnt;     /* [n_wide_seg] arrivals, at a block's first segment */
     double tune_ms[8];   /* last spmv_hll_autotune: best median per kernel id */
     char *tune_log;
 };
+
+#if defined(__HIPCC__)
+/* Sum part[0 .. n) in a FIXED order with one wavefront (all 64 lanes call):
+ * lane l adds part[l], part[l + 64], ... in index order, then a shuffle tree.
+ * The partial sums were written by other workgroups, on other XCDs: agent-
+ * scope atomic loads.  Total in lane 0.  (One lane adding 10^2..10^3 partials
+ * one dependent load at a time was a third of the hub matrices' launch.) */
+__device__ __forceinline__ double wave_ordered_sum(const double *part, int n,
+                                                   int lane) {
+    double s = 0.0;
+    for (int j = lane; j < n; j += WAVE)
+        s += __hip_atomic_load(part + j, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1)
+        s += __shfl_down(s, d, WAVE);
+    return s;
+}
+#endif
 
 /* clamp the launch knob: waves per workgroup */
 static inline int pick_waves(const spmv_launch_opts *o, int dflt) {

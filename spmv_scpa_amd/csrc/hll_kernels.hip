@@ -361,9 +361,9 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1, int wide,
 }
 
 /* ------------------------------------------------------------------ */
-/* wide hack blocks (> HLL_WIDE columns): workgroup g sums columns        */
-/* [j0, j0 + HLL_WSEG) of block b for all its rows, either layout; the     */
-/* block's last segment to arrive adds the partial row sums in segment     */
+/* wide hack blocks (> HLL_WIDE columns): workgroup g sums one segment of  */
+/* columns (seg.y wide) of block b for all its rows, either layout; the    */
+/* block's last segment to arrive adds the partial row sums in a fixed      */
 /* order (deterministic), writes y and re-arms the counter.                */
 /* ------------------------------------------------------------------ */
 __global__ void __launch_bounds__(256)
@@ -376,13 +376,13 @@ __global__ void __launch_bounds__(256)
     __shared__ int s_seen;
     const int g = blockIdx.x, tid = threadIdx.x;
     const int4 sg = seg[g];
-    const int b = sg.x, j0 = sg.y, kseg = sg.z, nseg = sg.w;
+    const int b = sg.x, segw = sg.y, kseg = sg.z, nseg = sg.w;
     if (b < b0 || b >= b1)
         return; /* another launch of a chunked exchange owns this block */
     const int rows = min(HACK, M - b * HACK);
     const int64_t o = off[b];
     const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
-    const int j1 = min(j0 + HLL_WSEG, w);
+    const int j0 = min(kseg * segw, w), j1 = min(j0 + segw, w);
     /* col-major: a wavefront reads two columns x 32 rows, each 256 B
      * contiguous; row-major: eight neighbouring columns of a row per 8 lanes */
     const int i = col_major ? (tid & 31) : (tid >> 3);
@@ -412,11 +412,23 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (s_seen != nseg - 1)
         return;
+    /* the block's last segment: 8 lanes per row add every 8th segment's
+     * partial, then the eight are added in lane order -- a fixed order */
+    {
+        const int r = tid & 31, c = tid >> 5;
+        double sum = 0.0;
+        for (int k = c; k < nseg; k += 8)
+            sum += __hip_atomic_load(part + (size_t)(g0 + k) * HACK + r,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads(); /* red[] of the column lanes is no longer needed */
+        red[c][r] = sum;
+    }
+    __syncthreads();
     if (tid < rows) {
         double sum = 0.0;
-        for (int k = 0; k < nseg; ++k)
-            sum += __hip_atomic_load(part + (size_t)(g0 + k) * HACK + tid,
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            sum += red[c][tid];
         y[(int64_t)b * HACK + tid] = sum;
     }
     if (tid == 0)

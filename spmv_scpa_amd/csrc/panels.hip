@@ -691,7 +691,7 @@ __global__ void k_long_copy_hll(int M, int col_major,
 
 /* the second launch: workgroup g sums segment g (entries [beg, end) of long
  * row seg[g].x); the last segment of a row to arrive adds the row's partial
- * sums in segment order and OVERWRITES y[row] (the tile kernels wrote 0) */
+ * sums in a fixed order and OVERWRITES y[row] (the tile kernels wrote 0) */
 __global__ void __launch_bounds__(256)
     k_long_rows(const int2 *__restrict__ seg, int nseg,
                 const int *__restrict__ long_row,
@@ -714,21 +714,26 @@ __global__ void __launch_bounds__(256)
     if ((tid & (WAVE - 1)) == 0)
         wsum[tid / WAVE] = acc;
     __syncthreads();
-    if (tid != 0)
-        return;
-    const double t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __shared__ int s_last;
     const int g0 = seg0[h];
-    const int n = (row_end - long_ptr[h] + PANELS_LONG_SEG - 1) / PANELS_LONG_SEG;
-    __hip_atomic_store(part + g, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int seen = __hip_atomic_fetch_add(cnt + h, 1, __ATOMIC_ACQ_REL,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-    if (seen == n - 1) {
-        double sum = 0.0;
-        for (int j = 0; j < n; ++j)
-            sum += __hip_atomic_load(part + g0 + j, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-        y[long_row[h]] = sum;
-        __hip_atomic_store(cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        const double t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const int n =
+            (row_end - long_ptr[h] + PANELS_LONG_SEG - 1) / PANELS_LONG_SEG;
+        __hip_atomic_store(part + g, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int seen = __hip_atomic_fetch_add(cnt + h, 1, __ATOMIC_ACQ_REL,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        s_last = seen == n - 1 ? n : 0;
+    }
+    __syncthreads();
+    if (s_last && tid < WAVE) { /* one wavefront adds the row's partial sums,
+                                   in a fixed order (hip_common.h) */
+        const double sum = wave_ordered_sum(part + g0, s_last, tid);
+        if (tid == 0) {
+            y[long_row[h]] = sum;
+            __hip_atomic_store(cnt + h, 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
