@@ -12,7 +12,9 @@
 
 #include "stream_table.h"
 
-static const int NNZ = 2048, ROWS = 1024, ROW_T = 48, LONG = 8192, SEG = 4096;
+// the kernel's constants (hip_common.h), handed over by the test as -D macros
+static const int NNZ = STREAM_NNZ, ROWS = STREAM_ROWS, ROW_T = STREAM_ROW_T,
+                 LONG = STREAM_LONG_ROW, SEG = STREAM_SEG;
 
 static uint64_t st;
 static uint64_t rnd(void) {

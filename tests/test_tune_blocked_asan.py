@@ -34,10 +34,19 @@ def test_stream_table_invariants_under_asan(tmp_path):
     one range, every row written exactly once, segment arithmetic as the
     kernel restates it"""
     exe = str(tmp_path / "stream_table_asan")
+    # the budgets the kernel is compiled with (hip_common.h)
+    import re
+    hdr = open(os.path.join(ROOT, "spmv_scpa_amd", "csrc", "hip_common.h")).read()
+    defs = []
+    for name in ("STREAM_NNZ", "STREAM_ROWS", "STREAM_ROW_T", "STREAM_LONG_ROW",
+                 "STREAM_SEG"):
+        m = re.search(r"#define\s+%s\s+(\d+)" % name, hdr)
+        assert m, name
+        defs.append("-D%s=%s" % (name, m.group(1)))
     subprocess.run(
         ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined",
-         "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
-         "-I", os.path.join(ROOT, "spmv_scpa_amd", "csrc"),
+         "-fno-omit-frame-pointer", "-fno-sanitize-recover=all"] + defs +
+        ["-I", os.path.join(ROOT, "spmv_scpa_amd", "csrc"),
          os.path.join(ROOT, "tests", "asan", "stream_table_asan.cc"),
          "-o", exe], check=True)
     r = subprocess.run([exe, "600"], capture_output=True, text=True)
