@@ -66,3 +66,28 @@ def test_product_driver_full_grid_on_gpu(tmp_path):
     for line in roof[1:]:
         f = line.split(",")
         assert float(f[-4]) > 0 and 0 < float(f[-1]) < 1.0
+
+
+@pytest.mark.parametrize("family,rows,k,window", [
+    ("hub", 200_000, 6, 512),         # dc1 class: a row of 131 072 entries
+    ("powerlaw", 300_000, 3, 0),      # webbase / amazon / roadNet class
+])
+def test_product_driver_on_the_irregular_classes(family, rows, k, window,
+                                                 tmp_path):
+    """the 27-row one-shot grid (every seam kernel called by name, -d
+    validation against serial CSR like the reference's driver) on the matrix
+    classes where a kernel used to walk a hub row with one lane: every call
+    must validate, and none may take the milliseconds it used to"""
+    out = str(tmp_path)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    r = subprocess.run([PRODUCT_DRIVER, "-s", family, "--rows", str(rows),
+                        "--nnz-row", str(k), "--window", str(window),
+                        "-o", out, "-d", "--iters", "3", "--no-cpu"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    gpu = open(os.path.join(out, "cuda.csv")).read().splitlines()
+    assert len(gpu) == 1 + 27
+    worst = max(float(line.split(",")[-2]) for line in gpu[1:])
+    # one-shot launches, cold: the hub row alone cost 6-16 ms per call before
+    # the long-row / wide-block launches (DESIGN.md section 8)
+    assert worst < 3.0, (worst, gpu)
