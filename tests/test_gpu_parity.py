@@ -942,3 +942,54 @@ def test_config3_ragged_variant_full_size():
     assert np.max(np.abs(ys["hll1"] - ys["auto"])) < 1e-11
     dH.release()
     dA.release()
+
+
+def test_arrival_counter_kernels_soak():
+    """The last-arriver reductions (CSR long rows: k_csr_stream mode 2 and
+    k_csr_long_seg; wide HLL blocks: k_hll_wide; rows beside the blocked copy:
+    k_long_rows) rely on agent-scope atomics across XCDs and on counters that
+    each launch re-arms.  Hundreds of back-to-back launches (SPMV_SOAK=5000
+    for a long run), every result compared with the first one BIT FOR BIT for
+    the deterministic kernels, and the long rows' entries of the blocked path
+    likewise: a lost partial sum, a stale read or a counter left armed shows
+    up as a different bit sooner or later."""
+    import os
+    n_rep = int(os.environ.get("SPMV_SOAK", "300"))
+    M = N = 400_000
+    dA = S.CsrDevice.generate(S.SYNTH_HUB, M, N, 4, 1 << 30, 0, 42)
+    dH = dA.to_hll(True)
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    hub = N // 3
+    IRP, JA, AS = S.csr_arrays(dA.download())
+    x = O.synth_x(7, 0, N)
+    want = float(np.dot(AS[IRP[hub]:IRP[hub + 1]], x[JA[IRP[hub]:IRP[hub + 1]]]))
+    scale = float(np.sum(np.abs(AS[IRP[hub]:IRP[hub + 1]]
+                                * x[JA[IRP[hub]:IRP[hub + 1]]])))
+    assert IRP[hub + 1] - IRP[hub] == 131_072
+    dA.build_panels(0, "chain")
+    cases = [("csr stream", dA, 4), ("csr subwave + long seg", dA, 2),
+             ("hll col + wide", dH, 1), ("blocked + long rows", dA,
+                                         S.CSR_KERNEL_PANELS)]
+    try:
+        for tag, m, k in cases:
+            first = None
+            for rep in range(n_rep):
+                if rep % 50 == 0:  # poison now and then: y must be rewritten
+                    S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                m.launch(k, d_x.ptr, d_y.ptr)
+                if rep % 10 and rep != n_rep - 1:
+                    continue  # back-to-back launches in between
+                S.stream_sync()
+                y = d_y.to_numpy(np.float64, M)
+                assert abs(y[hub] - want) <= 1e-12 * scale, (tag, rep)
+                if first is None:
+                    first = y
+                elif k == S.CSR_KERNEL_PANELS:
+                    assert y[hub] == first[hub], (tag, rep)  # fixed order
+                    assert np.max(np.abs(y - first)) <= 1e-12 * scale
+                else:
+                    assert np.array_equal(y, first), (tag, rep)
+    finally:
+        dH.release()
+        dA.release()
