@@ -367,6 +367,35 @@ def kernel_source_blob(kname):
     return fn, hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
+def _git_blob(path):
+    import hashlib
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def kernel_source_ident(kname):
+    """what a profile must agree with to describe this build: the blob ids
+    of the kernel's source file AND of hip_common.h (segment sizes, budgets
+    and the device helpers the kernels inline live there)"""
+    fn, blob = kernel_source_blob(kname)
+    return {"file": fn, "blob": blob, "common_file": "hip_common.h",
+            "common_blob": _git_blob(os.path.join(ROOT, "spmv_scpa_amd", "csrc",
+                                                  "hip_common.h"))}
+
+
+def same_build(ks, kname):
+    """does the `kernel_source` record of a committed profile name the tree's
+    sources?  (records without the common header's blob predate the rule)"""
+    me = kernel_source_ident(kname)
+    ks = ks or {}
+    return bool(me["blob"] and me["common_blob"]
+                and ks.get("blob") == me["blob"]
+                and ks.get("common_blob") == me["common_blob"])
+
+
 def measured_traffic(workload, kname):
     """-> (traffic dict or None, why-not or None).  HBM-side bytes per launch
     of the dominant kernel from the committed rocprofv3 PMC passes
@@ -387,10 +416,11 @@ def measured_traffic(workload, kname):
         if t.get("workload") != workload or t.get("bench_kernel") != kname:
             continue
         ks = t.get("kernel_source") or {}
-        if not blob or ks.get("blob") != blob:
-            why = ("profiles/%s was taken with another build of %s (blob %s, "
-                   "tree %s)" % (os.path.basename(fn), fn_src,
-                                 str(ks.get("blob"))[:12], str(blob)[:12]))
+        if not same_build(ks, kname):
+            why = ("profiles/%s was taken with another build of %s / "
+                   "hip_common.h (blob %s, tree %s)"
+                   % (os.path.basename(fn), fn_src,
+                      str(ks.get("blob"))[:12], str(blob)[:12]))
             continue
         best, why = t, None
     return best, why
@@ -458,7 +488,7 @@ def measured_l2_requests(workload, kname):
             continue
         if t.get("workload") != workload or t.get("bench_kernel") != kname:
             continue
-        if not blob or (t.get("kernel_source") or {}).get("blob") != blob:
+        if not same_build(t.get("kernel_source"), kname):
             why = ("profiles/%s was taken with another build of %s"
                    % (os.path.basename(fn), fn_src))
             continue
@@ -513,7 +543,7 @@ def window_variants(S, torch, x, y, Mloc, Nglob, K, fmt_family):
             kname = "hll_" + S.HLL_KERNEL_LABELS[best]
             wl = workload_name("random", "hll", Mloc, Nglob, Mloc, K, W, W)
             tr, _ = measured_traffic(wl, kname)
-            b = dH.algorithmic_bytes
+            b = dH.kernel_bytes(best)
             out[tag] = {
                 "kernel": kname,
                 "layout": dH.panels_describe()
@@ -783,8 +813,7 @@ def single_matrix_bench(args, S, torch, dev):
                         if kernel == S.CSR_KERNEL_PANELS else None,
                         "blocked_layout": dA.panels_describe()
                         if kernel == S.CSR_KERNEL_PANELS else None,
-                        "kernel_source": dict(zip(("file", "blob"),
-                                                  kernel_source_blob(kname))),
+                        "kernel_source": kernel_source_ident(kname),
                         "rows": M, "nnz": NZ}, **info),
         "roofline": roofline_dict(alg, kern_ms, kname, NZ,
                                   *measured_traffic(workload, kname)),
@@ -1172,8 +1201,10 @@ def main(argv=None):
             arrangement = "sweep: overlapped arrangement not built (%s)" % e
     pinfo = mat.panels_info() if blocked else None
     launches_per_step = (pinfo["steps"] if pinfo else 1) * L
-    # per step and GPU; one launch per logical shard
-    alg_bytes = sum(m.algorithmic_bytes for m in mats)
+    # per step and GPU; one launch per logical shard.  Priced
+    # for the kernel that runs: the blocked copy of an HLL handle stores no
+    # padding (spmv_hll_kernel_bytes); same number when the format pads nothing
+    alg_bytes = sum(m.kernel_bytes(kernel) for m in mats)
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -1347,8 +1378,7 @@ def main(argv=None):
             and arrangement is None else None,
             "blocked_schedule": mat.panels_schedule() if blocked else None,
             "blocked_layout": mat.panels_describe() if blocked else None,
-            "kernel_source": dict(zip(("file", "blob"),
-                                      kernel_source_blob(kname))),
+            "kernel_source": kernel_source_ident(kname),
             "kernel_launches_per_step": launches_per_step,
             "rows_per_gpu": Mloc, "logical_shards_per_gpu": L,
             "nnz_per_row": K, "nnz_global": nnz_global,
@@ -1514,6 +1544,9 @@ def native_mgpu_bench(args, argv, omp_team):
     exch = g.exchange_only(10) if n > 1 else None
     ngp, _, nnz_global, alg_bytes = g.info()
     stored, _, layout = g.shard_info(0)
+    if args.format == "hll" and kernel == S.HLL_KERNEL_PANELS:
+        # the blocked copy stores the true entries, not the padded slots
+        alg_bytes -= 12 * (stored - nnz_global // n)
     ms_per_step = wall_ms / args.steps
     workload = workload_name(args.family, args.format, Mloc, Nglob, Mglob, K,
                              args.window, W)
@@ -1540,8 +1573,7 @@ def native_mgpu_bench(args, argv, omp_team):
             else "fixed by --kernel",
             "tune_s": round(t_tune, 2) if t_tune is not None else None,
             "blocked_layout": layout or None,
-            "kernel_source": dict(zip(("file", "blob"),
-                                      kernel_source_blob(kname))),
+            "kernel_source": kernel_source_ident(kname),
             "kernel_launches_per_step": 1,
             "rows_per_gpu": Mloc, "logical_shards_per_gpu": 1,
             "nnz_per_row": K, "nnz_global": nnz_global,
@@ -1589,9 +1621,9 @@ def strong_one_gpu():
             ks = j["config"].get("kernel_source") or {}
             if j["scaling"] != "strong" or j["n_gpus"] != 1:
                 continue
-            if ks.get("blob") != blob:
+            if not same_build(ks, "hll_tile_panels"):
                 why = ("profiles/%s was measured with another build of "
-                       "panels.hip" % os.path.basename(fn))
+                       "panels.hip / hip_common.h" % os.path.basename(fn))
                 continue
             return float(j["ms_per_step"]), "profiles/" + os.path.basename(fn)
         except (ValueError, KeyError, OSError):

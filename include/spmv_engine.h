@@ -261,6 +261,11 @@ int spmv_hll_release_source(spmv_hll_dev *H);
 int spmv_hll_shape(const spmv_hll_dev *H, int *M, int *N, int64_t *NZ,
                    int *num_blocks, int64_t *slots, int *is_col_major);
 int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H);
+/* bytes one launch of `kernel` must move: spmv_hll_algorithmic_bytes (12 per
+ * STORED slot) for the direct kernels; for SPMV_HLL_KERNEL_PANELS, whose
+ * copy stores no padding, 12 per true entry (+ 12 nb + 8 M + 8 N as before).
+ * Equal when the format pads nothing (the headline matrix). */
+int64_t spmv_hll_kernel_bytes(const spmv_hll_dev *H, int kernel);
 void spmv_hll_release(spmv_hll_dev *H);
 
 /*

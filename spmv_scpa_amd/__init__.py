@@ -322,6 +322,7 @@ _sig("spmv_hll_launch_blocks", C.c_int, C.c_void_p, C.c_int,
 _sig("spmv_hll_shape", C.c_int, C.c_void_p, _ip, _ip, C.POINTER(C.c_int64),
      _ip, C.POINTER(C.c_int64), _ip)
 _sig("spmv_hll_algorithmic_bytes", C.c_int64, C.c_void_p)
+_sig("spmv_hll_kernel_bytes", C.c_int64, C.c_void_p, C.c_int)
 _sig("spmv_hll_release", None, C.c_void_p)
 _sig("spmv_csr_time", C.c_int, C.c_void_p, C.c_int, C.POINTER(LaunchOpts),
      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, _dp, C.c_void_p)
@@ -830,6 +831,10 @@ class CsrDevice:
     def algorithmic_bytes(self):
         return _lib.spmv_csr_algorithmic_bytes(self.h)
 
+    def kernel_bytes(self, kernel):
+        """CSR stores no padding: every kernel is priced on the same bytes"""
+        return self.algorithmic_bytes
+
     def launch(self, kernel, d_x, d_y, waves_per_block=0, group=0,
                stream=None, rows=None, variant=0):
         o = _opts(waves_per_block, group, variant)
@@ -1038,6 +1043,11 @@ class HllDevice:
     @property
     def algorithmic_bytes(self):
         return _lib.spmv_hll_algorithmic_bytes(self.h)
+
+    def kernel_bytes(self, kernel):
+        """bytes one launch of `kernel` must move: 12 per STORED slot for the
+        direct kernels, 12 per true entry for the blocked copy (no padding)"""
+        return _lib.spmv_hll_kernel_bytes(self.h, kernel)
 
     def launch(self, kernel, d_x, d_y, waves_per_block=0, stream=None,
                blocks=None, variant=0):

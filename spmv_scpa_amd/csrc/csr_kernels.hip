@@ -79,13 +79,11 @@ __global__ void k_csr_thread_row(int r0, int r1, int lrow,
     int row = r0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= r1)
         return;
-    double acc = 0.0;
     const int b = irp[row], e = irp[row + 1];
     if (lrow > 0 && e - b > lrow)
         return;
-    for (int k = b; k < e; ++k)
-        acc += ld_stream(as + k) * x[ld_stream(ja + k)];
-    y[row] = acc;
+    /* the row's entries in order, four loads in flight (hip_common.h) */
+    y[row] = strided_dot<1, 4>(ja, as, x, b, e, 0);
 }
 
 /* ------------------------------------------------------------------ */
@@ -101,12 +99,10 @@ __global__ void k_csr_wave_row(int r0, int r1, int lrow,
     const int row = r0 + blockIdx.x * waves + wave; /* wave-uniform */
     if (row >= r1)
         return;
-    double acc = 0.0;
     const int beg = irp[row], end = irp[row + 1];
     if (lrow > 0 && end - beg > lrow)
         return; /* wave-uniform: the whole wavefront leaves */
-    for (int k = beg + lane; k < end; k += WAVE)
-        acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+    double acc = strided_dot<WAVE, 4>(ja, as, x, beg, end, lane);
     acc = group_sum<WAVE>(acc);
     if (lane == 0)
         y[row] = acc;
@@ -346,9 +342,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
          * longer one (mode 2: entries [beg, end) of row row_a, cut at
          * multiples of STREAM_SEG): every lane strides the entries,
          * block-wide reduction */
-        double acc = 0.0;
-        for (int k = beg + tid; k < end; k += STREAM_THREADS)
-            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+        double acc = strided_dot<STREAM_THREADS, 8>(ja, as, x, beg, end, tid);
         acc = group_sum<WAVE>(acc);
         if (lane == 0)
             part[tid / WAVE] = acc;
@@ -507,7 +501,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
 /*
  * The long rows of kernels 0-3: workgroup g sums range long_rb[g] of the
  * stream kernel's table -- one whole row of 2049 .. STREAM_LONG_ROW entries,
- * or (mode 2) one 4096-entry segment of a longer row -- exactly as
+ * or (mode 2) one STREAM_SEG-entry segment of a longer row -- exactly as
  * k_csr_stream does (same strides, same partial sums, arrival counters and
  * summation order: the two kernels give the same bits for such a row).  Even
  * 2048 entries are 512 dependent steps for a 4-lane team (0.25 ms) -- the
@@ -529,9 +523,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     const int row = t_a.x, beg = t_a.y, end = t_z.y;
     if (row < r0 || row >= r1)
         return;
-    double acc = 0.0;
-    for (int k = beg + tid; k < end; k += STREAM_THREADS)
-        acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+    double acc = strided_dot<STREAM_THREADS, 8>(ja, as, x, beg, end, tid);
     acc = group_sum<WAVE>(acc);
     if (lane == 0)
         part[tid / WAVE] = acc;

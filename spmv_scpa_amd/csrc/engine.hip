@@ -1096,6 +1096,18 @@ int64_t spmv_hll_algorithmic_bytes(const spmv_hll_dev *H) {
            8 * (int64_t)H->N;
 }
 
+/* what ONE launch of `kernel` has to move at least: the direct kernels read
+ * every stored slot, padding included (12 S); the blocked copy (kernel 4)
+ * holds the true entries only, so it is priced on NZ -- else a padded matrix
+ * (S = 10 NZ on a power-law one) would show the blocked kernel above 100 % */
+int64_t spmv_hll_kernel_bytes(const spmv_hll_dev *H, int kernel) {
+    HANDLE_OK(H);
+    if (kernel != SPMV_HLL_KERNEL_PANELS)
+        return spmv_hll_algorithmic_bytes(H);
+    return 12 * H->NZ + 12 * (int64_t)H->nb + 8 * (int64_t)H->M +
+           8 * (int64_t)H->N;
+}
+
 int spmv_hll_launch_blocks(const spmv_hll_dev *H, int kernel,
                            const spmv_launch_opts *opts, const double *d_x,
                            double *d_y, int blk_begin, int blk_end,

@@ -69,16 +69,22 @@ static inline int hip_errno(hipError_t e) {
 /* hack blocks wider than HLL_WIDE columns go to k_hll_wide in segments of
  * HLL_WSEG columns (hll_kernels.hip) */
 #define HLL_WIDE 512
+#ifndef HLL_WSEG
 #define HLL_WSEG 256      /* narrowest segment */
+#endif
+#ifndef HLL_WSEG_MAX
 #define HLL_WSEG_MAX 512  /* most segments per block: a hub block of 5 x 10^5
                              columns is then cut into ~1000-column segments
                              (the block's last segment adds up one partial
                              sum per segment and row) */
+#endif
 /* a row beyond STREAM_LONG_ROW entries is cut into segments of
  * STREAM_SEG entries, one workgroup each (one lane team walking a row of
  * 10^5 entries is the whole launch otherwise: dc1-class matrices) */
 #define STREAM_LONG_ROW 8192
-#define STREAM_SEG 4096
+#ifndef STREAM_SEG
+#define STREAM_SEG 2048
+#endif
 
 struct spmv_panels; /* panels.hip */
 
@@ -183,6 +189,54 @@ __device__ __forceinline__ double wave_ordered_sum(const double *part, int n,
     for (int d = WAVE / 2; d > 0; d >>= 1)
         s += __shfl_down(s, d, WAVE);
     return s;
+}
+
+/* Thread `tid` of NT sums as[k] * x[ja[k]] over k = beg + tid, + NT, ... < end
+ * in THAT order (one accumulator: the bits do not depend on U), with the loads
+ * of U entries in flight at a time.  The plain loop is two dependent memory
+ * round trips per entry -- 4 us per 8 entries on a busy chip -- and a long
+ * row's segment is 4-32 entries per thread: the side launches of the long
+ * rows were latency, not bandwidth.  Entries stream past (non-temporal). */
+template <int NT, int U>
+__device__ __forceinline__ double strided_dot(const int *__restrict__ ja,
+                                              const double *__restrict__ as,
+                                              const double *__restrict__ x,
+                                              int beg, int end, int tid) {
+    double acc = 0.0;
+    int k = beg + tid;
+    for (; k + (U - 1) * NT < end; k += U * NT) {
+        int c[U];
+        double v[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c[u] = __builtin_nontemporal_load(ja + k + u * NT);
+            v[u] = __builtin_nontemporal_load(as + k + u * NT);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc += v[u] * xv[u];
+    }
+    if (k < end) { /* fewer than U left: one predicated batch */
+        int c[U];
+        double v[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool on = k + u * NT < end;
+            c[u] = on ? __builtin_nontemporal_load(ja + k + u * NT) : -1;
+            v[u] = on ? __builtin_nontemporal_load(as + k + u * NT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c[u] >= 0)
+                acc += v[u] * xv[u];
+    }
+    return acc;
 }
 #endif
 

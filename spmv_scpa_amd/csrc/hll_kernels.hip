@@ -104,10 +104,8 @@ __global__ void k_hll_row_major(int M, int b0, int b1, int wide,
         return;
     const int *rj = ja + o + (int64_t)i * w;
     const double *ra = as + o + (int64_t)i * w;
-    double acc = 0.0;
-    for (int j = 0; j < w; ++j)
-        acc += ld_stream(ra + j) * x[ld_stream(rj + j)];
-    y[(int64_t)b * HACK + i] = acc;
+    /* the row's slots in order, four loads in flight (hip_common.h) */
+    y[(int64_t)b * HACK + i] = strided_dot<1, 4>(rj, ra, x, 0, w, 0);
 }
 
 /* ------------------------------------------------------------------ */
@@ -349,8 +347,8 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1, int wide,
             live = !(wide > 0 && w > wide);
             const int *rj = ja + o + (int64_t)i * w;
             const double *ra = as + o + (int64_t)i * w;
-            for (int j = sub; live && j < w; j += 16)
-                acc += ld_stream(ra + j) * x[ld_stream(rj + j)];
+            if (live)
+                acc = strided_dot<16, 4>(rj, ra, x, 0, w, sub);
         }
     }
 #pragma unroll
@@ -388,12 +386,35 @@ __global__ void __launch_bounds__(256)
     const int i = col_major ? (tid & 31) : (tid >> 3);
     const int cl = col_major ? (tid >> 5) : (tid & 7);
     double acc = 0.0;
-    if (i < rows)
-        for (int j = j0 + cl; j < j1; j += 8) {
-            const int64_t t = o + (col_major ? (int64_t)j * rows + i
-                                             : (int64_t)i * w + j);
+    if (i < rows) {
+        /* slot of column j of row i; the lane's columns are j0 + cl, + 8, ...
+         * Four of them in flight at a time, added in column order (one
+         * accumulator): one at a time is two dependent memory round trips
+         * per slot, 32 times over -- the launch was latency, not bandwidth */
+        const int64_t base = o + (col_major ? i : (int64_t)i * w);
+        const int64_t step = col_major ? rows : 1;
+        int j = j0 + cl;
+        for (; j + 24 < j1; j += 32) {
+            int c[4];
+            double v[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t t = base + (int64_t)(j + 8 * u) * step;
+                c[u] = ld_stream(ja + t);
+                v[u] = ld_stream(as + t);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc += v[u] * xv[u];
+        }
+        for (; j < j1; j += 8) {
+            const int64_t t = base + (int64_t)j * step;
             acc += ld_stream(as + t) * x[ld_stream(ja + t)];
         }
+    }
     red[cl][i] = acc;
     __syncthreads();
     if (tid < HACK) {

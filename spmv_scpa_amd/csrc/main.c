@@ -262,7 +262,7 @@ static void run_gpu(void) {
             if (best == SPMV_HLL_KERNEL_PANELS)
                 log_roofline(A->name, "HLL", best, 8, 1, A->M, A->N, A->NZ,
                              hll_num_slots(H_col),
-                             spmv_hll_algorithmic_bytes(dHc), best_ms);
+                             spmv_hll_kernel_bytes(dHc, best), best_ms);
         }
     }
     spmv_hll_release(dHc);

@@ -144,7 +144,9 @@ struct spmv_panels {
  * one row of 8291 entries: 0.043 ms inside, 0.052 beside; a row of 30 000+
  * entries is worth the launch (4M rows: 0.155 -> 0.127 ms) */
 #define PANELS_LONG_ROW 16384
-#define PANELS_LONG_SEG 4096
+#ifndef PANELS_LONG_SEG
+#define PANELS_LONG_SEG 1024
+#endif
 #define PANELS_LONG_MAX 4096 /* more such rows than this: keep them inside */
 
 static void big_free(void *p); /* block pool of a selector run, below */
@@ -704,10 +706,7 @@ __global__ void __launch_bounds__(256)
     const int h = seg[g].x, beg = seg[g].y;
     const int row_end = long_ptr[h + 1];
     const int end = min(beg + PANELS_LONG_SEG, row_end);
-    double acc = 0.0;
-    for (int k = beg + tid; k < end; k += 256)
-        acc += __builtin_nontemporal_load(las + k) *
-               x[__builtin_nontemporal_load(lja + k)];
+    double acc = strided_dot<256, 4>(lja, las, x, beg, end, tid);
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1)
         acc += __shfl_down(acc, d, WAVE);

@@ -133,6 +133,7 @@ def test_release_is_idempotent_and_counted():
     o = S._panel_opts()
     for rc in (S._lib.spmv_hll_shape(raw, None, None, None, None, None, None),
                S._lib.spmv_hll_algorithmic_bytes(raw),
+               S._lib.spmv_hll_kernel_bytes(raw, 4),
                S._lib.spmv_hll_build_panels(raw, 0),
                S._lib.spmv_hll_build_panels_opts(raw, C.byref(o)),
                S._lib.spmv_hll_build_panels_as(raw, 0, 2, 0),

@@ -913,6 +913,12 @@ def test_config3_ragged_variant_full_size():
     dH = dA.to_hll(True)
     assert dH.slots > dA.NZ  # pads are stored (and are real traffic)
     assert dH.algorithmic_bytes > 12 * dA.NZ
+    # the direct kernels are priced on the stored slots, the blocked copy
+    # (no padding) on the true entries
+    assert dH.kernel_bytes(1) == dH.algorithmic_bytes
+    assert dH.kernel_bytes(S.HLL_KERNEL_PANELS) == (
+        12 * dA.NZ + 12 * dH.num_blocks + 8 * M + 8 * N)
+    assert dA.kernel_bytes(S.CSR_KERNEL_PANELS) == dA.algorithmic_bytes
     d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
     S.dev_fill_synth(d_x.ptr, N, 7)
     rng = np.random.default_rng(6)

@@ -100,7 +100,9 @@ def test_selector_on_the_reference_s_irregular_classes(kind, M, K, W):
         assert t[4] > 0 and t[2] > 0          # always candidates
         if dA.NZ / dA.M < 6:
             assert t[0] > 0, t                # thread_row was measured ...
-            assert ms < 0.2 * t[0], (ms, t)   # ... and lost by > 5x
+            # ... and lost by > 2x (3.5-6x measured, with four loads in flight
+            # per lane; 9-15x with one)
+            assert ms < 0.5 * t[0], (ms, t)
         if kind == S.SYNTH_HUB:
             assert t[3] > 0, t                # block_row measured, and lost
             assert ms < 0.5 * t[3], (ms, t)

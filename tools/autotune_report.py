@@ -87,7 +87,7 @@ def main():
             tune = time.time() - t0
             flush = (1 << 30) if m.algorithmic_bytes < (512 << 20) else 0
             ms = float(np.median(m.time(best, d_x.ptr, d_y.ptr, 3, 20, flush)))
-            b = m.algorithmic_bytes
+            b = m.kernel_bytes(best)  # blocked copy of an HLL handle: true entries
             lines.append("%-24s | %s | %-22s | %8.4f | %7.1f | %5.1f | %4.1f | %s"
                          % (label, fmt, labels[best], ms,
                             2 * m.NZ / ms / 1e6, 100 * b / ms / 1e6 / 8000,

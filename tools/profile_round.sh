@@ -29,6 +29,10 @@ prof w17 --window 131072
 prof c2_banded1M_csr --config 2
 prof c4_kkt_csr --config 4
 prof banded10M_hll --family banded --kernel 1
+# the reference's irregular classes (download-matrices.py: webbase / amazon /
+# roadNet; dc1), autotuned pick of an HLL handle = the blocked copy
+prof powerlaw4M --family powerlaw --rows-per-gpu 4000000 --nnz-row 3
+prof hub1M --family hub --rows-per-gpu 1000000 --nnz-row 6 --window 4096
 fi
 if [ "$part" = "passes" ]; then
     mkdir -p gpurun_out/profiles_${round} && cp -f profiles/${round}_* gpurun_out/profiles_${round}/
@@ -40,6 +44,17 @@ step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_l2req" \
     "profiles/${round}_wn.l2req.json" > /dev/null
 step tools/pmc.sh "${round}_tcc" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
     bench.py --no-extras --no-cpu-baseline --steps 20
+# the same request counters for the power-law matrix (what bounds 22 %) ...
+step tools/pmc.sh "${round}_pl_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
+    bench.py --no-extras --no-cpu-baseline --steps 20 --family powerlaw --rows-per-gpu 4000000 --nnz-row 3
+step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_pl_l2req" \
+    "profiles/${round}_powerlaw4M.l2req.json" > /dev/null
+# ... and for one rank's shard of config 5 (10M x 80M; profiles/<round>_config5_shard.counters.json)
+SH="tools/sweep.py --rows 10000000 --cols 80000000 --k 32 --windows 0 --hll-kernels 4 --csr-kernels= --iters 10"
+step tools/pmc.sh "${round}_sh_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" $SH
+step tools/pmc.sh "${round}_sh_tcc" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" $SH
+step tools/pmc.sh "${round}_sh_fetch" "FETCH_SIZE" $SH
+step python3 tools/shard_counters.py "$round" > /dev/null
 # un-profiled lines of the round
 python3 bench.py --strong --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline \
     > "profiles/${round}_strong_1gpu.json" 2> gpurun_out/${round}_strong.err || { echo "FAILED strong"; exit 1; }

@@ -97,7 +97,7 @@ def main():
                 if fmt == "csr" and k == 2:
                     kw["group"] = g
                 ms = float(np.median(m.time(k, d_x.ptr, d_y.ptr, **kw)))
-                b = m.algorithmic_bytes
+                b = m.kernel_bytes(k)
                 r = dict(family=a.family, W=W, fmt=fmt, kernel=k, waves=w,
                          group=g, variant=v, ms=round(ms, 4),
                          gflops=round(2 * m.NZ / ms / 1e6, 1),
