@@ -126,6 +126,12 @@ def parse_args(argv=None):
     ap.add_argument("--kernel", type=int, default=-1,
                     help="kernel id (hip_hll.h / hip_csr.h); -1 = autotuned")
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--blocked-pin", default="",
+                    help="run the 2-D blocked kernel on exactly this layout "
+                         "(the `config.blocked_pin` string of an earlier "
+                         "line) instead of asking the selector: the counter "
+                         "passes of tools/profile.sh measure the layout the "
+                         "un-profiled run picked")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N>1: split each shard into row chunks and overlap "
                          "the all-gather of chunk c with the kernel of c+1 "
@@ -396,7 +402,7 @@ def same_build(ks, kname):
                 and ks.get("common_blob") == me["common_blob"])
 
 
-def measured_traffic(workload, kname):
+def measured_traffic(workload, kname, schedule=None):
     """-> (traffic dict or None, why-not or None).  HBM-side bytes per launch
     of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*.traffic.json, written by tools/summarize_profile.py from
@@ -414,6 +420,12 @@ def measured_traffic(workload, kname):
         except ValueError:
             continue
         if t.get("workload") != workload or t.get("bench_kernel") != kname:
+            continue
+        if (schedule and t.get("blocked_schedule")
+                and t["blocked_schedule"] != schedule):
+            why = ("profiles/%s describes the %s schedule of the blocked "
+                   "kernel, this run the %s one"
+                   % (os.path.basename(fn), t["blocked_schedule"], schedule))
             continue
         ks = t.get("kernel_source") or {}
         if not same_build(ks, kname):
@@ -452,6 +464,9 @@ def roofline_dict(alg_bytes, kern_ms, kname, nnz, traffic, why=None):
                            + " (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, "
                            "separate passes; same kernel source blob)")
         if traffic else why,
+        # the blocked layout the counters were taken on (the selector runs
+        # again in every pass: compare with config.blocked_layout)
+        "traffic_layout": traffic.get("blocked_layout") if traffic else None,
         "kernel": kname, "algorithmic_bytes_per_launch": alg_bytes,
         "kernel_ms_avg": round(kavg, 5),
         "kernel_ms_min": round(float(np.min(kern_ms)), 5),
@@ -473,7 +488,7 @@ TCP_SLOTS = 107  # outstanding line requests a CU's vector L1 tracks (r02)
 NUM_CUS = 256
 
 
-def measured_l2_requests(workload, kname):
+def measured_l2_requests(workload, kname, schedule=None):
     """-> (profile dict or None, why-not): committed *.l2req.json of the same
     workload, kernel and kernel-source blob (same staleness rule as
     measured_traffic)"""
@@ -488,6 +503,13 @@ def measured_l2_requests(workload, kname):
             continue
         if t.get("workload") != workload or t.get("bench_kernel") != kname:
             continue
+        sched = t.get("blocked_schedule") or next(
+            (w for w in ("sweep", "chain", "steps")
+             if str(t.get("blocked_layout") or "").startswith(w)), None)
+        if schedule and sched and sched != schedule:
+            why = ("profiles/%s describes the %s schedule, this run the %s one"
+                   % (os.path.basename(fn), sched, schedule))
+            continue
         if not same_build(t.get("kernel_source"), kname):
             why = ("profiles/%s was taken with another build of %s"
                    % (os.path.basename(fn), fn_src))
@@ -496,12 +518,12 @@ def measured_l2_requests(workload, kname):
     return None, why
 
 
-def secondary_roofline(workload, kname, kavg_ms):
+def secondary_roofline(workload, kname, kavg_ms, schedule=None):
     """bound "l2_line_requests" (what the blocked sweep kernel on W = N is
     held by): measured CU->L2 line requests per launch against the L2s' peak
     acceptance rate, and the floor the per-CU outstanding-request capacity
     sets at the measured mean latency (Little's law)"""
-    prof, why = measured_l2_requests(workload, kname)
+    prof, why = measured_l2_requests(workload, kname, schedule)
     if not prof:
         return {"bound": "l2_line_requests", "frac": None, "source": why}
     reqs = float(prof["requests_per_launch"])
@@ -542,7 +564,9 @@ def window_variants(S, torch, x, y, Mloc, Nglob, K, fmt_family):
                          stream=st)
             kname = "hll_" + S.HLL_KERNEL_LABELS[best]
             wl = workload_name("random", "hll", Mloc, Nglob, Mloc, K, W, W)
-            tr, _ = measured_traffic(wl, kname)
+            tr, _ = measured_traffic(
+                wl, kname, dH.panels_schedule()
+                if best == S.HLL_KERNEL_PANELS else None)
             b = dH.kernel_bytes(best)
             out[tag] = {
                 "kernel": kname,
@@ -747,7 +771,10 @@ def single_matrix_bench(args, S, torch, dev):
                     "config 2), 1 GiB read-only flush between launches")
     y = torch.zeros(M, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-    if args.kernel >= 0:
+    if args.blocked_pin:  # the layout an earlier line printed (profiling)
+        kernel, tuned = S.CSR_KERNEL_PANELS, None
+        dA.build_panels_pinned(args.blocked_pin)
+    elif args.kernel >= 0:
         kernel, tuned = args.kernel, None
         if kernel == S.CSR_KERNEL_PANELS:  # fixed: default chain layout (the
             dA.build_panels(0, "chain")    # SPMV_TILE_ROWS knob applies)
@@ -808,15 +835,22 @@ def single_matrix_bench(args, S, torch, dev):
         info.get("source", "") else "file",
         "config": dict({"workload": workload, "kernel": kname,
                         "kernel_choice": "autotuned (spmv_csr_autotune)"
-                        if tuned is not None else "fixed by --kernel",
+                        if tuned is not None else
+                        "pinned layout (--blocked-pin)" if args.blocked_pin
+                        else "fixed by --kernel",
                         "blocked_schedule": dA.panels_schedule()
                         if kernel == S.CSR_KERNEL_PANELS else None,
                         "blocked_layout": dA.panels_describe()
                         if kernel == S.CSR_KERNEL_PANELS else None,
+                        "blocked_pin": dA.panels_pin()
+                        if kernel == S.CSR_KERNEL_PANELS else None,
                         "kernel_source": kernel_source_ident(kname),
                         "rows": M, "nnz": NZ}, **info),
         "roofline": roofline_dict(alg, kern_ms, kname, NZ,
-                                  *measured_traffic(workload, kname)),
+                                  *measured_traffic(
+                                      workload, kname, dA.panels_schedule()
+                                      if kernel == S.CSR_KERNEL_PANELS
+                                      else None)),
         "host": {"host_gap_ms": round(ms_per_step - float(np.mean(kern_ms)), 5)
                  if not flush else None},
         "setup_s": round(t_setup, 2), "rows_checked": len(rows),
@@ -1066,7 +1100,13 @@ def main(argv=None):
         labels, prefix = S.HLL_KERNEL_LABELS, "hll_"
     else:
         labels, prefix = S.CSR_KERNEL_LABELS, "csr_"
-    if args.kernel >= 0:
+    pinned = bool(args.blocked_pin) and not use_dist
+    if pinned:
+        kernel = (S.HLL_KERNEL_PANELS if args.format == "hll"
+                  else S.CSR_KERNEL_PANELS)
+        for m in mats:
+            m.build_panels_pinned(args.blocked_pin)
+    elif args.kernel >= 0:
         kernel = args.kernel
     else:
         # kernel chosen by measurement (spmv_*_autotune) on the first shard:
@@ -1339,7 +1379,8 @@ def main(argv=None):
 
     workload = workload_name(args.family, args.format, Mloc, Nglob, Mglob, K,
                              args.window, W, L, Mshard)
-    traffic, why = (measured_traffic(workload, kname) if world == 1
+    sched_now = mat.panels_schedule() if blocked else None
+    traffic, why = (measured_traffic(workload, kname, sched_now) if world == 1
                     else (None, "single-GPU profiles only"))
     roof = roofline_dict(alg_bytes, kern_ms, kname, nnz_local, traffic, why)
     if per_rank:  # rank 0's events above; every rank's mean here
@@ -1348,7 +1389,8 @@ def main(argv=None):
         roof["kernel_ms_max_rank"] = round(max(per_rank), 5)
     if world == 1 and sweep:  # the schedule for rows that reach beyond an L2
         roof["secondary"] = secondary_roofline(workload, kname,
-                                               float(np.mean(kern_ms)))
+                                               float(np.mean(kern_ms)),
+                                               sched_now)
     out = {
         "metric": METRIC,
         "value": round(value, 2),
@@ -1369,7 +1411,8 @@ def main(argv=None):
             if use_dist else None,
             "workload": workload,
             "kernel": kname,
-            "kernel_choice": "autotuned (spmv_%s_autotune)" % args.format
+            "kernel_choice": "pinned layout (--blocked-pin)" if pinned
+            else "autotuned (spmv_%s_autotune)" % args.format
             if tuned is not None else "fixed by --kernel",
             # host seconds the selector took; its phase log when that is > 1 s
             "tune_s": round(t_tune, 2) if t_tune is not None else None,
@@ -1378,6 +1421,8 @@ def main(argv=None):
             and arrangement is None else None,
             "blocked_schedule": mat.panels_schedule() if blocked else None,
             "blocked_layout": mat.panels_describe() if blocked else None,
+            # what --blocked-pin takes to run this layout again
+            "blocked_pin": mat.panels_pin() if blocked else None,
             "kernel_source": kernel_source_ident(kname),
             "kernel_launches_per_step": launches_per_step,
             "rows_per_gpu": Mloc, "logical_shards_per_gpu": L,

@@ -253,6 +253,14 @@ int spmv_hll_panels_info(const spmv_hll_dev *H, int *steps, int *tiles,
                          int *panels, int64_t *entries);
 int spmv_hll_build_panels_like(spmv_hll_dev *H, const spmv_hll_dev *model);
 int spmv_hll_panels_schedule(const spmv_hll_dev *H);
+/* the blocked copy's layout as build options + the launch's waves hint (set
+ * o->struct_size first; -ENOENT: no copy): spmv_*_build_panels_opts(o) and
+ * spmv_*_panels_set_waves(waves) on a handle of the same matrix rebuild
+ * exactly what spmv_*_autotune settled on */
+int spmv_csr_panels_layout(const spmv_csr_dev *A, spmv_panel_opts *o, int *waves);
+int spmv_hll_panels_layout(const spmv_hll_dev *H, spmv_panel_opts *o, int *waves);
+int spmv_csr_panels_set_waves(spmv_csr_dev *A, int waves); /* 0..16 */
+int spmv_hll_panels_set_waves(spmv_hll_dev *H, int waves);
 int spmv_hll_panels_tile_rows(const spmv_hll_dev *H);
 int spmv_hll_panels_describe(const spmv_hll_dev *H, char *buf, size_t len);
 int spmv_hll_build_panels_as(spmv_hll_dev *H, int panel_cols, int sched,

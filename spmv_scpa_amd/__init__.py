@@ -291,6 +291,12 @@ _sig("spmv_csr_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
 _sig("spmv_hll_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
      _ip, _dp)
 _sig("spmv_set_panel_schedule", C.c_int, C.c_int)
+_sig("spmv_csr_panels_layout", C.c_int, C.c_void_p, C.POINTER(PanelOpts),
+     C.POINTER(C.c_int))
+_sig("spmv_hll_panels_layout", C.c_int, C.c_void_p, C.POINTER(PanelOpts),
+     C.POINTER(C.c_int))
+_sig("spmv_csr_panels_set_waves", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_hll_panels_set_waves", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_csr_build_panels_opts", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_hll_build_panels_opts", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_csr_build_panels", C.c_int, C.c_void_p, C.c_int)
@@ -436,6 +442,41 @@ def _env_int(name, lo, hi):
     except ValueError:
         return 0
     return v if lo <= v <= hi else 0
+
+
+_PIN_FIELDS = ("sched", "panel_cols", "tile_rows", "sweep_wgs_per_cu",
+               "reserve_cus", "lds_min", "tile_order", "sweep_layout",
+               "bucket_order")
+
+
+def _layout_pin(fn_layout, h):
+    """the blocked copy's layout as one string, "sched=2,tile_rows=4096,...,
+    waves=16" (None when there is no copy): what `build_panels_pinned` takes"""
+    o, w = PanelOpts(), C.c_int()
+    o.struct_size = C.sizeof(PanelOpts)
+    rc = fn_layout(h, C.byref(o), C.byref(w))
+    if rc == -2:  # -ENOENT
+        return None
+    _check(rc, "spmv_*_panels_layout")
+    return ",".join(["%s=%d" % (f, getattr(o, f)) for f in _PIN_FIELDS]
+                    + ["waves=%d" % w.value])
+
+
+def _pinned_opts(pin):
+    """-> (PanelOpts, waves) of a `panels_pin()` string; unknown keys are an
+    error (a pin of another library version must not half-apply)"""
+    o = PanelOpts()
+    _lib.spmv_panel_opts_default(C.byref(o))
+    waves = 0
+    for kv in pin.split(","):
+        k, v = kv.split("=")
+        if k == "waves":
+            waves = int(v)
+        elif k in _PIN_FIELDS:
+            setattr(o, k, int(v))
+        else:
+            raise ValueError("unknown field %r in blocked-layout pin" % k)
+    return o, waves
 
 
 def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
@@ -879,6 +920,18 @@ class CsrDevice:
         rc = _lib.spmv_csr_panels_describe(self.h, buf, 256)
         return None if rc else buf.value.decode()
 
+    def panels_pin(self):
+        """the layout of the blocked copy (schedule, tile height, orders,
+        waves) as a string that `build_panels_pinned` rebuilds exactly"""
+        return _layout_pin(_lib.spmv_csr_panels_layout, self.h)
+
+    def build_panels_pinned(self, pin):
+        o, waves = _pinned_opts(pin)
+        _check(_lib.spmv_csr_build_panels_opts(self.h, C.byref(o)),
+               "spmv_csr_build_panels_opts")
+        _check(_lib.spmv_csr_panels_set_waves(self.h, waves),
+               "spmv_csr_panels_set_waves")
+
     def build_panels_like(self, model):
         _check(_lib.spmv_csr_build_panels_like(self.h, model.h),
                "spmv_csr_build_panels_like")
@@ -997,6 +1050,18 @@ class HllDevice:
         buf = C.create_string_buffer(256)
         rc = _lib.spmv_hll_panels_describe(self.h, buf, 256)
         return None if rc else buf.value.decode()
+
+    def panels_pin(self):
+        """the layout of the blocked copy (schedule, tile height, orders,
+        waves) as a string that `build_panels_pinned` rebuilds exactly"""
+        return _layout_pin(_lib.spmv_hll_panels_layout, self.h)
+
+    def build_panels_pinned(self, pin):
+        o, waves = _pinned_opts(pin)
+        _check(_lib.spmv_hll_build_panels_opts(self.h, C.byref(o)),
+               "spmv_hll_build_panels_opts")
+        _check(_lib.spmv_hll_panels_set_waves(self.h, waves),
+               "spmv_hll_panels_set_waves")
 
     def build_panels_like(self, model):
         _check(_lib.spmv_hll_build_panels_like(self.h, model.h),

@@ -801,6 +801,55 @@ int spmv_hll_panels_tile_rows(const spmv_hll_dev *H) {
     return H->panels ? panels_tile_rows(H->panels) : -ENOENT;
 }
 
+/* The layout of the blocked copy as build options + the launch's waves hint:
+ * build_panels_opts(o) followed by panels_set_waves(waves) on another handle
+ * of the same matrix reproduces exactly what the selector settled on (the
+ * profiling passes of a workload pin the layout of the un-profiled run this
+ * way: under the counters' serialised launches the selector may pick another
+ * candidate).  The caller sets o->struct_size = sizeof *o first. */
+static int panels_layout_of(const spmv_panels *P, spmv_panel_opts *o,
+                            int *waves) {
+    if (!o || o->struct_size != (int)sizeof *o)
+        return -EINVAL;
+    if (!P)
+        return -ENOENT;
+    panels_get_opts(P, o);
+    if (waves)
+        *waves = panels_waves(P);
+    return 0;
+}
+
+int spmv_csr_panels_layout(const spmv_csr_dev *A, spmv_panel_opts *o, int *waves) {
+    HANDLE_OK(A);
+    return panels_layout_of(A->panels, o, waves);
+}
+
+int spmv_hll_panels_layout(const spmv_hll_dev *H, spmv_panel_opts *o, int *waves) {
+    HANDLE_OK(H);
+    return panels_layout_of(H->panels, o, waves);
+}
+
+/* waves per workgroup of the blocked launch (0: the kernel's default) */
+int spmv_csr_panels_set_waves(spmv_csr_dev *A, int waves) {
+    HANDLE_OK(A);
+    if (!A->panels)
+        return -ENOENT;
+    if (waves < 0 || waves > 16)
+        return -EINVAL;
+    panels_set_waves(A->panels, waves);
+    return 0;
+}
+
+int spmv_hll_panels_set_waves(spmv_hll_dev *H, int waves) {
+    HANDLE_OK(H);
+    if (!H->panels)
+        return -ENOENT;
+    if (waves < 0 || waves > 16)
+        return -EINVAL;
+    panels_set_waves(H->panels, waves);
+    return 0;
+}
+
 /* explicit schedule (0 steps, 1 sweep, 2 chain) and tile height (0: default;
  * ignored by sweep): ranks of a multi-GPU job build what rank 0 tuned */
 int spmv_csr_build_panels_as(spmv_csr_dev *A, int panel_cols, int sched,

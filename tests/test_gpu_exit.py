@@ -140,6 +140,8 @@ def test_release_is_idempotent_and_counted():
                S._lib.spmv_hll_build_panels_like(raw, raw),
                S._lib.spmv_hll_panels_info(raw, None, None, None, None),
                S._lib.spmv_hll_panels_schedule(raw),
+               S._lib.spmv_hll_panels_layout(raw, C.byref(o), None),
+               S._lib.spmv_hll_panels_set_waves(raw, 4),
                S._lib.spmv_hll_panels_tile_rows(raw),
                S._lib.spmv_hll_panels_describe(raw, buf, 64),
                S._lib.spmv_hll_release_source(raw),

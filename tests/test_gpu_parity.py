@@ -624,6 +624,50 @@ def test_build_panels_like_copies_schedule_and_tile_height(
     A1.release()
 
 
+@pytest.mark.parametrize("kind,M,K,W", [
+    (S.SYNTH_RANDOM, 300_000, 16, 1 << 30),
+    (S.SYNTH_POWERLAW, 400_000, 3, 1 << 30),
+    (S.SYNTH_HUB, 200_000, 6, 4096),
+], ids=["random", "powerlaw", "hub"])
+def test_pinned_layout_rebuilds_what_the_selector_settled_on(kind, M, K, W):
+    """`panels_pin()` of a tuned handle -> `build_panels_pinned()` on another
+    handle of the same matrix: the same layout line, the same y, for both
+    formats (what the counter passes of tools/profile.sh rely on: they
+    measure the layout the un-profiled selector picked)."""
+    N = M
+    d_x, d_y, d_z = S.DevBuffer(N * 8), S.DevBuffer(M * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    A = S.CsrDevice.generate(kind, M, N, K, W, 0, 42)
+    B = S.CsrDevice.generate(kind, M, N, K, W, 0, 42)
+    assert A.panels_pin() is None  # no blocked copy yet
+    for a, b, pid in ((A, B, S.CSR_KERNEL_PANELS),
+                      (A.to_hll(True), B.to_hll(True), S.HLL_KERNEL_PANELS)):
+        a.autotune(d_x.ptr, d_y.ptr)
+        if a.panels_info() is None:       # a direct kernel won: build the copy
+            a.build_panels(0)
+        pin = a.panels_pin()
+        assert "sched=" in pin and "waves=" in pin
+        b.build_panels_pinned(pin)
+        assert b.panels_pin() == pin
+        assert b.panels_describe() == a.panels_describe()
+        a.launch(pid, d_x.ptr, d_y.ptr)
+        b.launch(pid, d_x.ptr, d_z.ptr)
+        S.stream_sync()
+        # the tiles add their products into LDS with atomics: the order --
+        # and so the last bits -- differ from launch to launch
+        ya, yb = d_y.to_numpy(np.float64, M), d_z.to_numpy(np.float64, M)
+        assert np.max(np.abs(ya - yb)) <= 1e-12 * max(1.0, np.max(np.abs(ya)))
+        with pytest.raises(ValueError):
+            b.build_panels_pinned(pin + ",no_such_field=1")
+        if a is not A:
+            a.release()
+            b.release()
+    A.release()
+    B.release()
+    for d in (d_x, d_y, d_z):
+        d.free()
+
+
 def test_release_source_keeps_only_the_blocked_copy(default_panel_schedule):
     """spmv_*_release_source: JA/AS freed, the blocked path still runs, every
     entry point that needs the source says -ENODATA."""
@@ -802,15 +846,17 @@ def test_stream_kernel_on_long_empty_and_ragged_rows():
 
 def test_long_rows_at_every_threshold_stream_segments_and_blocked_side_path():
     """Rows around the two long-row thresholds: the CSR stream kernel cuts a
-    row of more than 8192 entries into 4096-entry segments (mode 2: last
+    row of more than 8192 entries into 2048-entry segments (mode 2: last
     arriver sums the partials in order), the blocked copy keeps a row of more
-    than 16384 entries beside itself (k_long_rows).  Lengths at and next to
+    than 16384 entries beside itself (k_long_rows, 1024-entry segments).  Lengths at and next to
     every boundary, long rows first / last / adjacent / between empty rows,
     ranges of up to 1024 short rows; launched three times each (the arrival
     counters must be re-armed), the direct kernels bit-identical every time."""
     rng = np.random.default_rng(11)
     special = [8192, 8193, 12_288, 12_289, 4096 * 5 - 1, 16_384, 16_385,
-               20_000, 40_960, 0, 0, 70_001, 1, 8191, 4096, 4097]
+               20_000, 40_960, 0, 0, 70_001, 1, 8191, 4096, 4097,
+               2048 * 5 - 1, 2048 * 5, 2048 * 5 + 1,     # segment boundaries
+               1024 * 17 - 1, 1024 * 17, 1024 * 17 + 1]  # of both side paths
     lens = np.concatenate([
         [16_385],                              # a long row FIRST
         rng.integers(1, 4, 3_000),             # 1-3 entries: 1024-row ranges

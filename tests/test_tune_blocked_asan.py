@@ -29,7 +29,7 @@ def test_tune_blocked_ownership_under_asan(tmp_path):
 
 def test_stream_table_invariants_under_asan(tmp_path):
     """the CSR stream kernel's row-block table (stream_table.h: ranges of up
-    to 2048 entries / 1024 rows, rows beyond 8192 entries cut into 4096-entry
+    to 2048 entries / 1024 rows, rows beyond 8192 entries cut into 2048-entry
     segments): 600 seeded row-length vectors, every entry covered by exactly
     one range, every row written exactly once, segment arithmetic as the
     kernel restates it"""

@@ -34,6 +34,8 @@ def main():
     out = {"workload": cfg["workload"], "bench_kernel": cfg["kernel"],
            "kernel": kname, "kernel_source": cfg.get("kernel_source"),
            "blocked_layout": cfg.get("blocked_layout"),
+           "blocked_schedule": cfg.get("blocked_schedule"),
+           "kernel_choice": cfg.get("kernel_choice"),
            "requests_per_launch": req,
            "mean_latency_cycles": (lat / req) if lat else None,
            "launches": ctr["TCP_TCC_READ_REQ_sum"]["n"],

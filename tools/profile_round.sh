@@ -38,15 +38,26 @@ if [ "$part" = "passes" ]; then
     mkdir -p gpurun_out/profiles_${round} && cp -f profiles/${round}_* gpurun_out/profiles_${round}/
     echo "== passes done"; exit 0
 fi
+# counter passes run the layout of an UN-profiled selector run (--blocked-pin)
+pinned() {  # pinned <tag> <bench args...>: prints "--blocked-pin <pin>" or nothing
+    local tag="$1"; shift
+    python3 bench.py --no-extras --no-cpu-baseline --steps 5 "$@" \
+        > "gpurun_out/${round}_pin_$tag.json" 2> /dev/null || return 0
+    local pin; pin=$(python3 tools/blocked_pin.py "gpurun_out/${round}_pin_$tag.json")
+    [ -n "$pin" ] && echo "--blocked-pin $pin"
+}
+PIN_WN=$(pinned wn)
 step tools/pmc.sh "${round}_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-    bench.py --no-extras --no-cpu-baseline --steps 20
+    bench.py --no-extras --no-cpu-baseline --steps 20 $PIN_WN
 step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_l2req" \
     "profiles/${round}_wn.l2req.json" > /dev/null
 step tools/pmc.sh "${round}_tcc" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
-    bench.py --no-extras --no-cpu-baseline --steps 20
+    bench.py --no-extras --no-cpu-baseline --steps 20 $PIN_WN
 # the same request counters for the power-law matrix (what bounds 22 %) ...
+PL="--family powerlaw --rows-per-gpu 4000000 --nnz-row 3"
+PIN_PL=$(pinned pl $PL)
 step tools/pmc.sh "${round}_pl_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-    bench.py --no-extras --no-cpu-baseline --steps 20 --family powerlaw --rows-per-gpu 4000000 --nnz-row 3
+    bench.py --no-extras --no-cpu-baseline --steps 20 $PL $PIN_PL
 step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_pl_l2req" \
     "profiles/${round}_powerlaw4M.l2req.json" > /dev/null
 # ... and for one rank's shard of config 5 (10M x 80M; profiles/<round>_config5_shard.counters.json)

@@ -114,14 +114,28 @@ def main():
     # machine-readable traffic of the dominant kernel: bench.py quotes it as
     # roofline.traffic when its workload matches
     cfg, nsteps = None, 0
+    # the bench line of the FETCH pass itself: the selector runs again in
+    # every pass, and under the counters' serialised launches two candidates
+    # within noise of each other can swap (seen on the power-law matrix:
+    # chain<1024> in the trace pass, chain<256> in the counter passes) -- the
+    # traffic record must name the layout it was measured on
+    bf = os.path.join(src, "bench_fetch.json")
+    kt_layout = None
     if os.path.exists(bj) and os.path.getsize(bj):
         try:
-            jj = json.loads(open(bj).read().strip().splitlines()[-1])
-            cfg = jj["config"]
-            # warm-up + parity-check step + timed steps
-            nsteps = int(jj["steps"]) + int(jj["warmup"]) + 1
+            kt_layout = json.loads(open(bj).read().strip().splitlines()[-1])[
+                "config"].get("blocked_layout")
         except (ValueError, KeyError):
-            cfg = None
+            pass
+    for cand in (bf, bj):
+        if cfg is None and os.path.exists(cand) and os.path.getsize(cand):
+            try:
+                jj = json.loads(open(cand).read().strip().splitlines()[-1])
+                cfg = jj["config"]
+                # warm-up + parity-check step + timed steps
+                nsteps = int(jj["steps"]) + int(jj["warmup"]) + 1
+            except (ValueError, KeyError):
+                cfg = None
     if f and cfg:
         fpath = first(os.path.join(src, "fetch", "**", "*counter_collection.csv"))
         top = bench_kernel_function(cfg["kernel"], list(f), last_dispatch(fpath))
@@ -147,7 +161,9 @@ def main():
                   # the kernel's source file (measured_traffic)
                   "kernel_source": cfg.get("kernel_source"),
                   "blocked_schedule": cfg.get("blocked_schedule"),
-                  "blocked_layout": cfg.get("blocked_layout")}
+                  "blocked_layout": cfg.get("blocked_layout"),
+                  "trace_pass_layout": kt_layout,
+                  "passes_agree": kt_layout == cfg.get("blocked_layout")}
             json.dump(tj, open(dst[:-3] + ".traffic.json", "w"), indent=1)
             out += ["## bench.py's timed kernel", "",
                     "`%s`, last %d launches (%d per SpMV): %.4g B read + %.4g B "
@@ -156,6 +172,11 @@ def main():
                        tj["write_bytes"], tj["bytes_per_launch"],
                        jj.get("roofline", {}).get(
                            "algorithmic_bytes_per_launch", "?")), ""]
+            if not tj["passes_agree"]:
+                out += ["The selector of the counter passes settled on another "
+                        "layout than the trace pass's (candidates within noise "
+                        "under serialised launches): counters: `%s`; trace: `%s`."
+                        % (tj["blocked_layout"], kt_layout), ""]
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
