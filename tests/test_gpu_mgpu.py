@@ -207,6 +207,42 @@ def test_native_staged_exchange_runs_on_one_gpu(as_hll, kernel, chunks):
     g.destroy()
 
 
+@pytest.mark.parametrize("kind,K", [(S.SYNTH_HUB, 6), (S.SYNTH_POWERLAW, 3)],
+                         ids=["hub", "powerlaw"])
+@pytest.mark.parametrize("as_hll,kernel", [(True, 1), (True, 2), (False, 2),
+                                           (False, 0), (False, 4)])
+def test_native_chunked_launches_with_long_rows(kind, K, as_hll, kernel):
+    """The chunk launches of the overlapped exchange on the reference's
+    irregular classes: a hub row as long as the matrix is wide (64 000 entries:
+    segments of the CSR side launch, a wide hack block of the HLL one) must
+    be summed exactly once -- by the chunk that owns it, whose side launch
+    skips the other chunks' rows / blocks -- and land in the staging buffer at
+    the right place.  Whole y against the oracle's rows, two steps in a row
+    (arrival counters re-armed)."""
+    n = min(S.device_count(), 8)
+    rows = 64_000
+    g = S.MultiGpu(n)
+    g.generate(kind, rows, K, 4096, 42, as_hll=as_hll)
+    g.fill_x(7)
+    g.set_exchange(4, force=True)
+    g.spmv(kernel=kernel, warmup=1, iters=2)
+    M = rows * n
+    y = g.get_y(0)
+    hub = M // 3  # SYNTH_HUB's long row (include/spmv_synth.h)
+    probe = sorted({0, 31, 32, rows // 4 - 1, rows // 4, hub - 1, hub, hub + 1,
+                    rows - 1, M - 1} | set(
+        np.random.default_rng(3).integers(0, M, 300).tolist()))
+    for grow in probe:
+        want, sc = O.synth_row_dot(kind, M, M, K, 4096, 0, 42, 7, grow)
+        assert abs(y[grow] - want) <= 1e-12 * sc, (grow, y[grow], want)
+    # in-place exchange (chunks = 1): the same y, bit for bit on the direct
+    # kernels (their long-row reductions have a fixed order)
+    g.set_exchange(1, force=True)
+    g.spmv(kernel=kernel, warmup=0, iters=1)
+    assert np.array_equal(g.get_y(0), y)
+    g.destroy()
+
+
 @pytest.mark.parametrize("M", [128_000, 100_003])
 def test_native_staged_exchange_on_a_host_matrix(M):
     """load_csr + set_exchange(4, force): staged when the rows split into
