@@ -174,17 +174,40 @@ struct spmv_hll_dev {
 };
 
 #if defined(__HIPCC__)
+/* part[first * stride], part[(first + step) * stride], ... (indices below n)
+ * added up in THAT order, U loads in flight at a time.  The partial sums were
+ * written by other workgroups, on other XCDs: agent-scope atomic loads, each a
+ * round trip to the L2 / fabric -- one at a time, the 64 loads per lane of a
+ * 512-segment hack block were most of k_hll_wide's launch. */
+template <int U>
+__device__ __forceinline__ double ordered_partial_sum(const double *part, int n,
+                                                      int first, int step,
+                                                      size_t stride) {
+    double s = 0.0;
+    for (int j = first; j < n; j += step * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            v[u] = j + u * step < n
+                       ? __hip_atomic_load(part + (size_t)(j + u * step) * stride,
+                                           __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT)
+                       : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j + u * step < n)
+                s += v[u];
+    }
+    return s;
+}
+
 /* Sum part[0 .. n) in a FIXED order with one wavefront (all 64 lanes call):
  * lane l adds part[l], part[l + 64], ... in index order, then a shuffle tree.
- * The partial sums were written by other workgroups, on other XCDs: agent-
- * scope atomic loads.  Total in lane 0.  (One lane adding 10^2..10^3 partials
- * one dependent load at a time was a third of the hub matrices' launch.) */
+ * Total in lane 0.  (One lane adding 10^2..10^3 partials one dependent load
+ * at a time was a third of the hub matrices' launch.) */
 __device__ __forceinline__ double wave_ordered_sum(const double *part, int n,
                                                    int lane) {
-    double s = 0.0;
-    for (int j = lane; j < n; j += WAVE)
-        s += __hip_atomic_load(part + j, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+    double s = ordered_partial_sum<4>(part, n, lane, WAVE, 1);
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1)
         s += __shfl_down(s, d, WAVE);
@@ -203,7 +226,12 @@ __device__ __forceinline__ double strided_dot(const int *__restrict__ ja,
                                               const double *__restrict__ x,
                                               int beg, int end, int tid) {
     double acc = 0.0;
-    int k = beg + tid;
+    /* indices relative to `beg`: `end` may sit next to INT32_MAX (the entry
+     * count's limit), beg + k + U * NT must not be formed in 32 bits */
+    ja += beg;
+    as += beg;
+    end -= beg;
+    int k = tid;
     for (; k + (U - 1) * NT < end; k += U * NT) {
         int c[U];
         double v[U], xv[U];

@@ -388,26 +388,27 @@ __global__ void __launch_bounds__(256)
     double acc = 0.0;
     if (i < rows) {
         /* slot of column j of row i; the lane's columns are j0 + cl, + 8, ...
-         * Four of them in flight at a time, added in column order (one
+         * Eight of them in flight at a time, added in column order (one
          * accumulator): one at a time is two dependent memory round trips
          * per slot, 32 times over -- the launch was latency, not bandwidth */
         const int64_t base = o + (col_major ? i : (int64_t)i * w);
         const int64_t step = col_major ? rows : 1;
         int j = j0 + cl;
-        for (; j + 24 < j1; j += 32) {
-            int c[4];
-            double v[4], xv[4];
+        constexpr int U = 8;
+        for (; j + 8 * (U - 1) < j1; j += 8 * U) {
+            int c[U];
+            double v[U], xv[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int64_t t = base + (int64_t)(j + 8 * u) * step;
                 c[u] = ld_stream(ja + t);
                 v[u] = ld_stream(as + t);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
                 xv[u] = x[c[u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
                 acc += v[u] * xv[u];
         }
         for (; j < j1; j += 8) {
@@ -437,10 +438,8 @@ __global__ void __launch_bounds__(256)
      * partial, then the eight are added in lane order -- a fixed order */
     {
         const int r = tid & 31, c = tid >> 5;
-        double sum = 0.0;
-        for (int k = c; k < nseg; k += 8)
-            sum += __hip_atomic_load(part + (size_t)(g0 + k) * HACK + r,
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sum = ordered_partial_sum<8>(part + (size_t)g0 * HACK + r,
+                                                  nseg, c, 8, HACK);
         __syncthreads(); /* red[] of the column lanes is no longer needed */
         red[c][r] = sum;
     }
