@@ -114,6 +114,10 @@ def test_selector_on_the_reference_s_irregular_classes(kind, M, K, W):
             assert bh == S.HLL_KERNEL_PANELS     # the format pads 2.3x
             assert "long row(s) beside" in dH.panels_describe()
             assert mh < 2.0 * ms + 0.02, (mh, ms)   # was 4x the CSR time
+            # the blocked copy stores no padding: priced on the true entries,
+            # or a padded format would read > 100 % of the roofline
+            assert dH.kernel_bytes(bh) < dH.algorithmic_bytes
+            assert dH.kernel_bytes(bh) / (mh * 1e6) / 8000.0 < 1.0
         log = dA.tune_log()
         assert "direct kernels" in log and "total" in log
     finally:
