@@ -26,6 +26,7 @@
  * plus the x gathers.  JA/AS are read once -> non-temporal loads, so they
  * do not evict x from L2 / Infinity Cache.
  */
+#include <algorithm>
 #include "hip_common.h"
 
 template <typename T> __device__ __forceinline__ T ld_stream(const T *p) {
@@ -96,16 +97,19 @@ __global__ void k_csr_wave_row(int r0, int r1, int lrow,
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
     const int waves = blockDim.x / WAVE;
-    const int row = r0 + blockIdx.x * waves + wave; /* wave-uniform */
-    if (row >= r1)
-        return;
-    const int beg = irp[row], end = irp[row + 1];
-    if (lrow > 0 && end - beg > lrow)
-        return; /* wave-uniform: the whole wavefront leaves */
-    double acc = strided_dot<WAVE, 4>(ja, as, x, beg, end, lane);
-    acc = group_sum<WAVE>(acc);
-    if (lane == 0)
-        y[row] = acc;
+    /* grid-stride over the rows (wave-uniform): a launch holds fewer than 2^32
+     * work-items, i.e. 2^26 wavefronts -- a matrix at the entry-count limit
+     * (67M rows x 32) has more rows than that */
+    for (long long row = (long long)r0 + (long long)blockIdx.x * waves + wave;
+         row < r1; row += (long long)gridDim.x * waves) {
+        const int beg = irp[row], end = irp[row + 1];
+        if (lrow > 0 && end - beg > lrow)
+            continue; /* k_csr_long_seg's row */
+        double acc = strided_dot<WAVE, 4>(ja, as, x, beg, end, lane);
+        acc = group_sum<WAVE>(acc);
+        if (lane == 0)
+            y[row] = acc;
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -180,18 +184,19 @@ __global__ void k_csr_subwave_row(int r0, int r1, int ulen, int lrow,
     double a[P], acc[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int k = beg[p] + sub;
-        const bool has = k < end[p];
-        c[p] = has ? ld_stream(ja + k) : -1;
-        a[p] = has ? ld_stream(as + k) : 0.0;
+        /* offsets relative to the row's first entry: beg + sub (+ G below)
+         * must not be formed in 32 bits next to INT32_MAX */
+        const bool has = sub < end[p] - beg[p];
+        c[p] = has ? ld_stream(ja + beg[p] + sub) : -1;
+        a[p] = has ? ld_stream(as + beg[p] + sub) : 0.0;
     }
 #pragma unroll
     for (int p = 0; p < P; ++p)
         acc[p] = c[p] >= 0 ? a[p] * x[c[p]] : 0.0;
 #pragma unroll
     for (int p = 0; p < P; ++p)
-        for (int k = beg[p] + sub + G; k < end[p]; k += G)
-            acc[p] += ld_stream(as + k) * x[ld_stream(ja + k)];
+        for (int k = sub + G, n = end[p] - beg[p]; k < n; k += G)
+            acc[p] += ld_stream(as + beg[p] + k) * x[ld_stream(ja + beg[p] + k)];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         acc[p] = group_sum<G>(acc[p]);
@@ -217,8 +222,12 @@ __global__ void k_csr_block_row(int r0, int r1, int lrow,
         const int beg = irp[row], end = irp[row + 1];
         if (lrow > 0 && end - beg > lrow)
             continue; /* block-uniform; no barrier was entered for this row */
-        for (int k = beg + threadIdx.x; k < end; k += blockDim.x)
-            acc += ld_stream(as + k) * x[ld_stream(ja + k)];
+        /* relative to the row: beg + k + blockDim.x must not be formed in 32
+         * bits next to INT32_MAX (the entry count's limit) */
+        const int *rj = ja + beg;
+        const double *ra = as + beg;
+        for (int k = threadIdx.x, n = end - beg; k < n; k += blockDim.x)
+            acc += ld_stream(ra + k) * x[ld_stream(rj + k)];
 #pragma unroll
         for (int d = WAVE / 2; d > 0; d >>= 1)
             acc += __shfl_down(acc, d, WAVE);
@@ -670,7 +679,9 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                            0, s, r0, r1, lrow, A->irp, A->ja, A->as, x, y);
         break;
     case 1:
-        hipLaunchKernelGGL(k_csr_wave_row, dim3((rows + waves - 1) / waves),
+        hipLaunchKernelGGL(k_csr_wave_row,
+                           dim3(std::min((rows + waves - 1) / waves,
+                                         (int)(0xFFFFFFFFu / (unsigned)threads))),
                            dim3(threads), 0, s, r0, r1, lrow, A->irp, A->ja,
                            A->as, x, y);
         break;

@@ -24,6 +24,7 @@
  * No MFMA (no dense contraction).  JA/AS stream once -> non-temporal loads;
  * x gathers are ordinary cached loads.
  */
+#include <algorithm>
 #include "hip_common.h"
 
 #define HACK 32
@@ -335,27 +336,38 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1, int wide,
                                   const double *__restrict__ x,
                                   double *__restrict__ y) {
     const int sub = threadIdx.x & 15;
-    long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    int b = b0 + (int)(g / HACK), i = (int)(g % HACK);
-    double acc = 0.0;
-    bool live = false;
-    if (b < b1) {
-        int rows = min(HACK, M - b * HACK);
-        if (i < rows) {
-            int64_t o = off[b];
-            int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
-            live = !(wide > 0 && w > wide);
-            const int *rj = ja + o + (int64_t)i * w;
-            const double *ra = as + o + (int64_t)i * w;
-            if (live)
-                acc = strided_dot<16, 4>(rj, ra, x, 0, w, sub);
+    /* grid-stride over the rows: 16 work-items per row are more than one
+     * launch holds (2^32) beyond 2^28 rows.  The trip count is the same for
+     * every lane of a wavefront (`first` is the wavefront's first row); rows
+     * past the end are masked */
+    const long long total = (long long)(b1 - b0) * HACK;
+    const long long step = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long lane_g = (threadIdx.x & (WAVE - 1)) >> 4;
+    for (long long first =
+             (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4) - lane_g;
+         first < total; first += step) {
+        const long long g = first + lane_g;
+        const int b = b0 + (int)(g / HACK), i = (int)(g % HACK);
+        double acc = 0.0;
+        bool live = false;
+        if (g < total) {
+            int rows = min(HACK, M - b * HACK);
+            if (i < rows) {
+                int64_t o = off[b];
+                int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+                live = !(wide > 0 && w > wide);
+                const int *rj = ja + o + (int64_t)i * w;
+                const double *ra = as + o + (int64_t)i * w;
+                if (live)
+                    acc = strided_dot<16, 4>(rj, ra, x, 0, w, sub);
+            }
         }
-    }
 #pragma unroll
-    for (int d = 8; d > 0; d >>= 1)
-        acc += __shfl_down(acc, d, 16);
-    if (live && sub == 0)
-        y[(int64_t)b * HACK + i] = acc;
+        for (int d = 8; d > 0; d >>= 1)
+            acc += __shfl_down(acc, d, 16);
+        if (live && sub == 0)
+            y[(int64_t)b * HACK + i] = acc;
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -575,7 +587,8 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
     case 3:
         hipLaunchKernelGGL(
             k_hll_subwave_row,
-            dim3((unsigned)((lanes * 16 + threads - 1) / threads)),
+            dim3((unsigned)std::min<long long>((lanes * 16 + threads - 1) / threads,
+                                               0xFFFFFFFFll / threads)),
             dim3(threads), 0, s, H->M, b0, b1, wide, H->off, H->ja, H->as, x,
             y);
         break;

@@ -211,20 +211,26 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
                                 unsigned *idx) {
     /* 8 lanes per row keep the writes reasonably coalesced */
     const int sub = threadIdx.x & 7;
-    long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    if (row >= M)
-        return;
-    const uint64_t tile = (uint64_t)(row / tile_rows);
     const unsigned low = (1u << shift) - 1u;
-    /* a long row's entries live beside the copy: dropped from the buckets */
-    const bool out = nlong > 0 && in_sorted(long_row, nlong, (int)row);
     const uint64_t dropped = nbuckets << shift;
-    for (int k = irp[row] + sub, e = irp[row + 1]; k < e; k += 8) {
-        const unsigned c = (unsigned)ja[k];
-        key[k] = out ? dropped
-                     : (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
-                           (c & low);
-        idx[k] = (unsigned)k;
+    /* grid-stride over the rows: 8 work-items per row are more than one
+     * launch holds (2^32) beyond 2^29 rows */
+    const long long step = ((long long)gridDim.x * blockDim.x) >> 3;
+    for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+         row < M; row += step) {
+        const uint64_t tile = (uint64_t)(row / tile_rows);
+        /* a long row's entries live beside the copy: dropped from the buckets */
+        const bool out = nlong > 0 && in_sorted(long_row, nlong, (int)row);
+        /* 64-bit entry index: k + 8 next to INT32_MAX (the entry count's limit) */
+        for (int64_t k = (int64_t)irp[row] + sub, e = irp[row + 1]; k < e;
+             k += 8) {
+            const unsigned c = (unsigned)ja[k];
+            key[k] = out ? dropped
+                         : (bucket_id(tile, c >> shift, panels, pm_grid)
+                            << shift) |
+                               (c & low);
+            idx[k] = (unsigned)k;
+        }
     }
 }
 
@@ -616,28 +622,32 @@ __global__ void k_long_rows_hll(int M, int limit, int cap, int col_major,
                                 const int64_t *__restrict__ off,
                                 const unsigned *__restrict__ padmask, int *list) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    if (row >= M)
-        return;
-    const int b = (int)(row >> 5), i = (int)(row & 31);
-    const int rows = min(32, M - b * 32);
-    const int64_t o = off[b];
-    const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
-    if (w <= limit)
-        return;
-    int len = 0;
-    for (int j = lane; j < w; j += WAVE) {
-        const int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
-        len += !((padmask[t >> 5] >> (t & 31)) & 1u);
-    }
+    /* grid-stride (wave-uniform): M wavefronts are more work-items than one
+     * launch holds (2^32) once M reaches 2^26 */
+    const long long step = (long long)gridDim.x * blockDim.x / WAVE;
+    for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+         row < M; row += step) {
+        const int b = (int)(row >> 5), i = (int)(row & 31);
+        const int rows = min(32, M - b * 32);
+        const int64_t o = off[b];
+        const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+        if (w <= limit)
+            continue;
+        int len = 0;
+        for (int j = lane; j < w; j += WAVE) {
+            const int64_t t =
+                o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
+            len += !((padmask[t >> 5] >> (t & 31)) & 1u);
+        }
 #pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1)
-        len += __shfl_down(len, d, WAVE);
-    if (lane == 0 && len > limit) {
-        const int k = atomicAdd(list, 1);
-        if (k < cap) {
-            list[1 + 2 * k] = (int)row;
-            list[2 + 2 * k] = len;
+        for (int d = WAVE / 2; d > 0; d >>= 1)
+            len += __shfl_down(len, d, WAVE);
+        if (lane == 0 && len > limit) {
+            const int k = atomicAdd(list, 1);
+            if (k < cap) {
+                list[1 + 2 * k] = (int)row;
+                list[2 + 2 * k] = len;
+            }
         }
     }
 }
@@ -760,7 +770,8 @@ static int long_rows_extract(spmv_panels *P, int M, int nb,
                            d_list);
     else
         hipLaunchKernelGGL(k_long_rows_hll,
-                           dim3((unsigned)(((long long)M * WAVE + 255) / 256)),
+                           dim3((unsigned)std::min<long long>(
+                               ((long long)M * WAVE + 255) / 256, 1 << 22)),
                            dim3(256), 0, 0, M, PANELS_LONG_ROW, PANELS_LONG_MAX,
                            col_major, off_or_null, padmask, d_list);
     HIP_TRY(hipGetLastError());
@@ -1048,7 +1059,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     if (slots > 0) {
         if (irp_or_null)
             hipLaunchKernelGGL(k_keys_from_csr,
-                               dim3((unsigned)(((long long)M * 8 + 255) / 256)),
+                               dim3((unsigned)std::min<long long>(
+                                   ((long long)M * 8 + 255) / 256, 1 << 23)),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
                                pm_grid, (uint64_t)nbuckets, P->long_row,
                                P->nlong, irp_or_null, ja, key[0], idx[0]);

@@ -1,0 +1,114 @@
+"""The largest matrix the host API can describe: its structs count entries in
+`int` (reference csr.h:9-10, hll.h), so a matrix holds at most INT32_MAX of
+them.  One GPU of 288 GB takes such a matrix whole (26 GB as CSR, another 26 GB
+per HLL layout, 26 GB for the blocked copy) -- 6.7 times config 3.
+
+* 67 108 863 rows x 32 entries = INT32_MAX - 31 entries: the last rows' entry
+  indices lie within a wavefront's stride of the int32 limit (an index formed
+  as `first + lane + stride` in 32 bits wraps there), a wavefront per row is
+  2^32 work-items (more than one launch holds), the last hack block is ragged
+  (31 rows).  Every direct kernel of both formats and the selector; the
+  blocked copy, whose padded slots are indexed with 32 bits, must say
+  -EOVERFLOW (and the selector must then keep a direct kernel).
+* 66 000 000 rows x 32 = 2.112e9 entries: the blocked path as well, from both
+  sources and with both of its main schedules.
+
+Against rows recomputed from the workload definition by the oracle."""
+import errno
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import spmv_scpa_amd as S
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-12
+K, W = 32, 1 << 20
+
+
+def _setup(M):
+    if S.device_info(0)[2] < 200 << 30:
+        pytest.skip("needs ~150 GB of device memory")
+    dA = S.CsrDevice.generate(S.SYNTH_RANDOM, M, M, K, W, 0, 42)
+    assert dA.NZ == M * K
+    d_x, d_y = S.DevBuffer(M * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, M, 7)
+    rng = np.random.default_rng(5)
+    rows = np.unique(np.concatenate([
+        [0, 31, 32, M - 33, M - 32, M - 1],
+        rng.integers(0, M, 1_500),
+        rng.integers(M - 100_000, M, 500)]))   # entry indices next to 2^31
+    want = np.array([O.synth_row_dot(S.SYNTH_RANDOM, M, M, K, W, 0, 42, 7,
+                                     int(g)) for g in rows])
+
+    def check(handle, kernel, tag):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        handle.launch(kernel, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        y = d_y.to_numpy(np.float64, M)
+        assert np.all(np.isfinite(y)), tag
+        err = np.max(np.abs(y[rows] - want[:, 0]) / want[:, 1])
+        assert err <= TIGHT, (tag, err)
+        return y
+
+    return dA, d_x, d_y, check
+
+
+def _agree(ys):
+    ref = ys.pop(next(iter(ys)))
+    for tag, y in ys.items():
+        assert np.max(np.abs(y - ref)) < 1e-11, tag
+
+
+def test_at_the_entry_count_limit():
+    M = 67_108_863
+    assert M * K == 2 ** 31 - 1 - 31
+    dA, d_x, d_y, check = _setup(M)
+    ys = {}
+    for k in (2, 4, 0, 1, 3):              # every CSR kernel of the seam
+        ys["csr %d" % k] = check(dA, k, "csr kernel %d" % k)
+    # the blocked copy indexes its padded slots with 32 bits: no room here
+    with pytest.raises(OSError) as ei:
+        dA.build_panels(0)
+    assert ei.value.errno == errno.EOVERFLOW
+    best, ms = dA.autotune(d_x.ptr, d_y.ptr)   # ... so a direct kernel it is
+    assert best in (2, 4) and ms > 0
+    dH = dA.to_hll(True)
+    dR = dA.to_hll(False)
+    dA.release()
+    assert dH.slots == M * K and dH.num_blocks == (M + 31) // 32
+    for k in (1, 2):
+        ys["hll %d" % k] = check(dH, k, "hll col-major kernel %d" % k)
+    for k in (0, 3):
+        ys["hll %d" % k] = check(dR, k, "hll row-major kernel %d" % k)
+    dR.release()
+    best, ms = dH.autotune(d_x.ptr, d_y.ptr)
+    assert best in (1, 2) and ms > 0
+    dH.release()
+    _agree(ys)
+    d_x.free()
+    d_y.free()
+
+
+def test_blocked_path_at_2e9_entries():
+    M = 66_000_000
+    dA, d_x, d_y, check = _setup(M)
+    ys = {"csr 2": check(dA, 2, "csr sub-wave")}
+    # the measured selector at this size (several blocked candidates, each
+    # built from 2.1e9 keys), then whatever it picked
+    best, ms = dA.autotune(d_x.ptr, d_y.ptr)
+    ys["csr autotuned"] = check(dA, best, "csr autotuned %d" % best)
+    if best != S.CSR_KERNEL_PANELS:
+        dA.build_panels(0)
+    ys["csr blocked"] = check(dA, S.CSR_KERNEL_PANELS, "csr blocked")
+    assert dA.panels_info()["entries"] == dA.NZ
+    dH = dA.to_hll(True)
+    dA.release()
+    dH.build_panels(0, "sweep")            # the headline's schedule
+    ys["hll blocked sweep"] = check(dH, S.HLL_KERNEL_PANELS, "hll blocked")
+    assert dH.panels_info()["entries"] == M * K
+    dH.release()
+    _agree(ys)
+    d_x.free()
+    d_y.free()
