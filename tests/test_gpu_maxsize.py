@@ -13,6 +13,11 @@ per HLL layout, 26 GB for the blocked copy) -- 6.7 times config 3.
 * 66 000 000 rows x 32 = 2.112e9 entries: the blocked path as well, from both
   sources and with both of its main schedules.
 
+* 2^29 rows x 2..4 entries (1.6e9 entries, x and y of 4.3 GB each): the other
+  way to be large -- a wavefront, 16 or 8 lanes per row are more work-items
+  than a launch holds, so those kernels walk the rows grid-stride; 16.8M hack
+  blocks; 131 072 row tiles x 2048 panels of the blocked copy.
+
 Against rows recomputed from the workload definition by the oracle."""
 import errno
 
@@ -27,11 +32,11 @@ TIGHT = 1e-12
 K, W = 32, 1 << 20
 
 
-def _setup(M):
+def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W):
     if S.device_info(0)[2] < 200 << 30:
         pytest.skip("needs ~150 GB of device memory")
-    dA = S.CsrDevice.generate(S.SYNTH_RANDOM, M, M, K, W, 0, 42)
-    assert dA.NZ == M * K
+    dA = S.CsrDevice.generate(kind, M, M, K, W, 0, 42)
+    assert kind != S.SYNTH_RANDOM or dA.NZ == M * K
     d_x, d_y = S.DevBuffer(M * 8), S.DevBuffer(M * 8)
     S.dev_fill_synth(d_x.ptr, M, 7)
     rng = np.random.default_rng(5)
@@ -39,8 +44,8 @@ def _setup(M):
         [0, 31, 32, M - 33, M - 32, M - 1],
         rng.integers(0, M, 1_500),
         rng.integers(M - 100_000, M, 500)]))   # entry indices next to 2^31
-    want = np.array([O.synth_row_dot(S.SYNTH_RANDOM, M, M, K, W, 0, 42, 7,
-                                     int(g)) for g in rows])
+    want = np.array([O.synth_row_dot(kind, M, M, K, W, 0, 42, 7, int(g))
+                     for g in rows])
 
     def check(handle, kernel, tag):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
@@ -108,6 +113,34 @@ def test_blocked_path_at_2e9_entries():
     dH.build_panels(0, "sweep")            # the headline's schedule
     ys["hll blocked sweep"] = check(dH, S.HLL_KERNEL_PANELS, "hll blocked")
     assert dH.panels_info()["entries"] == M * K
+    dH.release()
+    _agree(ys)
+    d_x.free()
+    d_y.free()
+
+
+def test_half_a_billion_rows():
+    M = 1 << 29
+    dA, d_x, d_y, check = _setup(M, S.SYNTH_RAGGED, 3, 4096)
+    assert 2 * M <= dA.NZ <= 4 * M and dA.NZ < 2 ** 31
+    ys = {}
+    for k in (2, 4, 0, 1, 3):
+        ys["csr %d" % k] = check(dA, k, "csr kernel %d" % k)
+    dA.build_panels(0, "chain")
+    info = dA.panels_info()
+    assert info["entries"] == dA.NZ and info["tiles"] * info["panels"] > 1 << 27
+    ys["csr blocked"] = check(dA, S.CSR_KERNEL_PANELS, "csr blocked chain")
+    dH = dA.to_hll(True)
+    dR = dA.to_hll(False)
+    dA.release()
+    assert dH.num_blocks == M // 32 and dH.slots >= dH.NZ
+    for k in (1, 2):
+        ys["hll %d" % k] = check(dH, k, "hll col-major kernel %d" % k)
+    for k in (0, 3):
+        ys["hll %d" % k] = check(dR, k, "hll row-major kernel %d" % k)
+    dR.release()
+    dH.build_panels(0, "chain")
+    ys["hll blocked"] = check(dH, S.HLL_KERNEL_PANELS, "hll blocked chain")
     dH.release()
     _agree(ys)
     d_x.free()
