@@ -32,6 +32,22 @@ TIGHT = 1e-12
 K, W = 32, 1 << 20
 
 
+def needs_a_whole_gpu(test):
+    """these cases hold 100-150 GB at a time: on a card that somebody else is
+    using too, running out of memory is not a finding about this library"""
+    import functools
+
+    @functools.wraps(test)
+    def run():
+        try:
+            test()
+        except OSError as e:
+            if e.errno != errno.ENOMEM:
+                raise
+            pytest.skip("device memory ran out: %s" % e)
+    return run
+
+
 def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W):
     if S.device_info(0)[2] < 200 << 30:
         pytest.skip("needs ~150 GB of device memory")
@@ -47,6 +63,8 @@ def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W):
     want = np.array([O.synth_row_dot(kind, M, M, K, W, 0, 42, 7, int(g))
                      for g in rows])
 
+    ref = []  # the first kernel's y: every later one must agree with ALL of it
+
     def check(handle, kernel, tag):
         S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
         handle.launch(kernel, d_x.ptr, d_y.ptr)
@@ -55,24 +73,21 @@ def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W):
         assert np.all(np.isfinite(y)), tag
         err = np.max(np.abs(y[rows] - want[:, 0]) / want[:, 1])
         assert err <= TIGHT, (tag, err)
-        return y
+        if not ref:
+            ref.append(y)
+        else:
+            assert np.max(np.abs(y - ref[0])) < 1e-11, tag
 
     return dA, d_x, d_y, check
 
 
-def _agree(ys):
-    ref = ys.pop(next(iter(ys)))
-    for tag, y in ys.items():
-        assert np.max(np.abs(y - ref)) < 1e-11, tag
-
-
+@needs_a_whole_gpu
 def test_at_the_entry_count_limit():
     M = 67_108_863
     assert M * K == 2 ** 31 - 1 - 31
     dA, d_x, d_y, check = _setup(M)
-    ys = {}
     for k in (2, 4, 0, 1, 3):              # every CSR kernel of the seam
-        ys["csr %d" % k] = check(dA, k, "csr kernel %d" % k)
+        check(dA, k, "csr kernel %d" % k)
     # the blocked copy indexes its padded slots with 32 bits: no room here
     with pytest.raises(OSError) as ei:
         dA.build_panels(0)
@@ -84,64 +99,62 @@ def test_at_the_entry_count_limit():
     dA.release()
     assert dH.slots == M * K and dH.num_blocks == (M + 31) // 32
     for k in (1, 2):
-        ys["hll %d" % k] = check(dH, k, "hll col-major kernel %d" % k)
+        check(dH, k, "hll col-major kernel %d" % k)
     for k in (0, 3):
-        ys["hll %d" % k] = check(dR, k, "hll row-major kernel %d" % k)
+        check(dR, k, "hll row-major kernel %d" % k)
     dR.release()
     best, ms = dH.autotune(d_x.ptr, d_y.ptr)
     assert best in (1, 2) and ms > 0
     dH.release()
-    _agree(ys)
     d_x.free()
     d_y.free()
 
 
+@needs_a_whole_gpu
 def test_blocked_path_at_2e9_entries():
     M = 66_000_000
     dA, d_x, d_y, check = _setup(M)
-    ys = {"csr 2": check(dA, 2, "csr sub-wave")}
+    check(dA, 2, "csr sub-wave")
     # the measured selector at this size (several blocked candidates, each
     # built from 2.1e9 keys), then whatever it picked
     best, ms = dA.autotune(d_x.ptr, d_y.ptr)
-    ys["csr autotuned"] = check(dA, best, "csr autotuned %d" % best)
+    check(dA, best, "csr autotuned %d" % best)
     if best != S.CSR_KERNEL_PANELS:
         dA.build_panels(0)
-    ys["csr blocked"] = check(dA, S.CSR_KERNEL_PANELS, "csr blocked")
+    check(dA, S.CSR_KERNEL_PANELS, "csr blocked")
     assert dA.panels_info()["entries"] == dA.NZ
     dH = dA.to_hll(True)
     dA.release()
     dH.build_panels(0, "sweep")            # the headline's schedule
-    ys["hll blocked sweep"] = check(dH, S.HLL_KERNEL_PANELS, "hll blocked")
+    check(dH, S.HLL_KERNEL_PANELS, "hll blocked")
     assert dH.panels_info()["entries"] == M * K
     dH.release()
-    _agree(ys)
     d_x.free()
     d_y.free()
 
 
+@needs_a_whole_gpu
 def test_half_a_billion_rows():
     M = 1 << 29
     dA, d_x, d_y, check = _setup(M, S.SYNTH_RAGGED, 3, 4096)
     assert 2 * M <= dA.NZ <= 4 * M and dA.NZ < 2 ** 31
-    ys = {}
     for k in (2, 4, 0, 1, 3):
-        ys["csr %d" % k] = check(dA, k, "csr kernel %d" % k)
+        check(dA, k, "csr kernel %d" % k)
     dA.build_panels(0, "chain")
     info = dA.panels_info()
     assert info["entries"] == dA.NZ and info["tiles"] * info["panels"] > 1 << 27
-    ys["csr blocked"] = check(dA, S.CSR_KERNEL_PANELS, "csr blocked chain")
+    check(dA, S.CSR_KERNEL_PANELS, "csr blocked chain")
     dH = dA.to_hll(True)
     dR = dA.to_hll(False)
     dA.release()
     assert dH.num_blocks == M // 32 and dH.slots >= dH.NZ
     for k in (1, 2):
-        ys["hll %d" % k] = check(dH, k, "hll col-major kernel %d" % k)
+        check(dH, k, "hll col-major kernel %d" % k)
     for k in (0, 3):
-        ys["hll %d" % k] = check(dR, k, "hll row-major kernel %d" % k)
+        check(dR, k, "hll row-major kernel %d" % k)
     dR.release()
     dH.build_panels(0, "chain")
-    ys["hll blocked"] = check(dH, S.HLL_KERNEL_PANELS, "hll blocked chain")
+    check(dH, S.HLL_KERNEL_PANELS, "hll blocked chain")
     dH.release()
-    _agree(ys)
     d_x.free()
     d_y.free()
