@@ -307,6 +307,19 @@ __global__ void k_synth_lens(synth_spec s, int *lens) {
         lens[i] = synth_row_len(&s, s.row0 + i);
 }
 
+/* Rows of the power-law family and the hub row draw every column on its own
+ * (synth_col_strat: stratified, ascending by construction), so a long one
+ * can be filled by many lanes instead of one walking 10^5..10^8 entries (a
+ * hub row of 131 072 entries was 79 ms of generation, one of 2.7e8 three
+ * minutes) -- the same functions per entry, the same matrix. */
+#define SYNTH_PARALLEL_ROW 4096
+__host__ __device__ static inline bool synth_row_is_parallel(const synth_spec *s,
+                                                             int64_t g, int len) {
+    return len > SYNTH_PARALLEL_ROW &&
+           (s->kind == SYNTH_POWERLAW ||
+            (s->kind == SYNTH_HUB && g == synth_hub_row(s)));
+}
+
 /* one lane per row; rows are short, the insertion sort runs in place */
 __global__ void k_synth_rows(synth_spec s, const int *irp, int *ja,
                              double *as) {
@@ -314,7 +327,27 @@ __global__ void k_synth_rows(synth_spec s, const int *irp, int *ja,
     if (i >= s.M)
         return;
     int beg = irp[i], len = irp[i + 1] - beg;
+    if (synth_row_is_parallel(&s, s.row0 + i, len))
+        return; /* k_synth_long_rows */
     synth_fill_row(&s, s.row0 + i, len, ja + beg, as + beg);
+}
+
+/* grid (long rows, chunks): the workgroups of a row stride over its entries */
+__global__ void k_synth_long_rows(synth_spec s, const int *irp,
+                                  const int *rows, int *ja, double *as) {
+    const int i = rows[blockIdx.x];
+    const int64_t g = s.row0 + i;
+    const int beg = irp[i], len = irp[i + 1] - beg;
+    int64_t lo = 0, hi = s.N;
+    if (s.kind != SYNTH_HUB)
+        synth_window(&s, g, &lo, &hi);
+    int *cols = ja + beg;
+    double *vals = as + beg;
+    for (int64_t j = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; j < len;
+         j += (int64_t)gridDim.y * blockDim.x) {
+        cols[j] = synth_col_strat(&s, g, (int)j, len, lo, hi);
+        vals[j] = synth_val(&s, g, (int)j);
+    }
 }
 
 /* CSR -> HLL on the device: per-block width, then slot fill */
@@ -328,6 +361,37 @@ __global__ void k_block_width(int M, const int *irp, int *width) {
         width[row / 32] = len;
 }
 
+/* a hack block is as wide as its longest row: with one lane per row the 32
+ * lanes of a hub block walk 10^5..10^8 slots each (93 ms of a 1M-row
+ * conversion).  Blocks beyond HLL_FILL_WIDE columns are filled a lane per
+ * SLOT instead (grid: wide blocks x chunks) -- same slots, same pad rule */
+#define HLL_FILL_WIDE 2048
+__global__ void k_hll_fill_wide(int M, int col_major, const int *wide_blocks,
+                                const int *irp, const int *cja,
+                                const double *cas, const int64_t *off, int *ja,
+                                double *as, unsigned *padmask) {
+    const int b = wide_blocks[blockIdx.x];
+    const int rows = min(32, M - b * 32);
+    const int64_t o = off[b];
+    const int64_t n = off[b + 1] - o;
+    const int w = (int)(n / rows);
+    for (int64_t q = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; q < n;
+         q += (int64_t)gridDim.y * blockDim.x) {
+        const int i = col_major ? (int)(q % rows) : (int)(q / w);
+        const int j = col_major ? (int)(q / rows) : (int)(q % w);
+        const int beg = irp[b * 32 + i], len = irp[b * 32 + i + 1] - beg;
+        const int64_t t = o + q;
+        if (j < len) {
+            ja[t] = cja[beg + j];
+            as[t] = cas[beg + j];
+        } else { /* pad -> the row's last valid column, or 0 (hip_hll.h) */
+            ja[t] = len > 0 ? cja[beg + len - 1] : 0;
+            as[t] = 0.0;
+            atomicOr(padmask + (t >> 5), 1u << (t & 31));
+        }
+    }
+}
+
 __global__ void k_hll_fill(int M, int col_major, const int *irp,
                            const int *cja, const double *cas,
                            const int64_t *off, int *ja, double *as,
@@ -339,6 +403,8 @@ __global__ void k_hll_fill(int M, int col_major, const int *irp,
     int rows = min(32, M - b * 32);
     int64_t o = off[b];
     int w = (int)((off[b + 1] - o) / rows);
+    if (w > HLL_FILL_WIDE)
+        return; /* k_hll_fill_wide */
     int beg = irp[row], len = irp[row + 1] - beg;
     int last = 0; /* pad -> previous valid column, or 0 (hip_hll.h) */
     for (int j = 0; j < w; ++j) {
@@ -587,6 +653,39 @@ int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
         hipLaunchKernelGGL(k_synth_rows, dim3((M + 127) / 128), dim3(128), 0,
                            0, s, d->irp, d->ja, d->as);
     HIP_TRY(hipGetLastError());
+    {
+        std::vector<int> long_rows;
+        int longest = 0;
+        for (int i = 0; i < M; ++i) {
+            const int len = irp[(size_t)i + 1] - irp[i];
+            if (synth_row_is_parallel(&s, row0 + i, len)) {
+                long_rows.push_back(i);
+                longest = std::max(longest, len);
+            }
+        }
+        if (!long_rows.empty()) {
+            int *d_rows = NULL;
+            HIP_TRY(hipMalloc((void **)&d_rows, long_rows.size() * sizeof(int)));
+            hipError_t e = hipMemcpy(d_rows, long_rows.data(),
+                                     long_rows.size() * sizeof(int),
+                                     hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                const int chunks = std::min(1024, (longest + 4095) / 4096);
+                hipLaunchKernelGGL(k_synth_long_rows,
+                                   dim3((unsigned)long_rows.size(), chunks),
+                                   dim3(256), 0, 0, s, d->irp, d_rows, d->ja,
+                                   d->as);
+                e = hipGetLastError();
+                if (e == hipSuccess)
+                    e = hipDeviceSynchronize();
+            }
+            (void)hipFree(d_rows);
+            if (e != hipSuccess) {
+                rc = hip_errno(e);
+                goto fail;
+            }
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
     rc = finish_csr_handle(d, irp.data());
     if (rc)
@@ -1110,6 +1209,22 @@ int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
                            M, d->col_major, A->irp, A->ja, A->as, d->off,
                            d->ja, d->as, d->padmask);
         HIP_TRY(hipGetLastError());
+        std::vector<int> wide;
+        for (int b = 0; b < nb; ++b)
+            if (w[b] > HLL_FILL_WIDE)
+                wide.push_back(b);
+        if (!wide.empty()) {
+            /* d_w (the widths) has done its job: reuse it for the list */
+            HIP_TRY(hipMemcpy(d_w, wide.data(), wide.size() * sizeof(int),
+                              hipMemcpyHostToDevice));
+            const int64_t most = (int64_t)32 * maxw;
+            const int chunks = (int)std::min<int64_t>(1024, (most + 8191) / 8192);
+            hipLaunchKernelGGL(k_hll_fill_wide,
+                               dim3((unsigned)wide.size(), chunks), dim3(256), 0,
+                               0, M, d->col_major, d_w, A->irp, A->ja, A->as,
+                               d->off, d->ja, d->as, d->padmask);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipDeviceSynchronize());
     }
     (void)hipFree(d_w);

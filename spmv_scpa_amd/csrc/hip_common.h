@@ -214,6 +214,15 @@ __device__ __forceinline__ double wave_ordered_sum(const double *part, int n,
     return s;
 }
 
+/* Columns of hack block b (`rows` = its row count).  The slot count is 64-bit:
+ * a hub block of 2^27 columns holds 2^32 slots, and `(unsigned)(off[b + 1] -
+ * off[b])` -- a 32-bit division is cheaper -- silently halved such a block */
+__device__ __forceinline__ int hack_block_width(const int64_t *__restrict__ off,
+                                                int b, int rows) {
+    const uint64_t n = (uint64_t)(off[b + 1] - off[b]);
+    return rows == HACK_SIZE ? (int)(n >> 5) : (int)(n / (unsigned)rows);
+}
+
 /* Thread `tid` of NT sums as[k] * x[ja[k]] over k = beg + tid, + NT, ... < end
  * in THAT order (one accumulator: the bits do not depend on U), with the loads
  * of U entries in flight at a time.  The plain loop is two dependent memory

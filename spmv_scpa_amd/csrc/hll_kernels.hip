@@ -100,7 +100,7 @@ __global__ void k_hll_row_major(int M, int b0, int b1, int wide,
     if (i >= rows)
         return;
     int64_t o = off[b];
-    int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    int w = hack_block_width(off, b, rows);
     if (wide > 0 && w > wide)
         return;
     const int *rj = ja + o + (int64_t)i * w;
@@ -158,8 +158,7 @@ __global__ void k_hll_col_direct(int M, int b0, int b1, int wide, xcd_ranges xr,
     if (i >= rows)
         return;
     const int64_t o = off[b];
-    const unsigned len = (unsigned)(off[b + 1] - o);
-    const int w = rows == HACK ? (int)(len >> 5) : (int)(len / (unsigned)rows);
+    const int w = hack_block_width(off, b, rows);
     if (wide > 0 && w > wide)
         return;
     const int *cj = ja + o + i;
@@ -266,15 +265,14 @@ __global__ void k_hll_col_lds(int b0, int b1, int wide, xcd_ranges xr,
         return;
     const bool hasB = bA + 1 < b1;
     const int64_t oA = off[bA], oB = off[bA + 1];
-    int nA = (int)(oB - oA); /* slots of block A = 32 * wA */
-    int nB = hasB ? (int)(off[bA + 2] - oB) : 0;
+    /* slots of block A = 32 * wA; 64-bit until the wide blocks are out (a
+     * hub block of 2^26 columns and more does not fit an int) */
+    const int64_t nA64 = oB - oA, nB64 = hasB ? off[bA + 2] - oB : 0;
     /* a wide block of the pair is k_hll_wide's: nothing read, nothing stored */
-    const bool skipA = wide > 0 && (nA >> 5) > wide;
-    const bool skipB = wide > 0 && (nB >> 5) > wide;
-    if (skipA)
-        nA = 0;
-    if (skipB)
-        nB = 0;
+    const bool skipA = wide > 0 && (nA64 >> 5) > wide;
+    const bool skipB = wide > 0 && (nB64 >> 5) > wide;
+    const int nA = skipA ? 0 : (int)nA64;
+    const int nB = skipB ? 0 : (int)nB64;
     const int half = lane >> 5, i = lane & 31;
     const int w = (half ? nB : nA) >> 5;
     const int nmax = nA > nB ? nA : nB;
@@ -354,7 +352,7 @@ __global__ void k_hll_subwave_row(int M, int b0, int b1, int wide,
             int rows = min(HACK, M - b * HACK);
             if (i < rows) {
                 int64_t o = off[b];
-                int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+                int w = hack_block_width(off, b, rows);
                 live = !(wide > 0 && w > wide);
                 const int *rj = ja + o + (int64_t)i * w;
                 const double *ra = as + o + (int64_t)i * w;
@@ -391,7 +389,7 @@ __global__ void __launch_bounds__(256)
         return; /* another launch of a chunked exchange owns this block */
     const int rows = min(HACK, M - b * HACK);
     const int64_t o = off[b];
-    const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    const int w = hack_block_width(off, b, rows);
     const int j0 = min(kseg * segw, w), j1 = min(j0 + segw, w);
     /* col-major: a wavefront reads two columns x 32 rows, each 256 B
      * contiguous; row-major: eight neighbouring columns of a row per 8 lanes */

@@ -260,7 +260,7 @@ __global__ void k_keys_from_hll(int M, int nb, int64_t slots, int tile_rows,
     const int b = lo;
     const int rows = min(32, M - b * 32);
     const int64_t local = t - off[b];
-    const int w = (int)((unsigned)(off[b + 1] - off[b]) / (unsigned)rows);
+    const int w = hack_block_width(off, b, rows);
     const int i = col_major ? (int)(local % rows) : (int)(local / w);
     const int row = b * 32 + i;
     const uint64_t tile = (uint64_t)(row / tile_rows);
@@ -363,7 +363,7 @@ __global__ void k_tile_gather_hll(int64_t n, int M, int nb, int tile_rows,
     }
     const int rows = min(32, M - lo * 32);
     const unsigned rel = (unsigned)((int64_t)t - off[lo]);
-    const unsigned w = (unsigned)(off[lo + 1] - off[lo]) / (unsigned)rows;
+    const unsigned w = (unsigned)hack_block_width(off, lo, rows);
     const int i = col_major ? (int)(rel % (unsigned)rows) : (int)(rel / w);
     tent[dst] = ((unsigned)((lo * 32 + i) % tile_rows) << shift) |
                 ((unsigned)ja[t] & ((1u << shift) - 1u));
@@ -630,7 +630,7 @@ __global__ void k_long_rows_hll(int M, int limit, int cap, int col_major,
         const int b = (int)(row >> 5), i = (int)(row & 31);
         const int rows = min(32, M - b * 32);
         const int64_t o = off[b];
-        const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+        const int w = hack_block_width(off, b, rows);
         if (w <= limit)
             continue;
         int len = 0;
@@ -681,7 +681,7 @@ __global__ void k_long_copy_hll(int M, int col_major,
     const int b = row >> 5, i = row & 31;
     const int rows = min(32, M - b * 32);
     const int64_t o = off[b];
-    const int w = (int)((unsigned)(off[b + 1] - o) / (unsigned)rows);
+    const int w = hack_block_width(off, b, rows);
     int dst = long_ptr[h];
     for (int j0 = 0; j0 < w; j0 += WAVE) {
         const int j = j0 + lane;

@@ -18,6 +18,13 @@ per HLL layout, 26 GB for the blocked copy) -- 6.7 times config 3.
   than a launch holds, so those kernels walk the rows grid-stride; 16.8M hack
   blocks; 131 072 row tiles x 2048 panels of the blocked copy.
 
+* INT32_MAX columns (x of 17 GB, 8192 panels of the blocked copy), columns
+  anywhere: column indices up to the int32 limit.
+* a hub row of 268 435 455 entries (INT32_MAX / 8 columns of a 1M-row matrix,
+  CSR): 131 072 segments of the stream kernel and of the direct kernels' side
+  launch, 262 144 beside the blocked copy, their partial sums added up by one
+  wavefront each; as HLL a hack block of 8.6e9 slots (103 GB).
+
 Against rows recomputed from the workload definition by the oracle."""
 import errno
 
@@ -48,20 +55,21 @@ def needs_a_whole_gpu(test):
     return run
 
 
-def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W):
+def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W, N=0, row0=0):
     if S.device_info(0)[2] < 200 << 30:
         pytest.skip("needs ~150 GB of device memory")
-    dA = S.CsrDevice.generate(kind, M, M, K, W, 0, 42)
+    N = N or M
+    dA = S.CsrDevice.generate(kind, M, N, K, W, row0, 42)   # rows row0 .. + M
     assert kind != S.SYNTH_RANDOM or dA.NZ == M * K
-    d_x, d_y = S.DevBuffer(M * 8), S.DevBuffer(M * 8)
-    S.dev_fill_synth(d_x.ptr, M, 7)
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
     rng = np.random.default_rng(5)
     rows = np.unique(np.concatenate([
-        [0, 31, 32, M - 33, M - 32, M - 1],
+        [0, 31, 32, M // 3, M - 33, M - 32, M - 1],
         rng.integers(0, M, 1_500),
         rng.integers(M - 100_000, M, 500)]))   # entry indices next to 2^31
-    want = np.array([O.synth_row_dot(kind, M, M, K, W, 0, 42, 7, int(g))
-                     for g in rows])
+    want = np.array([O.synth_row_dot(kind, row0 + M, N, K, W, 0, 42, 7,
+                                     row0 + int(g)) for g in rows])
 
     ref = []  # the first kernel's y: every later one must agree with ALL of it
 
@@ -76,7 +84,9 @@ def _setup(M, kind=S.SYNTH_RANDOM, K=K, W=W):
         if not ref:
             ref.append(y)
         else:
-            assert np.max(np.abs(y - ref[0])) < 1e-11, tag
+            # (relative to the row's magnitude: a row of 2.7e8 entries is
+            # ~1e4 in size, and the summation orders differ)
+            assert np.max(np.abs(y - ref[0]) / (1.0 + np.abs(ref[0]))) < 1e-11, tag
 
     return dA, d_x, d_y, check
 
@@ -155,6 +165,58 @@ def test_half_a_billion_rows():
     dR.release()
     dH.build_panels(0, "chain")
     check(dH, S.HLL_KERNEL_PANELS, "hll blocked chain")
+    dH.release()
+    d_x.free()
+    d_y.free()
+
+
+@needs_a_whole_gpu
+def test_two_billion_columns():
+    M, N = 2_000_000, 2 ** 31 - 1
+    dA, d_x, d_y, check = _setup(M, S.SYNTH_RANDOM, 32, 1 << 40, N)
+    for k in (2, 4, 0, 1):
+        check(dA, k, "csr kernel %d" % k)
+    for sched in ("chain", "sweep"):
+        dA.build_panels(0, sched)
+        assert dA.panels_info()["panels"] == 8192
+        check(dA, S.CSR_KERNEL_PANELS, "csr blocked " + sched)
+    dH = dA.to_hll(True)
+    dA.release()
+    for k in (1, 2):
+        check(dH, k, "hll col-major kernel %d" % k)
+    best, ms = dH.autotune(d_x.ptr, d_y.ptr)
+    check(dH, best, "hll autotuned %d" % best)
+    dH.release()
+    d_x.free()
+    d_y.free()
+
+
+@needs_a_whole_gpu
+def test_a_hub_row_of_a_quarter_billion_entries():
+    M, N = 1_000_000, 2 ** 31 - 1
+    # the family's hub row is global row N / 3: a shard of rows around it,
+    # the hub at local row M / 3 (which _setup always probes)
+    dA, d_x, d_y, check = _setup(M, S.SYNTH_HUB, 6, 4096, N,
+                                 row0=N // 3 - M // 3)
+    assert dA.NZ > N // 8
+    for k in (4, 2, 0, 1, 3):              # stream segments / k_csr_long_seg
+        check(dA, k, "csr kernel %d" % k)
+    dA.build_panels(0, "chain")            # the row beside the copy
+    assert "long row(s) beside" in dA.panels_describe()
+    check(dA, S.CSR_KERNEL_PANELS, "csr blocked chain")
+    best, ms = dA.autotune(d_x.ptr, d_y.ptr)
+    check(dA, best, "csr autotuned %d" % best)
+    # ... and as HLL: the hub's hack block alone is 32 x 268M slots (103 GB,
+    # filled a lane per slot); its columns go to k_hll_wide in 512 segments
+    # of 524 288; the blocked copy cannot index 8.6e9 source slots
+    dH = dA.to_hll(True)
+    dA.release()
+    assert dH.slots > 32 * (N // 8)
+    for k in (1, 2):
+        check(dH, k, "hll col-major kernel %d" % k)
+    with pytest.raises(OSError) as ei:
+        dH.build_panels(0)
+    assert ei.value.errno == errno.EOVERFLOW
     dH.release()
     d_x.free()
     d_y.free()
