@@ -39,14 +39,21 @@ if [ "$part" = "passes" ]; then
     echo "== passes done"; exit 0
 fi
 # counter passes run the layout of an UN-profiled selector run (--blocked-pin)
-pinned() {  # pinned <tag> <bench args...>: prints "--blocked-pin <pin>" or nothing
-    local tag="$1"; shift
-    python3 bench.py --no-extras --no-cpu-baseline --steps 5 "$@" \
-        > "gpurun_out/${round}_pin_$tag.json" 2> /dev/null || return 0
-    local pin; pin=$(python3 tools/blocked_pin.py "gpurun_out/${round}_pin_$tag.json")
+# -- the layout of the workload's trace pass when this call took it (`all`), so
+# that every record of a workload describes ONE layout; else a fresh run's
+pinned() {  # pinned <tag> <prof tag> <bench args...>: "--blocked-pin <pin>" or nothing
+    local tag="$1" prof="gpurun_out/prof_${round}_$2/bench_kt.json"; shift 2
+    local src="gpurun_out/${round}_pin_$tag.json"
+    if [ -s "$prof" ]; then
+        src="$prof"
+    else
+        python3 bench.py --no-extras --no-cpu-baseline --steps 5 "$@" \
+            > "$src" 2> /dev/null || return 0
+    fi
+    local pin; pin=$(python3 tools/blocked_pin.py "$src")
     [ -n "$pin" ] && echo "--blocked-pin $pin"
 }
-PIN_WN=$(pinned wn)
+PIN_WN=$(pinned wn wn_hll_tile_panels)
 step tools/pmc.sh "${round}_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
     bench.py --no-extras --no-cpu-baseline --steps 20 $PIN_WN
 step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_l2req" \
@@ -55,7 +62,7 @@ step tools/pmc.sh "${round}_tcc" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
     bench.py --no-extras --no-cpu-baseline --steps 20 $PIN_WN
 # the same request counters for the power-law matrix (what bounds 22 %) ...
 PL="--family powerlaw --rows-per-gpu 4000000 --nnz-row 3"
-PIN_PL=$(pinned pl $PL)
+PIN_PL=$(pinned pl powerlaw4M $PL)
 step tools/pmc.sh "${round}_pl_l2req" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
     bench.py --no-extras --no-cpu-baseline --steps 20 $PL $PIN_PL
 step python3 tools/l2req_profile.py "gpurun_out/pmc_${round}_pl_l2req" \
