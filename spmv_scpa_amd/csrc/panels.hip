@@ -1165,8 +1165,12 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         HIP_TRY(hipMemcpy(&total, P->bptr + buckets, sizeof total,
                           hipMemcpyDeviceToHost));
     }
-    if (total + SWEEP_TAIL > (int64_t)INT32_MAX) {
-        rc = -EOVERFLOW; /* the kernels index slots with 32 bits */
+    /* The kernels index the copy's slots with UNSIGNED 32 bits (fk / fe /
+     * blk, `fk + CH >= fe`): room for every matrix the API can describe
+     * (INT32_MAX entries) plus its bucket padding, as long as `slot + chunk`
+     * cannot wrap -- 3e9 leaves 1.29e9 of head room for a chunk of 16 Ki. */
+    if (total + SWEEP_TAIL > (int64_t)3000000000LL) {
+        rc = -EOVERFLOW;
         goto fail;
     }
     P->total = total;
