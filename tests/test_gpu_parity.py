@@ -947,6 +947,53 @@ def test_long_rows_at_every_threshold_stream_segments_and_blocked_side_path():
     S.csr_free(A)
 
 
+def test_more_long_rows_than_the_side_path_takes():
+    """6000 rows of 17 000 entries each: every row is beyond the blocked
+    copy's long-row threshold (16 384), but more of them than the side path
+    holds (PANELS_LONG_MAX = 4096) -- they stay in the buckets; every row is
+    cut into segments by the CSR stream kernel / k_csr_long_seg; as HLL every
+    hack block is wide (k_hll_wide does all the work, 67 segments per block).
+    Whole y against the oracle, every kernel."""
+    rng = np.random.default_rng(17)
+    M, N, L = 6_000, 200_000, 17_000
+    IRP = (np.arange(M + 1, dtype=np.int64) * L).astype(np.int32)
+    JA = np.sort(rng.integers(0, N, (M, L), dtype=np.int32), axis=1).ravel()
+    AS = rng.uniform(-1, 1, M * L)
+    x = O.synth_x(7, 0, N)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("all_long", M, N, IRP, JA, AS)
+    dA = S.CsrDevice.upload(A)
+    d_x, d_y = S.DevBuffer.from_numpy(x), S.DevBuffer(M * 8)
+
+    def run(h, k, tag, **kw):
+        S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+        h.launch(k, d_x.ptr, d_y.ptr, **kw)
+        S.stream_sync()
+        assert_parity(d_y.to_numpy(np.float64, M), y_ref, scale, tag)
+
+    for k in range(5):
+        run(dA, k, ("all long csr", k))
+    for sched in ("chain", "sweep", "steps"):
+        dA.build_panels(0, sched)
+        assert "long row(s) beside" not in dA.panels_describe()
+        assert dA.panels_info()["entries"] == M * L
+        run(dA, S.CSR_KERNEL_PANELS, ("all long blocked", sched))
+    for cm in (True, False):
+        dH = dA.to_hll(cm)
+        for k in range(S.NUM_HLL_KERNELS):
+            if S.HLL_KERNEL_COL_MAJOR[k] == cm:
+                run(dH, k, ("all long hll", k), waves_per_block=4)
+        if cm:
+            dH.build_panels(0, "chain")
+            run(dH, S.HLL_KERNEL_PANELS, ("all long hll blocked",))
+        dH.release()
+    dA.release()
+    S.csr_free(A)
+    d_x.free()
+    d_y.free()
+
+
 def test_config3_ragged_variant_full_size():
     """SURVEY 8d, secondary variant of config 3: row lengths uniform in
     [24, 40] (mean 32) so that the HLL form carries pads (S > nnz).  10M x 10M,
