@@ -32,9 +32,10 @@ def want_ablations(argv):
 if want_ablations(sys.argv) and not os.environ.get("SPMV_LIB"):
     import subprocess
     abl = os.path.join(ROOT, "spmv_scpa_amd", "lib", "libspmv_scpa_amd_abl.so")
-    if not os.path.exists(abl):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "spmv_scpa_amd",
-                                                   "csrc"), "abl"], check=True)
+    # always through make: a no-op when the flavour is up to date, a rebuild
+    # when a kernel source is newer than it (a stale flavour times old code)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "spmv_scpa_amd",
+                                                     "csrc"), "abl"], check=True)
     os.environ["SPMV_LIB"] = abl
 import spmv_scpa_amd as S  # noqa: E402
 
