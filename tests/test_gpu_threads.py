@@ -73,3 +73,49 @@ def test_two_host_threads_two_handles_two_streams():
         dA.release()
         d_x.free()
         d_y.free()
+
+
+def test_two_host_threads_upload_build_and_tune_at_the_same_time():
+    """... "may upload, build, tune and launch DIFFERENT handles
+    concurrently": generation, CSR -> HLL, the selector (its block pool and
+    phase log are per thread, its sorts share the default stream) and the
+    launch of its pick, in two threads at once; y against the oracle's rows.
+    What the selectors pick under each other's load is not the point."""
+    specs = [(S.SYNTH_HUB, 400_000, 6, 4096), (S.SYNTH_RANDOM, 600_000, 32, 1 << 30)]
+    errors = []
+    start = threading.Barrier(len(specs))
+
+    def worker(kind, M, K, W):
+        try:
+            rows = np.unique(np.concatenate(
+                [[0, M // 3, M - 1], np.random.default_rng(2).integers(0, M, 300)]))
+            want = np.array([O.synth_row_dot(kind, M, M, K, W, 0, 42, 7, int(g))
+                             for g in rows])
+            start.wait()
+            for rep in range(3):
+                dA = S.CsrDevice.generate(kind, M, M, K, W, 0, 42)
+                dH = dA.to_hll(True)
+                d_x, d_y = S.DevBuffer(M * 8), S.DevBuffer(M * 8)
+                S.dev_fill_synth(d_x.ptr, M, 7)
+                for h in (dA, dH):
+                    best, ms = h.autotune(d_x.ptr, d_y.ptr)
+                    assert ms > 0 and "total" in h.tune_log()
+                    S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                    h.launch(best, d_x.ptr, d_y.ptr)
+                    S.stream_sync()
+                    y = d_y.to_numpy(np.float64, M)
+                    err = np.max(np.abs(y[rows] - want[:, 0]) / want[:, 1])
+                    assert err <= 1e-12, (kind, rep, best, err)
+                dH.release()
+                dA.release()
+                d_x.free()
+                d_y.free()
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=s) for s in specs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
