@@ -234,21 +234,12 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
     }
 }
 
-/* one lane per SLOT (a lane per row walks a hack block as wide as its
- * longest row: 32 lanes x 500 000 steps for a hub row, 0.14-0.33 s per build):
- * the block of slot t is found by bisection in off[], row and column slot
- * follow from the layout; writes are coalesced */
-__global__ void k_keys_from_hll(int M, int nb, int64_t slots, int tile_rows,
-                                int panels, int shift, int pm_grid,
-                                uint64_t nbuckets,
-                                const int *__restrict__ long_row, int nlong,
-                                int col_major, const int64_t *__restrict__ off,
-                                const int *__restrict__ ja,
-                                const unsigned *__restrict__ padmask,
-                                uint64_t *key, unsigned *idx) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= slots)
-        return;
+/* HLL source, one lane per SLOT (a lane per row walks a hack block as wide as
+ * its longest row: 32 lanes x 500 000 steps for a hub row, 0.14-0.33 s per
+ * build).  Row of stored slot t: its block by bisection in off[], the row
+ * inside the block from the layout */
+__device__ __forceinline__ int hll_slot_row(int64_t t, int M, int nb, int col_major,
+                                            const int64_t *__restrict__ off) {
     int lo = 0, hi = nb; /* largest b with off[b] <= t */
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -257,26 +248,63 @@ __global__ void k_keys_from_hll(int M, int nb, int64_t slots, int tile_rows,
         else
             hi = mid;
     }
-    const int b = lo;
-    const int rows = min(32, M - b * 32);
-    const int64_t local = t - off[b];
-    const int w = hack_block_width(off, b, rows);
-    const int i = col_major ? (int)(local % rows) : (int)(local / w);
-    const int row = b * 32 + i;
+    const int rows = min(32, M - lo * 32);
+    const int64_t local = t - off[lo];
+    const int w = hack_block_width(off, lo, rows);
+    return lo * 32 + (col_major ? (int)(local % rows) : (int)(local / w));
+}
+
+/* One lane per STORED slot: does it hold an entry of the copy?  Only PAD
+ * slots are left out (bitmap written when the pads were rewritten,
+ * hll_kernels.hip) -- an explicit zero is an entry like any other, exactly
+ * as from a CSR source -- and the slots of a long row, which is kept beside
+ * the copy.  The kept slots are then COMPACTED before anything is sorted:
+ * the format pads (slots / nnz = 8.6 on the KKT matrix, 10 on the power-law
+ * rows), and 24 bytes of sort buffers per STORED slot were both the build's
+ * time (the first multi-GB hipMalloc of a selector run: 1.3 s) and its
+ * memory. */
+__global__ void k_hll_keep_flags(int M, int nb, int64_t slots,
+                                 const int *__restrict__ long_row, int nlong,
+                                 int col_major, const int64_t *__restrict__ off,
+                                 const unsigned *__restrict__ padmask,
+                                 unsigned char *flag,
+                                 unsigned long long *count) {
+    /* grid-stride, one atomic per wavefront at the END (a count per 64 slots
+     * would be 5M atomics on one address for the headline matrix: 50 ms) */
+    unsigned long long mine = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < slots;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        bool keep = !((padmask[t >> 5] >> (t & 31)) & 1u);
+        if (keep && nlong > 0)
+            keep = !in_sorted(long_row, nlong,
+                              hll_slot_row(t, M, nb, col_major, off));
+        flag[t] = keep ? 1 : 0;
+        mine += keep;
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1)
+        mine += __shfl_down(mine, d, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && mine)
+        atomicAdd(count, mine);
+}
+
+/* key of kept slot idx[r] (the list the compaction wrote, ascending) */
+__global__ void k_keys_from_hll(int M, int nb, int64_t n, int tile_rows,
+                                int panels, int shift, int pm_grid,
+                                int col_major, const int64_t *__restrict__ off,
+                                const int *__restrict__ ja, int identity,
+                                unsigned *idx, uint64_t *key) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n)
+        return;
+    if (identity) /* every stored slot is kept: no list was compacted */
+        idx[r] = (unsigned)r;
+    const int64_t t = idx[r];
+    const int row = hll_slot_row(t, M, nb, col_major, off);
     const uint64_t tile = (uint64_t)(row / tile_rows);
-    const uint64_t dropped = nbuckets << shift;
     const unsigned low = (1u << shift) - 1u;
-    /* only PAD slots are dropped (bitmap written when the pads were
-     * rewritten, hll_kernels.hip); an explicit zero is an entry like any
-     * other, exactly as from a CSR source -- and the slots of a long row,
-     * which is kept beside the copy */
     const unsigned c = (unsigned)ja[t];
-    const bool pad = ((padmask[t >> 5] >> (t & 31)) & 1u) ||
-                     (nlong > 0 && in_sorted(long_row, nlong, row));
-    key[t] = !pad ? (bucket_id(tile, c >> shift, panels, pm_grid) << shift) |
-                        (c & low)
-                  : dropped;
-    idx[t] = (unsigned)t;
+    key[r] = (bucket_id(tile, c >> shift, panels, pm_grid) << shift) | (c & low);
 }
 
 /*
@@ -1041,7 +1069,9 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     size_t tmp_bytes = 0;
     int64_t *raw = NULL, *padded = NULL; /* unpadded bucket starts, scan input */
     int *span = NULL;                    /* per-tile first / last panel */
-    const size_t n = (size_t)(slots > 0 ? slots : 1);
+    int64_t n_sort = slots; /* sorted pairs: every CSR entry / every KEPT HLL slot */
+    unsigned char *flag = NULL;
+    unsigned long long *d_count = NULL;
     int64_t total = 0;
     double tp[5] = {build_now_s(), 0, 0, 0, 0};
     g_build_phases[0] = 0;
@@ -1050,27 +1080,67 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                            as, padmask);
     if (rc)
         goto fail;
-    for (int k = 0; k < 2; ++k) {
-        HIP_TRY(big_malloc((void **)&key[k], n * sizeof(uint64_t)));
-        HIP_TRY(big_malloc((void **)&idx[k], n * sizeof(unsigned)));
+    if (!irp_or_null && slots > 0) {
+        /* HLL source: flag the slots that hold entries, count them, compact
+         * their indices (ascending) into idx[0] -- see k_hll_keep_flags */
+        unsigned long long h_count = 0;
+        HIP_TRY(big_malloc((void **)&flag, (size_t)slots));
+        HIP_TRY(hipMalloc((void **)&d_count, sizeof *d_count));
+        HIP_TRY(hipMemset(d_count, 0, sizeof *d_count));
+        hipLaunchKernelGGL(k_hll_keep_flags,
+                           dim3((unsigned)std::min<int64_t>((slots + 255) / 256,
+                                                            8192)),
+                           dim3(256), 0,
+                           0, M, nb, slots, P->long_row, P->nlong, col_major,
+                           off_or_null, padmask, flag, d_count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(&h_count, d_count, sizeof h_count,
+                          hipMemcpyDeviceToHost));
+        n_sort = (int64_t)h_count;
+    }
+    {
+        const size_t na = (size_t)(n_sort > 0 ? n_sort : 1);
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(big_malloc((void **)&key[k], na * sizeof(uint64_t)));
+            HIP_TRY(big_malloc((void **)&idx[k], na * sizeof(unsigned)));
+        }
     }
     skey = key[0];
     sidx = idx[0];
     if (slots > 0) {
-        if (irp_or_null)
+        if (irp_or_null) {
             hipLaunchKernelGGL(k_keys_from_csr,
                                dim3((unsigned)std::min<long long>(
                                    ((long long)M * 8 + 255) / 256, 1 << 23)),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
                                pm_grid, (uint64_t)nbuckets, P->long_row,
                                P->nlong, irp_or_null, ja, key[0], idx[0]);
-        else
+        } else if (n_sort > 0) {
+            const int identity = n_sort == slots; /* the format padded nothing */
+            if (!identity) {
+                void *st = NULL;
+                size_t stb = 0;
+                hipcub::CountingInputIterator<unsigned> every_slot(0u);
+                /* the count is known: d_count is only written again */
+                HIP_TRY(hipcub::DeviceSelect::Flagged(st, stb, every_slot, flag,
+                                                      idx[0], d_count,
+                                                      (int)slots, 0));
+                HIP_TRY(big_malloc(&st, stb ? stb : 16));
+                hipError_t e1 = hipcub::DeviceSelect::Flagged(
+                    st, stb, every_slot, flag, idx[0], d_count, (int)slots, 0);
+                if (e1 == hipSuccess)
+                    e1 = hipDeviceSynchronize();
+                big_free(st);
+                HIP_TRY(e1);
+            }
+            big_free(flag); /* 1 byte per stored slot: not needed any more */
+            flag = NULL;
             hipLaunchKernelGGL(k_keys_from_hll,
-                               dim3((unsigned)((slots + 255) / 256)), dim3(256),
-                               0, 0, M, nb, slots, (int)tr, panels, shift,
-                               pm_grid, (uint64_t)nbuckets, P->long_row,
-                               P->nlong, col_major, off_or_null, ja, padmask,
-                               key[0], idx[0]);
+                               dim3((unsigned)((n_sort + 255) / 256)), dim3(256),
+                               0, 0, M, nb, n_sort, (int)tr, panels, shift,
+                               pm_grid, col_major, off_or_null, ja, identity,
+                               idx[0], key[0]);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         tp[1] = build_now_s();
@@ -1083,10 +1153,10 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             while (end_bit < 64 && (((uint64_t)nbuckets) >> (end_bit - shift)))
                 ++end_bit;
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
-                NULL, tmp_bytes, dk, dv, (int)slots, 0, end_bit, 0));
+                NULL, tmp_bytes, dk, dv, (int)n_sort, 0, end_bit, 0));
             HIP_TRY(big_malloc(&tmp, tmp_bytes ? tmp_bytes : 16));
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
-                tmp, tmp_bytes, dk, dv, (int)slots, 0, end_bit, 0));
+                tmp, tmp_bytes, dk, dv, (int)n_sort, 0, end_bit, 0));
             HIP_TRY(hipDeviceSynchronize());
             skey = dk.Current();
             sidx = dv.Current();
@@ -1103,7 +1173,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                           ((size_t)buckets + 1) * sizeof(int64_t)));
         HIP_TRY(hipMalloc((void **)&P->blen, ((size_t)buckets + 1) * sizeof(int)));
         hipLaunchKernelGGL(k_bucket_bounds, dim3(gb), dim3(256), 0, 0, buckets,
-                           slots, shift, skey, raw);
+                           n_sort, shift, skey, raw);
         hipLaunchKernelGGL(k_bucket_sizes, dim3(gb), dim3(256), 0, 0, buckets,
                            (int64_t)256, raw, P->blen, padded);
         HIP_TRY(hipGetLastError());
@@ -1209,9 +1279,9 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     }
     tp[4] = build_now_s();
     snprintf(g_build_phases, sizeof g_build_phases,
-             "%lld slots sorted: alloc+keys %.3f s, sort %.3f, bucket tables "
-             "%.3f, gather %.3f",
-             (long long)slots, tp[1] > 0 ? tp[1] - tp[0] : 0.0,
+             "%lld of %lld slots sorted: alloc+keys %.3f s, sort %.3f, bucket "
+             "tables %.3f, gather %.3f",
+             (long long)n_sort, (long long)slots, tp[1] > 0 ? tp[1] - tp[0] : 0.0,
              tp[1] > 0 ? tp[2] - tp[1] : 0.0, tp[3] - tp[2], tp[4] - tp[3]);
     *out = P;
     P = NULL;
@@ -1221,6 +1291,8 @@ fail:
         big_free(idx[k]);
     }
     big_free(tmp);
+    big_free(flag);
+    (void)hipFree(d_count);
     (void)hipFree(raw);
     (void)hipFree(padded);
     (void)hipFree(span);
