@@ -1100,7 +1100,10 @@ def main(argv=None):
         labels, prefix = S.HLL_KERNEL_LABELS, "hll_"
     else:
         labels, prefix = S.CSR_KERNEL_LABELS, "csr_"
-    pinned = bool(args.blocked_pin) and not use_dist
+    if args.blocked_pin and use_dist:
+        raise SystemExit("--blocked-pin pins ONE rank's layout for the "
+                         "profiling passes: single GPU only")
+    pinned = bool(args.blocked_pin)
     if pinned:
         kernel = (S.HLL_KERNEL_PANELS if args.format == "hll"
                   else S.CSR_KERNEL_PANELS)
