@@ -1560,9 +1560,11 @@ def native_mgpu_bench(args, argv, omp_team):
     g = S.MultiGpu(n)
     g.generate(kind, Mloc, K, W, MATRIX_SEED, as_hll=args.format == "hll")
     g.fill_x(X_SEED)
-    # exchange: chunked + overlapped for the direct kernels (like the torch
-    # path's "staged" mode), after the kernel for the blocked path
-    chunks = args.chunks if args.chunks > 0 else (4 if n > 1 else 1)
+    # exchange: ONE grouped in-place all-gather after the shard kernels.  The
+    # chunked, overlapped "staged" mode is opt-in (--chunks k): it has only
+    # ever run as a 1-rank collective (spmv_mgpu.h), and the first real N > 1
+    # run should not go down the most complex branch by default
+    chunks = args.chunks if args.chunks > 0 else 1
     g.set_exchange(chunks, args.force_exchange)
     labels, prefix = ((S.HLL_KERNEL_LABELS, "hll_") if args.format == "hll"
                       else (S.CSR_KERNEL_LABELS, "csr_"))

@@ -113,6 +113,24 @@ void csr_free(sparse_csr *A);
  */
 int *partition_rows_nnz(const sparse_csr *A, int *parts);
 int *partition_rows_even(int M, int parts, int align);
+/*
+ * The multi-GPU form of the nnz-balanced cut (modelled on the
+ * reference's partition_csr_rows, csr.c:218-276): `parts` contiguous row
+ * ranges of near-equal entry counts whose boundaries are multiples of
+ * `align` rows (32: no HLL hack block straddles two GPUs).  Cut k is the
+ * aligned boundary whose prefix entry count is nearest to k/parts of the
+ * total -- prefix targets instead of the reference's per-range running
+ * count, which hands every overshoot to the last range.  `parts` never
+ * shrinks; no range is empty while M >= parts * align (with fewer aligned
+ * blocks than parts the trailing ranges are empty, as in
+ * partition_rows_even).  IRP = row offsets of the whole matrix (M + 1).
+ * Returns malloc'ed starts[parts+1] or ERR_PTR(-EINVAL / -ENOMEM).
+ */
+int *partition_rows_nnz_aligned(const int *IRP, int M, int parts, int align);
+/* the same cut for a synthetic family (spmv_synth.h) of M global rows,
+ * from the generator's row lengths -- no matrix is materialised */
+int *partition_synth_rows_nnz(int kind, int M, int N, int K, int64_t W,
+                              uint64_t seed, int parts, int align);
 
 /* ---- CPU benchmarks (reference csr.c:342-380) ---- */
 int bench_csr_serial(const sparse_csr *A, const double *x, bench *out);

@@ -345,6 +345,11 @@ void spmv_hll_release_checked(spmv_hll_dev *H, uint64_t generation);
 
 /* Library self-description: "spmv_scpa_amd <version> gfx950". */
 const char *spmv_version(void);
+/* HIP_VERSION (major * 10^7 + minor * 10^5 + patch) of the headers the library
+ * was built with / of the runtime the process has bound it to (-EIO when the
+ * runtime does not answer).  Majors must agree. */
+int spmv_hip_build_version(void);
+int spmv_hip_runtime_version(void);
 /* "product", or "ablations": built with -DSPMV_ABLATIONS (`make abl` ->
  * lib/libspmv_scpa_amd_abl.so), the only flavour that accepts the experiment
  * bits of spmv_launch_opts.variant (timing ablations, some of which compute a

@@ -6,6 +6,14 @@
  * multi-GPU path; this is what `spmv_scpa_amd -g N` runs.  (bench.py does
  * the same with one process per GPU through torch.distributed.)
  *
+ * Partitions: equal row counts (default), or near-equal ENTRY
+ * counts -- the multi-GPU form of the reference's partition_csr_rows
+ * (csr.c:218-276; partition_rows_nnz_aligned, csr.h).  With the latter the
+ * devices own different row counts, y holds exactly M rows and the ragged
+ * fragments travel by grouped ncclSend/ncclRecv (default), one ncclBroadcast
+ * per device, or one ncclAllGather padded to the longest fragment + a
+ * compaction copy (spmv_mgpu_set_ragged_exchange).
+ *
  * All functions return 0 or a negative errno (-ENODEV: fewer GPUs than
  * asked for).  Every entry point restores the caller's current HIP device; a
  * handle may be loaded / generated again (the previous shards are freed).
@@ -35,13 +43,51 @@ typedef struct spmv_mgpu spmv_mgpu;
 /* devices 0..ngpus-1, one RCCL communicator (ncclCommInitAll), one stream each */
 int spmv_mgpu_create(int ngpus, spmv_mgpu **out);
 void spmv_mgpu_destroy(spmv_mgpu *g);
+/* REHEARSAL handle, test infrastructure: `nlogical` (<= 64) logical devices
+ * spread over the visible card(s) -- all on ONE card of a 1-GPU box -- and NO
+ * communicator (RCCL refuses two ranks on one device): the exchange is plain
+ * device-to-device copies between the logical devices' y buffers.  Partition,
+ * row offsets, empty ranges, per-device launches and the assembled y run
+ * exactly as on a node; the RCCL calls do not, and its timings mean nothing.
+ * spmv_mgpu_comm_ranks() returns 0 for it. */
+int spmv_mgpu_create_rehearsal(int nlogical, spmv_mgpu **out);
+
+enum spmv_mgpu_partition_kind {
+    SPMV_MGPU_PART_EVEN = 0, /* equal row counts (rounded up to 32) */
+    SPMV_MGPU_PART_NNZ = 1   /* near-equal entry counts, 32-aligned cuts */
+};
+enum spmv_mgpu_ragged_exchange {
+    SPMV_MGPU_XCHG_P2P = 0,   /* grouped ncclSend / ncclRecv, in place */
+    SPMV_MGPU_XCHG_BCAST = 1, /* one in-place ncclBroadcast per device */
+    SPMV_MGPU_XCHG_PADDED = 2 /* ncclAllGather of `longest` rows + compaction */
+};
 
 /* shard a host matrix by rows; as_hll != 0: col-major HLL shards (kernel 1/2) */
 int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll);
+/* ... with the partition named (spmv_mgpu_load_csr = _PART_EVEN).  A range
+ * may be empty when the matrix has fewer 32-row blocks than devices. */
+int spmv_mgpu_load_csr_part(spmv_mgpu *g, const sparse_csr *A, int as_hll,
+                            int partition);
 /* weak scaling: every device generates rows_per_gpu (multiple of 32) rows of
  * the (rows_per_gpu*ngpus)-square synthetic matrix (spmv_synth.h) */
 int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
                        int64_t W, uint64_t seed, int as_hll);
+/* ... or, _PART_NNZ, its share of the ENTRIES of that matrix (cut from the
+ * generator's row lengths, partition_synth_rows_nnz) */
+int spmv_mgpu_generate_part(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
+                            int64_t W, uint64_t seed, int as_hll,
+                            int partition);
+
+/* how RAGGED fragments travel (enum spmv_mgpu_ragged_exchange; default
+ * _XCHG_P2P).  Persists over reloads; the even partition keeps its in-place
+ * all-gather.  With force (spmv_mgpu_set_exchange) _BCAST and _PADDED run
+ * with one device too (1-rank collectives); _P2P has no peer then. */
+int spmv_mgpu_set_ragged_exchange(spmv_mgpu *g, int kind);
+
+/* the partition in use: starts[ngpus+1] row offsets and entries[ngpus] true
+ * entries per device (either may be NULL); returns 1 when the ranges differ
+ * (ragged fragments), 0 for the even partition, < 0 on a bad handle */
+int spmv_mgpu_partition(const spmv_mgpu *g, int *starts, int64_t *entries);
 
 int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host); /* N doubles */
 int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed);       /* synth_x on device */
@@ -61,8 +107,9 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
 int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
                   double *wall_ms_total, double *kernel_ms_avg);
 
-/* How the fragments of y travel.  chunks = 1 (default): one grouped in-place
- * ncclAllGather after the shard kernels.  chunks = 2..16: the shard's rows in
+/* How the fragments of y travel (even partition).  chunks = 1 (default, and
+ * what `spmv_scpa_amd -g N` and bench.py --native-mgpu run unless asked
+ * otherwise): one grouped in-place ncclAllGather after the shard kernels.  chunks = 2..16: the shard's rows in
  * that many equal pieces; chunk c of every device is all-gathered on a second
  * stream (chunk-major staging buffer, one strided copy back at the end) while
  * the kernel of chunk c+1 runs -- direct kernels only; the blocked path runs
@@ -94,6 +141,8 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel);
 /* the gathered y as device `rank` holds it (M doubles, row order) */
 int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host);
 
+/* rows_per_gpu = the longest range; bytes_per_gpu = algorithmic bytes of the
+ * heaviest shard (what bounds a step) */
 int spmv_mgpu_info(const spmv_mgpu *g, int *ngpus, int *rows_per_gpu,
                    int64_t *nnz_total, int64_t *bytes_per_gpu);
 

@@ -78,17 +78,150 @@ def _share_the_rocm_runtime_with_torch():
     if not spec or not spec.submodule_search_locations:
         return None
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    # A bundled copy can stand in for /opt/rocm's only if the loader will
+    # take it for the name this library asks for: its DT_SONAME must equal our
+    # DT_NEEDED entry (libamdhip64.so.7, librccl.so.1, libgomp.so.1).  Another
+    # SONAME (a torch wheel built for another ROCm major) would map BOTH
+    # runtimes -- the very state this function removes -- so such a copy is
+    # not preloaded, and the import says so.
+    _, needed = _elf_dynamic(LIB_PATH)
     loaded = []
     for name in ("libgomp.so", "libamdhip64.so", "librccl.so"):
         path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_LOCAL)
-            loaded.append(path)
+        if not os.path.exists(path):
+            continue
+        soname, _ = _elf_dynamic(path)
+        want = [n for n in needed if n.startswith(name)]
+        if want and soname != want[0]:
+            import warnings
+            warnings.warn(
+                "spmv_scpa_amd: torch bundles %s with SONAME %r but "
+                "libspmv_scpa_amd.so needs %r: not sharing torch's ROCm "
+                "runtime (importing torch later in this process would map a "
+                "second one)" % (name, soname, want[0]), RuntimeWarning)
+            return loaded or None
+        C.CDLL(path, mode=C.RTLD_LOCAL)
+        loaded.append(path)
     return loaded or None
+
+
+def _elf_dynamic(path):
+    """(DT_SONAME or None, [DT_NEEDED ...]) of an ELF64 little-endian shared
+    object, read from its section headers; (None, []) when it is not one"""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            eh = f.read(64)
+            if eh[:6] != b"\x7fELF\x02\x01":
+                return None, []
+            shoff, = struct.unpack_from("<Q", eh, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", eh, 0x3A)
+            f.seek(shoff)
+            sh = [struct.unpack_from("<IIQQQQIIQQ", f.read(shentsize))
+                  for _ in range(shnum)]
+            dyn = next((s for s in sh if s[1] == 6), None)  # SHT_DYNAMIC
+            if dyn is None or dyn[6] >= len(sh):
+                return None, []
+            f.seek(sh[dyn[6]][4])
+            strtab = f.read(sh[dyn[6]][5])
+            f.seek(dyn[4])
+            raw = f.read(dyn[5])
+    except (OSError, struct.error):
+        return None, []
+
+    def name(off):
+        return strtab[off:strtab.index(b"\0", off)].decode()
+
+    soname, needed = None, []
+    for i in range(0, len(raw) - 15, 16):
+        tag, val = struct.unpack_from("<qQ", raw, i)
+        if tag == 0:
+            break
+        if tag == 1:
+            needed.append(name(val))
+        elif tag == 14:
+            soname = name(val)
+    return soname, needed
+
+
+def mapped_rocm_runtimes():
+    """{library: sorted real paths} of the HIP / RCCL / HSA runtimes mapped
+    into this process right now (/proc/self/maps): one path each in a healthy
+    process, whatever the import order"""
+    seen = {}
+    try:
+        with open("/proc/self/maps") as f:
+            lines = f.read().splitlines()
+    except OSError:
+        lines = []
+    for line in lines:
+        m = re.search(r"(/\S+\.so\S*)$", line.strip())
+        if m:
+            base = re.sub(r"\.so.*", ".so", os.path.basename(m.group(1)))
+            if base in ("libamdhip64.so", "librccl.so", "libhsa-runtime64.so"):
+                seen.setdefault(base, set()).add(os.path.realpath(m.group(1)))
+    return {k: sorted(v) for k, v in seen.items()}
+
+
+def _fmt_hip(v):
+    return "%d.%d.%d" % (v // 10_000_000, v // 100_000 % 100, v % 100_000)
+
+
+def rocm_runtime_report():
+    """what this process runs the library on: the HIP version it was built
+    against, the one the bound runtime reports, whether torch's bundled
+    runtime is shared, and every runtime copy mapped (bench.py prints it)"""
+    built = _lib.spmv_hip_build_version()
+    run = _lib.spmv_hip_runtime_version()
+    maps = mapped_rocm_runtimes()
+    return {"hip_built": _fmt_hip(built),
+            "hip_runtime": _fmt_hip(run) if run > 0 else None,
+            "shared_with_torch": bool(ROCM_RUNTIME_SHARED_WITH_TORCH),
+            "runtimes_mapped": {k: len(v) for k, v in maps.items()},
+            "hip_library": (maps.get("libamdhip64.so") or [None])[0]}
+
+
+def _check_the_bound_runtime():
+    """after loading: exactly one copy of each runtime library mapped (a file
+    read; no HIP call is made at import -- a process that only imports, like
+    a launcher, must not initialise the GPU runtime)"""
+    import warnings
+    twice = {k: v for k, v in mapped_rocm_runtimes().items() if len(v) > 1}
+    if twice:
+        warnings.warn("spmv_scpa_amd: more than one copy of the ROCm runtime "
+                      "is mapped into this process: %r -- objects may be "
+                      "destroyed by two owners at exit" % (twice,),
+                      RuntimeWarning)
+    return not twice
+
+
+_versions_checked = False
+
+
+def _check_the_hip_version_once():
+    """first device query: the HIP runtime the library is bound to must have
+    the major version it was built with (a minor difference -- /opt/rocm's
+    headers, torch's bundled runtime -- is reported by rocm_runtime_report(),
+    not refused)"""
+    global _versions_checked
+    if _versions_checked:
+        return
+    _versions_checked = True
+    built = _lib.spmv_hip_build_version()
+    run = _lib.spmv_hip_runtime_version()
+    if run > 0 and run // 10_000_000 != built // 10_000_000:
+        import warnings
+        warnings.warn("spmv_scpa_amd: built against HIP %s, bound to a HIP %s "
+                      "runtime" % (_fmt_hip(built), _fmt_hip(run)),
+                      RuntimeWarning)
 
 
 ROCM_RUNTIME_SHARED_WITH_TORCH = _share_the_rocm_runtime_with_torch()
 _lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)  # never RTLD_GLOBAL: see above
+for _n in ("spmv_hip_build_version", "spmv_hip_runtime_version"):
+    getattr(_lib, _n).restype = C.c_int
+    getattr(_lib, _n).argtypes = []
+ROCM_RUNTIME_ONCE = _check_the_bound_runtime()
 
 MAX_NAME = 64
 HACK_SIZE = 32
@@ -211,6 +344,9 @@ _sig("csr_row_slice", _CSRp, _CSRp, C.c_int, C.c_int)
 _sig("extract_matrix_name", None, C.c_char_p, C.c_char_p)
 _sig("partition_rows_nnz", _ip, _CSRp, _ip)
 _sig("partition_rows_even", _ip, C.c_int, C.c_int, C.c_int)
+_sig("partition_rows_nnz_aligned", _ip, _ip, C.c_int, C.c_int, C.c_int)
+_sig("partition_synth_rows_nnz", _ip, C.c_int, C.c_int, C.c_int, C.c_int,
+     C.c_int64, C.c_uint64, C.c_int, C.c_int)
 _sig("csr_to_hll", _HLLp, _CSRp, C.c_bool)
 _sig("hll_free", None, _HLLp)
 _sig("hll_num_slots", C.c_int64, _HLLp)
@@ -404,6 +540,7 @@ if os.environ.get("SPMV_DEBUG", "") not in ("", "0"):
 
 
 def device_count():
+    _check_the_hip_version_once()
     return _lib.spmv_device_count()
 
 
@@ -598,6 +735,32 @@ def partition_rows_nnz(A, parts):
 def partition_rows_even(M, parts, align=HACK_SIZE):
     p = _ptr_or_raise(_lib.partition_rows_even(M, parts, align),
                       "partition_rows_even")
+    out = np.ctypeslib.as_array(p, (parts + 1,)).copy()
+    _libc_free(p)
+    return out
+
+
+def partition_rows_nnz_aligned(IRP, parts, align=HACK_SIZE):
+    """multi-GPU nnz-balanced cut (csr.h): starts[parts+1], boundaries
+    multiples of `align`; IRP = the whole matrix's row offsets (or a
+    sparse_csr pointer)"""
+    if isinstance(IRP, _CSRp):
+        M, irp = IRP.contents.M, IRP.contents.IRP
+    else:
+        IRP = np.ascontiguousarray(IRP, dtype=np.int32)
+        M, irp = len(IRP) - 1, IRP.ctypes.data_as(_ip)
+    p = _ptr_or_raise(_lib.partition_rows_nnz_aligned(irp, M, parts, align),
+                      "partition_rows_nnz_aligned")
+    out = np.ctypeslib.as_array(p, (parts + 1,)).copy()
+    _libc_free(p)
+    return out
+
+
+def partition_synth_rows_nnz(kind, M, N, K, W, seed, parts, align=HACK_SIZE):
+    """the same cut from a synthetic family's row lengths (no matrix built)"""
+    p = _ptr_or_raise(
+        _lib.partition_synth_rows_nnz(kind, M, N, K, W, seed, parts, align),
+        "partition_synth_rows_nnz")
     out = np.ctypeslib.as_array(p, (parts + 1,)).copy()
     _libc_free(p)
     return out
@@ -843,6 +1006,10 @@ class CsrDevice:
         # the generation the library gave this handle: release_checked() acts
         # only on THAT handle, never on a newer one at a recycled address
         self.gen = _lib.spmv_handle_generation(self.h)
+        if not self.gen:  # not a live handle: release_checked would be a
+            #               silent no-op and the device memory would leak
+            raise OSError(9, "spmv_handle_generation: %r is not a live "
+                             "handle of this library" % (self.h,))
         M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
         _check(_lib.spmv_csr_shape(self.h, C.byref(M), C.byref(N),
                                    C.byref(NZ)), "spmv_csr_shape")
@@ -1010,6 +1177,10 @@ class HllDevice:
     def __init__(self, handle):
         self.h = handle
         self.gen = _lib.spmv_handle_generation(self.h)
+        if not self.gen:  # not a live handle: release_checked would be a
+            #               silent no-op and the device memory would leak
+            raise OSError(9, "spmv_handle_generation: %r is not a live "
+                             "handle of this library" % (self.h,))
         _live.add(self)
         M, N, NZ = C.c_int(), C.c_int(), C.c_int64()
         nb, S, cm = C.c_int(), C.c_int64(), C.c_int()
@@ -1174,10 +1345,16 @@ def compute_gflops(ms, nnz):
 
 # ---------------------------------------------------------------- multi-GPU (C)
 _sig("spmv_mgpu_create", C.c_int, C.c_int, C.POINTER(C.c_void_p))
+_sig("spmv_mgpu_create_rehearsal", C.c_int, C.c_int, C.POINTER(C.c_void_p))
 _sig("spmv_mgpu_destroy", None, C.c_void_p)
 _sig("spmv_mgpu_load_csr", C.c_int, C.c_void_p, _CSRp, C.c_int)
 _sig("spmv_mgpu_generate", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
      C.c_int64, C.c_uint64, C.c_int)
+_sig("spmv_mgpu_load_csr_part", C.c_int, C.c_void_p, _CSRp, C.c_int, C.c_int)
+_sig("spmv_mgpu_generate_part", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+     C.c_int64, C.c_uint64, C.c_int, C.c_int)
+_sig("spmv_mgpu_set_ragged_exchange", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_mgpu_partition", C.c_int, C.c_void_p, _ip, C.POINTER(C.c_int64))
 _sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
 _sig("spmv_mgpu_fill_x", C.c_int, C.c_void_p, C.c_uint64)
 _sig("spmv_mgpu_spmv", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp)
@@ -1204,9 +1381,16 @@ class MultiGpu:
     h = None
     _RANK = 2
 
-    def __init__(self, ngpus):
+    def __init__(self, ngpus, rehearsal=False):
+        """rehearsal: `ngpus` LOGICAL devices on the visible card(s), no RCCL
+        communicator, copies instead of collectives (spmv_mgpu.h)"""
         h = C.c_void_p()
-        _check(_lib.spmv_mgpu_create(ngpus, C.byref(h)), "spmv_mgpu_create")
+        if rehearsal:
+            _check(_lib.spmv_mgpu_create_rehearsal(ngpus, C.byref(h)),
+                   "spmv_mgpu_create_rehearsal")
+        else:
+            _check(_lib.spmv_mgpu_create(ngpus, C.byref(h)),
+                   "spmv_mgpu_create")
         self.h, self.n = h, ngpus
         _live.add(self)
 
@@ -1216,15 +1400,36 @@ class MultiGpu:
     def _release_now(self):
         self.destroy()
 
-    def load_csr(self, A, as_hll=False):
-        _check(_lib.spmv_mgpu_load_csr(self.h, A, int(as_hll)),
-               "spmv_mgpu_load_csr")
+    PARTITIONS = {"even": 0, "nnz": 1}
+    RAGGED_EXCHANGES = {"p2p": 0, "bcast": 1, "padded": 2}
+
+    def load_csr(self, A, as_hll=False, partition="even"):
+        """partition "nnz": near-equal entries per device (ragged fragments)"""
+        _check(_lib.spmv_mgpu_load_csr_part(
+            self.h, A, int(as_hll), self.PARTITIONS[partition]),
+            "spmv_mgpu_load_csr_part")
         self.M = A.contents.M
 
-    def generate(self, kind, rows_per_gpu, K, W, seed=42, as_hll=True):
-        _check(_lib.spmv_mgpu_generate(self.h, kind, rows_per_gpu, K, W, seed,
-                                       int(as_hll)), "spmv_mgpu_generate")
+    def generate(self, kind, rows_per_gpu, K, W, seed=42, as_hll=True,
+                 partition="even"):
+        _check(_lib.spmv_mgpu_generate_part(
+            self.h, kind, rows_per_gpu, K, W, seed, int(as_hll),
+            self.PARTITIONS[partition]), "spmv_mgpu_generate_part")
         self.M = rows_per_gpu * self.n
+
+    def set_ragged_exchange(self, kind="p2p"):
+        """how ragged fragments travel: p2p | bcast | padded"""
+        _check(_lib.spmv_mgpu_set_ragged_exchange(
+            self.h, self.RAGGED_EXCHANGES[kind]),
+            "spmv_mgpu_set_ragged_exchange")
+
+    def partition(self):
+        """-> (starts[n+1], entries[n], ragged?)"""
+        st = (C.c_int * (self.n + 1))()
+        ent = (C.c_int64 * self.n)()
+        rg = _check(_lib.spmv_mgpu_partition(self.h, st, ent),
+                    "spmv_mgpu_partition")
+        return list(st), list(ent), bool(rg)
 
     def set_x(self, x):
         x, xp = _as_d(x)

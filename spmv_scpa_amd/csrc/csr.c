@@ -842,6 +842,114 @@ int *partition_rows_even(int M, int parts, int align) {
     return starts;
 }
 
+/*
+ * Cut `nb` consecutive blocks of weight w[] into `parts` contiguous ranges of
+ * near-equal weight: cut k sits at the block boundary whose prefix weight is
+ * nearest to k/parts of the total (the reference's partitioner, csr.c:218-276,
+ * closes a range once its OWN running count reaches total/parts and starts
+ * the next from zero, so every overshoot is taken from the last range; prefix
+ * targets do not drift).  Every range holds at least one block while
+ * nb >= parts; with fewer blocks than parts the trailing ranges are empty.
+ * cut[parts+1] in blocks, cut[0] = 0, cut[parts] = nb.
+ */
+static void cut_blocks_balanced(const int64_t *w, int nb, int parts, int *cut) {
+    int64_t total = 0;
+    for (int b = 0; b < nb; ++b)
+        total += w[b];
+    cut[0] = 0;
+    int b = 0;
+    int64_t pre = 0; /* weight of blocks [0, b) */
+    for (int k = 1; k < parts; ++k) {
+        /* boundaries cut k may take: one block per range either side */
+        int lo = cut[k - 1] + 1, hi = nb - (parts - k);
+        if (nb < parts) { /* not enough blocks: one each, the rest empty */
+            cut[k] = k < nb ? k : nb;
+            continue;
+        }
+        /* target = total * k / parts, compared as pre * parts vs total * k
+         * (total < 2^31 entries x parts <= 2^16: no overflow) */
+        const int64_t tk = total * k;
+        while (b < hi && (pre + w[b]) * parts <= tk)
+            pre += w[b++];
+        /* b = last boundary at or below the target; b + 1 may be nearer */
+        int c = b;
+        if (b < hi && (pre + w[b]) * parts - tk < tk - pre * parts)
+            c = b + 1;
+        if (c < lo)
+            c = lo;
+        if (c > hi)
+            c = hi;
+        while (b < c)
+            pre += w[b++];
+        cut[k] = c;
+    }
+    cut[parts] = nb;
+}
+
+static int *starts_from_cuts(const int *cut, int parts, int align, int M) {
+    int *starts = malloc(((size_t)parts + 1) * sizeof *starts);
+    if (!starts)
+        return ERR_PTR(-ENOMEM);
+    for (int k = 0; k <= parts; ++k) {
+        const long long s = (long long)cut[k] * align;
+        starts[k] = (int)(s < M ? s : M);
+    }
+    return starts;
+}
+
+int *partition_rows_nnz_aligned(const int *IRP, int M, int parts, int align) {
+    if (!IRP || M < 0 || parts < 1 || parts > 65536 || align < 1)
+        return ERR_PTR(-EINVAL);
+    const int nb = (int)(((long long)M + align - 1) / align);
+    int64_t *w = malloc(((size_t)nb + 1) * sizeof *w);
+    int *cut = malloc(((size_t)parts + 1) * sizeof *cut);
+    if (!w || !cut) {
+        free(w);
+        free(cut);
+        return ERR_PTR(-ENOMEM);
+    }
+    for (int b = 0; b < nb; ++b) {
+        const long long r0 = (long long)b * align;
+        const long long r1 = r0 + align < M ? r0 + align : M;
+        w[b] = (int64_t)IRP[r1] - IRP[r0];
+    }
+    cut_blocks_balanced(w, nb, parts, cut);
+    int *starts = starts_from_cuts(cut, parts, align, M);
+    free(w);
+    free(cut);
+    return starts;
+}
+
+int *partition_synth_rows_nnz(int kind, int M, int N, int K, int64_t W,
+                              uint64_t seed, int parts, int align) {
+    if (kind < 0 || kind > SYNTH_KIND_LAST || M < 0 || N < 1 || K < 1 ||
+        parts < 1 || parts > 65536 || align < 1)
+        return ERR_PTR(-EINVAL);
+    const int nb = (int)(((long long)M + align - 1) / align);
+    int64_t *w = malloc(((size_t)nb + 1) * sizeof *w);
+    int *cut = malloc(((size_t)parts + 1) * sizeof *cut);
+    if (!w || !cut) {
+        free(w);
+        free(cut);
+        return ERR_PTR(-ENOMEM);
+    }
+    const synth_spec s = {kind, M, N, K, W, 0, seed};
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < nb; ++b) {
+        const long long r0 = (long long)b * align;
+        const long long r1 = r0 + align < M ? r0 + align : M;
+        int64_t acc = 0;
+        for (long long g = r0; g < r1; ++g)
+            acc += synth_row_len(&s, g);
+        w[b] = acc;
+    }
+    cut_blocks_balanced(w, nb, parts, cut);
+    int *starts = starts_from_cuts(cut, parts, align, M);
+    free(w);
+    free(cut);
+    return starts;
+}
+
 /* ------------------------------------------------------------------ */
 /* CPU kernels (reference csr.c:201-216, 278-339)                       */
 /* ------------------------------------------------------------------ */

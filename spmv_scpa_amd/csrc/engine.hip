@@ -143,7 +143,17 @@ extern "C" {
 
 /* 0.3: spmv_panel_opts.bucket_order; 0.4: spmv_panel_opts.struct_size (first
  * field), spmv_*_release_checked, handle checks on every entry point */
-const char *spmv_version(void) { return "spmv_scpa_amd 0.4 gfx950"; }
+const char *spmv_version(void) { return "spmv_scpa_amd 0.5 gfx950"; }
+
+/* HIP_VERSION of the headers this library was compiled against, and of the
+ * runtime it is bound to now (hipRuntimeGetVersion; needs no device).  The
+ * binding compares them: a process that maps torch's bundled runtime runs
+ * this library on THAT build of HIP (__init__.py). */
+int spmv_hip_build_version(void) { return HIP_VERSION; }
+int spmv_hip_runtime_version(void) {
+    int v = 0;
+    return hipRuntimeGetVersion(&v) == hipSuccess ? v : -EIO;
+}
 
 /* "product", or "ablations" for a -DSPMV_ABLATIONS build (make abl): only
  * that flavour understands the experiment bits of spmv_launch_opts.variant */

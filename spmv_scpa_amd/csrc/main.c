@@ -35,7 +35,11 @@ static struct {
     int rows, nnz_row, iters, cpu, gpus, only_mgpu;
     long long window;
     bool debug;
-} opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, 0, false};
+    int partition; /* SPMV_MGPU_PART_EVEN / _NNZ */
+    int xchg;      /* SPMV_MGPU_XCHG_*: how ragged fragments travel */
+    int chunks;    /* > 1: opt-in staged exchange (even partition only) */
+} opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, 0, false,
+         SPMV_MGPU_PART_EVEN, SPMV_MGPU_XCHG_P2P, 1};
 
 static sparse_csr *A;
 static sparse_hll *H_row, *H_col;
@@ -277,8 +281,14 @@ static void run_gpu(void) {
 
 /*
  * -g N: the matrix is cut into N contiguous row ranges (multiples of 32
- * rows), one per GPU; a step = every shard's kernel + an RCCL all-gather of
- * the y fragments.  Rows go to roofline.csv with gpus = N.
+ * rows), one per GPU -- equal row counts, or with `--partition nnz`
+ * near-equal entry counts (the multi-GPU form of the reference's
+ * partition_csr_rows, csr.c:218-276) -- a step = every shard's kernel + the
+ * exchange of the y fragments over RCCL: one in-place all-gather (even
+ * partition) or the ragged exchange chosen by --ragged-exchange.  The
+ * overlapped "staged" exchange is opt-in (--exchange-chunks k): it has only
+ * ever run as a 1-rank collective (spmv_mgpu.h).  Rows go to roofline.csv
+ * with gpus = N.
  */
 static void run_multi_gpu(void) {
     spmv_mgpu *g = NULL;
@@ -294,11 +304,30 @@ static void run_multi_gpu(void) {
             if (rc)
                 break;
         }
-        rc = spmv_mgpu_load_csr(g, A, fmt);
-        if (!rc) /* direct kernels: all-gather of chunk c under chunk c+1 */
-            rc = spmv_mgpu_set_exchange(g, opt.gpus > 1 ? 4 : 1, 0);
+        rc = spmv_mgpu_set_ragged_exchange(g, opt.xchg);
+        if (!rc)
+            rc = spmv_mgpu_load_csr_part(g, A, fmt, opt.partition);
+        if (!rc) /* 1: the exchange follows the kernels (default) */
+            rc = spmv_mgpu_set_exchange(g, opt.chunks, 0);
         if (!rc)
             rc = spmv_mgpu_set_x(g, x.data);
+        if (!rc && fmt == 0) { /* what each device holds */
+            int starts[65];
+            int64_t ent[64], lo = INT64_MAX, hi = 0;
+            const int ragged = spmv_mgpu_partition(g, starts, ent);
+            for (int r = 0; r < opt.gpus; ++r) {
+                LOG_INFO("GPU %d: rows [%d, %d), %lld entries", r, starts[r],
+                         starts[r + 1], (long long)ent[r]);
+                if (ent[r] > hi)
+                    hi = ent[r];
+                if (ent[r] < lo)
+                    lo = ent[r];
+            }
+            LOG_INFO("partition %s%s: entries per GPU max / min = %.3f",
+                     opt.partition == SPMV_MGPU_PART_NNZ ? "nnz" : "even",
+                     ragged > 0 ? " (ragged fragments)" : "",
+                     lo > 0 ? (double)hi / (double)lo : 0.0);
+        }
         int kernel = -1;
         if (!rc)
             rc = spmv_mgpu_autotune(g, &kernel);
@@ -319,10 +348,15 @@ static void run_multi_gpu(void) {
             vec_put(&y);
         }
         int64_t nz = 0, bytes = 0;
-        spmv_mgpu_info(g, NULL, NULL, &nz, &bytes);
+        spmv_mgpu_info(g, NULL, NULL, &nz, NULL);
+        for (int r = 0; r < opt.gpus; ++r) { /* shards may differ in size */
+            int64_t b = 0;
+            if (spmv_mgpu_shard_info(g, r, NULL, &b, NULL, 0) == 0)
+                bytes += b;
+        }
         double med = median_of(ms, opt.iters > 0 ? opt.iters : 1);
         log_roofline(A->name, fmt ? "HLL" : "CSR", fmt ? 1 : 2, 8, opt.gpus,
-                     A->M, A->N, nz, nz, bytes * opt.gpus, med);
+                     A->M, A->N, nz, nz, bytes, med);
         LOG_INFO("%d GPU(s) %s: %.4f ms per step (kernel + all-gather), "
                  "%.1f GFLOP/s", opt.gpus, fmt ? "HLL" : "CSR", med,
                  compute_gflops64(med, nz));
@@ -353,6 +387,9 @@ int main(int argc, char **argv) {
         {"iters", required_argument, NULL, 'i'},
         {"gpus", required_argument, NULL, 'g'},
         {"only-multi-gpu", no_argument, NULL, 1003},
+        {"partition", required_argument, NULL, 1004},
+        {"ragged-exchange", required_argument, NULL, 1005},
+        {"exchange-chunks", required_argument, NULL, 1006},
         {"no-cpu", no_argument, NULL, 'C'},
         {"debug", no_argument, NULL, 'd'},
         {"help", no_argument, NULL, 'h'},
@@ -369,6 +406,36 @@ int main(int argc, char **argv) {
         case 'i': opt.iters = atoi(optarg); break;
         case 'g': opt.gpus = atoi(optarg); break;
         case 1003: opt.only_mgpu = 1; break;
+        case 1004:
+            if (!strcmp(optarg, "nnz"))
+                opt.partition = SPMV_MGPU_PART_NNZ;
+            else if (!strcmp(optarg, "even"))
+                opt.partition = SPMV_MGPU_PART_EVEN;
+            else {
+                LOG_ERR("--partition takes even or nnz, not %s", optarg);
+                return EXIT_FAILURE;
+            }
+            break;
+        case 1005:
+            if (!strcmp(optarg, "p2p"))
+                opt.xchg = SPMV_MGPU_XCHG_P2P;
+            else if (!strcmp(optarg, "bcast"))
+                opt.xchg = SPMV_MGPU_XCHG_BCAST;
+            else if (!strcmp(optarg, "padded"))
+                opt.xchg = SPMV_MGPU_XCHG_PADDED;
+            else {
+                LOG_ERR("--ragged-exchange takes p2p, bcast or padded, not %s",
+                        optarg);
+                return EXIT_FAILURE;
+            }
+            break;
+        case 1006:
+            opt.chunks = atoi(optarg);
+            if (opt.chunks < 1 || opt.chunks > 16) {
+                LOG_ERR("--exchange-chunks takes 1..16");
+                return EXIT_FAILURE;
+            }
+            break;
         case 'C': opt.cpu = 0; break;
         case 'd': opt.debug = true; break;
         case 'h':
@@ -381,6 +448,10 @@ int main(int argc, char **argv) {
     }
     if ((!opt.matrix && !opt.synthetic) || !opt.out_dir) {
         log_prog_usage(basename(argv[0]));
+        return EXIT_FAILURE;
+    }
+    if (opt.gpus < 1 || opt.gpus > 64) {
+        LOG_ERR("--gpus takes 1..64");
         return EXIT_FAILURE;
     }
     if (logger_init(opt.out_dir)) {

@@ -41,6 +41,21 @@ struct spmv_mgpu {
     int chunks, force_exchange;
     int even; /* every shard holds exactly rows_per_gpu rows (no padded last
                  shard): the chunk launches of the staged pipeline need it */
+    /* row ranges: device r owns rows [start[r], start[r+1]).  Even partition:
+     * start[r] = r * rows_per_gpu (y is padded to rows_per_gpu * n so that one
+     * in-place ncclAllGather moves it).  nnz-balanced partition
+     * (partition_rows_nnz_aligned, csr.h): the ranges differ -- `ragged` --
+     * y holds exactly M rows and the fragments travel by `xchg`:
+     * SPMV_MGPU_XCHG_P2P / _BCAST / _PADDED (spmv_mgpu.h) */
+    std::vector<int> start;
+    int ragged, xchg, longest;
+    /* REHEARSAL handle (spmv_mgpu_create_rehearsal): n logical devices on the
+     * visible card(s), no communicator (RCCL refuses two ranks on one device);
+     * the exchange is device-to-device copies between the logical devices'
+     * y buffers.  Tests the partition / offsets / empty-range logic on a
+     * 1-GPU box; its timings mean nothing. */
+    int loopback;
+    std::vector<double *> pad; /* _PADDED: [n][longest] staging per device */
     std::vector<hipStream_t> xstream;
     std::vector<double *> stage;
     std::vector<hipEvent_t> ev_k, ev_x; /* [device * MG_MAX_CHUNKS + chunk] */
@@ -124,11 +139,14 @@ static void drop_shards(spmv_mgpu *g) {
         (void)hipFree(g->x[r]);
         (void)hipFree(g->y[r]);
         (void)hipFree(g->stage[r]);
+        (void)hipFree(g->pad[r]);
         g->csr[r] = NULL;
         g->hll[r] = NULL;
-        g->x[r] = g->y[r] = g->stage[r] = NULL;
+        g->x[r] = g->y[r] = g->stage[r] = g->pad[r] = NULL;
     }
     g->rows_per_gpu = g->M = g->N = 0;
+    g->ragged = g->longest = 0;
+    g->start.assign((size_t)g->n + 1, 0);
 }
 
 extern "C" {
@@ -156,11 +174,22 @@ void spmv_mgpu_destroy(spmv_mgpu *g) {
     delete g;
 }
 
+static int create(int ngpus, int loopback, spmv_mgpu **out);
+
 int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
-    if (!out || ngpus < 1)
+    return create(ngpus, 0, out);
+}
+
+int spmv_mgpu_create_rehearsal(int nlogical, spmv_mgpu **out) {
+    return create(nlogical, 1, out);
+}
+
+static int create(int ngpus, int loopback, spmv_mgpu **out) {
+    if (!out || ngpus < 1 || ngpus > 64)
         return -EINVAL;
     *out = NULL;
-    if (spmv_device_count() < ngpus)
+    const int have = spmv_device_count();
+    if (have < (loopback ? 1 : ngpus))
         return -ENODEV;
     int rc = 0;
     device_guard keep;
@@ -179,15 +208,21 @@ int spmv_mgpu_create(int ngpus, spmv_mgpu **out) {
     g->x.assign(ngpus, NULL);
     g->y.assign(ngpus, NULL);
     g->stage.assign(ngpus, NULL);
+    g->pad.assign(ngpus, NULL);
+    g->start.assign((size_t)ngpus + 1, 0);
+    g->ragged = g->longest = 0;
+    g->xchg = SPMV_MGPU_XCHG_P2P;
     g->xstream.assign(ngpus, NULL);
     g->ev_k.assign((size_t)ngpus * MG_MAX_CHUNKS, NULL);
     g->ev_x.assign((size_t)ngpus * MG_MAX_CHUNKS, NULL);
     g->chunks = 1;
     g->force_exchange = 0;
     g->even = 0;
+    g->loopback = loopback;
     for (int r = 0; r < ngpus; ++r)
-        g->dev[r] = r;
-    NCCL_TRY(ncclCommInitAll(g->comm.data(), ngpus, g->dev.data()));
+        g->dev[r] = loopback ? r % have : r;
+    if (!loopback)
+        NCCL_TRY(ncclCommInitAll(g->comm.data(), ngpus, g->dev.data()));
     for (int r = 0; r < ngpus; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         HIP_TRY(hipStreamCreate(&g->stream[r]));
@@ -206,28 +241,75 @@ fail:
     return rc;
 }
 
+/* y of an even partition is padded to rows_per_gpu * n; a ragged one holds
+ * exactly M rows */
+static size_t y_len(const spmv_mgpu *g) {
+    return g->ragged ? (size_t)g->M : (size_t)g->rows_per_gpu * g->n;
+}
+
+static int alloc_pad(spmv_mgpu *g) {
+    int rc = 0;
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        (void)hipFree(g->pad[r]);
+        g->pad[r] = NULL;
+        if (g->ragged && g->xchg == SPMV_MGPU_XCHG_PADDED && g->longest > 0)
+            HIP_TRY(hipMalloc((void **)&g->pad[r],
+                              (size_t)g->longest * g->n * sizeof(double)));
+    }
+fail:
+    return rc;
+}
+
 static int alloc_vectors(spmv_mgpu *g) {
     int rc = 0;
-    const size_t ny = (size_t)g->rows_per_gpu * g->n; /* padded length */
+    const size_t ny = y_len(g);
     for (int r = 0; r < g->n; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         HIP_TRY(hipMalloc((void **)&g->x[r],
                           (size_t)(g->N > 0 ? g->N : 1) * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&g->y[r], (ny ? ny : 1) * sizeof(double)));
         HIP_TRY(hipMemset(g->y[r], 0, (ny ? ny : 1) * sizeof(double)));
-        if (g->chunks > 1 && ny > 0) /* a reload keeps the exchange setting */
+        if (g->chunks > 1 && ny > 0 && !g->ragged) /* a reload keeps the
+                                                      exchange setting */
             HIP_TRY(hipMalloc((void **)&g->stage[r], ny * sizeof(double)));
     }
+    rc = alloc_pad(g);
 fail:
     return rc;
 }
 
-/* shard a host matrix: contiguous row ranges, boundaries multiples of 32 */
-int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
+/* take over a partition: start[], the longest range, even / ragged */
+static void set_ranges(spmv_mgpu *g, const int *starts, int M, int by_nnz) {
+    g->start.assign(starts, starts + g->n + 1);
+    g->longest = 0;
+    for (int r = 0; r < g->n; ++r)
+        if (starts[r + 1] - starts[r] > g->longest)
+            g->longest = starts[r + 1] - starts[r];
+    g->rows_per_gpu = g->n == 1 ? M : g->longest;
+    /* an nnz partition is handled as ragged even when its ranges happen to be
+     * equal (a uniform matrix; one device): one code path per partition kind */
+    g->ragged = by_nnz != 0;
+    for (int r = 0; r <= g->n; ++r) {
+        const long long ev = (long long)r * g->rows_per_gpu;
+        if (starts[r] != (int)(ev < M ? ev : M))
+            g->ragged = 1;
+    }
+    g->even = !g->ragged && (long long)g->rows_per_gpu * g->n == (long long)M;
+}
+
+/* shard a host matrix: contiguous row ranges, boundaries multiples of 32;
+ * partition: SPMV_MGPU_PART_EVEN (equal row counts) or _NNZ (near-equal entry
+ * counts, partition_rows_nnz_aligned) */
+int spmv_mgpu_load_csr_part(spmv_mgpu *g, const sparse_csr *A, int as_hll,
+                            int partition) {
     MG_OK(g);
-    if (!g || !A)
+    if (!g || !A || (partition != SPMV_MGPU_PART_EVEN &&
+                     partition != SPMV_MGPU_PART_NNZ))
         return -EINVAL;
-    int *starts = partition_rows_even(A->M, g->n, HACK_SIZE);
+    int *starts = partition == SPMV_MGPU_PART_NNZ
+                      ? partition_rows_nnz_aligned(A->IRP, A->M, g->n, HACK_SIZE)
+                      : partition_rows_even(A->M, g->n, HACK_SIZE);
     if (IS_ERR(starts))
         return PTR_ERR(starts);
     int rc = 0;
@@ -236,12 +318,11 @@ int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
     g->M = A->M;
     g->N = A->N;
     g->is_hll = as_hll != 0;
-    g->rows_per_gpu = g->n > 0 ? starts[1] - starts[0] : 0;
-    if (g->n == 1)
-        g->rows_per_gpu = A->M;
-    g->even = (long long)g->rows_per_gpu * g->n == (long long)A->M;
+    set_ranges(g, starts, A->M, partition == SPMV_MGPU_PART_NNZ);
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
+        if (starts[r + 1] == starts[r] && g->n > 1)
+            continue; /* more devices than hack blocks: nothing to run here */
         sparse_csr *S = csr_row_slice(A, starts[r], starts[r + 1]);
         if (IS_ERR(S)) {
             rc = PTR_ERR(S);
@@ -262,23 +343,40 @@ fail:
     return rc;
 }
 
-/* every device generates its own shard (spmv_synth.h), weak scaling */
-int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
-                       int64_t W, uint64_t seed, int as_hll) {
+int spmv_mgpu_load_csr(spmv_mgpu *g, const sparse_csr *A, int as_hll) {
+    return spmv_mgpu_load_csr_part(g, A, as_hll, SPMV_MGPU_PART_EVEN);
+}
+
+/* every device generates its own shard (spmv_synth.h), weak scaling: the
+ * (rows_per_gpu * ngpus)-square matrix cut evenly or -- families with ragged
+ * rows -- by entries (partition_synth_rows_nnz: from the row lengths alone) */
+int spmv_mgpu_generate_part(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
+                            int64_t W, uint64_t seed, int as_hll,
+                            int partition) {
     MG_OK(g);
-    if (!g || rows_per_gpu < 0 || rows_per_gpu % HACK_SIZE)
+    if (!g || rows_per_gpu < 0 || rows_per_gpu % HACK_SIZE ||
+        (long long)rows_per_gpu * g->n > INT32_MAX ||
+        (partition != SPMV_MGPU_PART_EVEN && partition != SPMV_MGPU_PART_NNZ))
         return -EINVAL;
+    const int M = rows_per_gpu * g->n;
+    int *starts = partition == SPMV_MGPU_PART_NNZ && M > 0
+                      ? partition_synth_rows_nnz(kind, M, M, K, W, seed, g->n,
+                                                 HACK_SIZE)
+                      : partition_rows_even(M, g->n, HACK_SIZE);
+    if (IS_ERR(starts))
+        return PTR_ERR(starts);
     int rc = 0;
     device_guard keep;
     drop_shards(g);
-    g->rows_per_gpu = rows_per_gpu;
-    g->even = 1;
-    g->M = g->N = rows_per_gpu * g->n;
+    g->M = g->N = M;
     g->is_hll = as_hll != 0;
+    set_ranges(g, starts, M, partition == SPMV_MGPU_PART_NNZ);
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
-        rc = spmv_csr_generate(kind, rows_per_gpu, g->N, K, W,
-                               (int64_t)r * rows_per_gpu, seed, &g->csr[r]);
+        if (starts[r + 1] == starts[r] && g->n > 1)
+            continue;
+        rc = spmv_csr_generate(kind, starts[r + 1] - starts[r], g->N, K, W,
+                               (int64_t)starts[r], seed, &g->csr[r]);
         if (!rc && as_hll) {
             rc = spmv_hll_from_csr(g->csr[r], 1, &g->hll[r]);
             spmv_csr_release(g->csr[r]);
@@ -288,7 +386,14 @@ int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
     if (!rc)
         rc = alloc_vectors(g);
 fail:
+    free(starts);
     return rc;
+}
+
+int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
+                       int64_t W, uint64_t seed, int as_hll) {
+    return spmv_mgpu_generate_part(g, kind, rows_per_gpu, K, W, seed, as_hll,
+                                   SPMV_MGPU_PART_EVEN);
 }
 
 int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host) {
@@ -332,9 +437,13 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
     int rc = 0, pick = -1;
     device_guard keep;
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
+    if (!g->hll[0] && !g->csr[0])
+        return -EINVAL; /* nothing loaded */
     for (int r = 0; r < g->n && !rc; ++r) {
+        if (!g->hll[r] && !g->csr[r])
+            continue; /* an empty range */
         HIP_TRY(hipSetDevice(g->dev[r]));
-        double *yfrag = g->y[r] + (size_t)r * g->rows_per_gpu;
+        double *yfrag = g->y[r] + (size_t)g->start[r];
         int k = -1;
         rc = g->is_hll
                  ? spmv_hll_autotune(g->hll[r], g->x[r], yfrag, 1, &k, NULL)
@@ -346,6 +455,8 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
      * with its schedule, tile height and build options unless it already
      * holds the same (shards of one matrix run one arrangement) */
     for (int r = 1; r < g->n && !rc && pick == blocked; ++r) {
+        if (!g->hll[r] && !g->csr[r])
+            continue;
         HIP_TRY(hipSetDevice(g->dev[r]));
         const bool same =
             g->is_hll
@@ -368,9 +479,10 @@ fail:
 }
 
 static int launch_shard(spmv_mgpu *g, int r, int kernel);
+static int sync_all(spmv_mgpu *g);
 static int gather_y(spmv_mgpu *g);
 static bool staged(const spmv_mgpu *g, int kernel);
-static int step_staged(spmv_mgpu *g, int kernel);
+static int step_staged(spmv_mgpu *g, int kernel, hipEvent_t *kernels_done);
 
 static double wall_ms_now(void) {
     struct timespec t;
@@ -399,7 +511,7 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
         }
         const double t0 = wall_ms_now();
         if (staged(g, kernel)) {
-            rc = step_staged(g, kernel);
+            rc = step_staged(g, kernel, NULL);
         } else {
             for (int r = 0; r < g->n && !rc; ++r) {
                 HIP_TRY(hipSetDevice(g->dev[r]));
@@ -443,7 +555,8 @@ static bool staged(const spmv_mgpu *g, int kernel) {
      * which a long row makes 100x slower -- whole-shard launches instead */
     if (!g->is_hll && kernel == 4)
         return false;
-    return g->chunks > 1 && g->even && kernel != blocked &&
+    return g->chunks > 1 && g->even && !g->ragged && !g->loopback &&
+           kernel != blocked &&
            (g->n > 1 || g->force_exchange) &&
            g->rows_per_gpu % (g->chunks * HACK_SIZE) == 0 && g->stage[0] != NULL;
 }
@@ -451,8 +564,10 @@ static bool staged(const spmv_mgpu *g, int kernel) {
 /* one step with the overlapped exchange: every device's chunk-c kernel, then
  * (second stream, after that kernel) the grouped all-gather of chunk c, while
  * the compute streams go on with chunk c+1; at the end the compute streams
- * wait for the last gathers and un-stage */
-static int step_staged(spmv_mgpu *g, int kernel) {
+ * wait for the last gathers and un-stage.  kernels_done[r] (may be NULL) is
+ * recorded on device r's compute stream right after its LAST chunk kernel,
+ * i.e. before the wait for the gathers: the kernel time of a device */
+static int step_staged(spmv_mgpu *g, int kernel, hipEvent_t *kernels_done) {
     int rc = 0;
     const int k = g->chunks, ch = g->rows_per_gpu / k;
     for (int c = 0; c < k && !rc; ++c) {
@@ -475,6 +590,8 @@ static int step_staged(spmv_mgpu *g, int kernel) {
             hipEvent_t e = g->ev_k[(size_t)r * MG_MAX_CHUNKS + c];
             HIP_TRY(hipEventRecord(e, g->stream[r]));
             HIP_TRY(hipStreamWaitEvent(g->xstream[r], e, 0));
+            if (c == k - 1 && kernels_done)
+                HIP_TRY(hipEventRecord(kernels_done[r], g->stream[r]));
         }
         if (rc)
             break;
@@ -508,11 +625,120 @@ fail:
 }
 
 static int launch_shard(spmv_mgpu *g, int r, int kernel) {
-    double *yfrag = g->y[r] + (size_t)r * g->rows_per_gpu;
+    double *yfrag = g->y[r] + (size_t)g->start[r];
+    if (!g->hll[r] && !g->csr[r])
+        return 0; /* an empty range */
     return g->is_hll ? spmv_hll_launch(g->hll[r], kernel, NULL, g->x[r], yfrag,
                                        g->stream[r])
                      : spmv_csr_launch(g->csr[r], kernel, NULL, g->x[r], yfrag,
                                        g->stream[r]);
+}
+
+/*
+ * Ragged fragments (nnz-balanced partition).  Every variant is ONE RCCL group
+ * over all devices; every call inside the group is checked and the group is
+ * always closed before an error leaves.
+ *   P2P     device r sends its fragment to each peer and receives each peer's
+ *           fragment straight into place (ncclSend / ncclRecv): exactly M - own
+ *           rows arrive per device, each xGMI link carries one peer's fragment
+ *   BCAST   one in-place ncclBroadcast per device (SURVEY 8e "general case")
+ *   PADDED  the fragment is copied to slot r of a [n][longest] staging buffer,
+ *           one in-place ncclAllGather of `longest` rows, then the peers'
+ *           fragments are copied back into row order
+ */
+static int gather_y_ragged(spmv_mgpu *g) {
+    int rc = 0;
+    ncclResult_t first_bad = ncclSuccess;
+#define GROUPED(call)                                                         \
+    do {                                                                      \
+        const ncclResult_t e_ = (call);                                       \
+        if (e_ != ncclSuccess && first_bad == ncclSuccess)                    \
+            first_bad = e_;                                                   \
+    } while (0)
+    const int L = g->longest;
+    if (g->xchg == SPMV_MGPU_XCHG_PADDED) {
+        if (!g->pad[0])
+            return -EINVAL;
+        for (int r = 0; r < g->n; ++r) {
+            const size_t cnt = (size_t)(g->start[r + 1] - g->start[r]);
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            if (cnt)
+                HIP_TRY(hipMemcpyAsync(g->pad[r] + (size_t)r * L,
+                                       g->y[r] + g->start[r],
+                                       cnt * sizeof(double),
+                                       hipMemcpyDeviceToDevice, g->stream[r]));
+        }
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < g->n; ++r) {
+        if (g->xchg == SPMV_MGPU_XCHG_PADDED) {
+            GROUPED(ncclAllGather(g->pad[r] + (size_t)r * L, g->pad[r],
+                                  (size_t)L, ncclDouble, g->comm[r],
+                                  g->stream[r]));
+            continue;
+        }
+        for (int p = 0; p < g->n; ++p) {
+            const size_t cnt = (size_t)(g->start[p + 1] - g->start[p]);
+            double *frag = g->y[r] + g->start[p];
+            if (!cnt)
+                continue;
+            if (g->xchg == SPMV_MGPU_XCHG_BCAST) {
+                GROUPED(ncclBroadcast(frag, frag, cnt, ncclDouble, p,
+                                      g->comm[r], g->stream[r]));
+            } else if (p == r) { /* P2P: my fragment to every peer */
+                for (int q = 0; q < g->n; ++q)
+                    if (q != r)
+                        GROUPED(ncclSend(frag, cnt, ncclDouble, q, g->comm[r],
+                                         g->stream[r]));
+            } else {
+                GROUPED(ncclRecv(frag, cnt, ncclDouble, p, g->comm[r],
+                                 g->stream[r]));
+            }
+        }
+    }
+    {
+        const ncclResult_t closed = ncclGroupEnd();
+        NCCL_TRY(first_bad);
+        NCCL_TRY(closed);
+    }
+#undef GROUPED
+    if (g->xchg == SPMV_MGPU_XCHG_PADDED) {
+        for (int r = 0; r < g->n; ++r) {
+            HIP_TRY(hipSetDevice(g->dev[r]));
+            for (int p = 0; p < g->n; ++p) {
+                const size_t cnt = (size_t)(g->start[p + 1] - g->start[p]);
+                if (p != r && cnt)
+                    HIP_TRY(hipMemcpyAsync(
+                        g->y[r] + g->start[p], g->pad[r] + (size_t)p * L,
+                        cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                        g->stream[r]));
+            }
+        }
+    }
+fail:
+    return rc;
+}
+
+/* rehearsal handles: every logical device copies every other one's fragment
+ * out of that device's y (all streams drained first: no cross-stream order
+ * is needed, and no timing is claimed) */
+static int gather_y_loopback(spmv_mgpu *g) {
+    int rc = sync_all(g);
+    for (int r = 0; r < g->n && !rc; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        for (int p = 0; p < g->n; ++p) {
+            const size_t cnt = (size_t)(g->start[p + 1] - g->start[p]);
+            if (p != r && cnt)
+                HIP_TRY(hipMemcpyAsync(g->y[r] + g->start[p],
+                                       g->y[p] + g->start[p],
+                                       cnt * sizeof(double), hipMemcpyDefault,
+                                       g->stream[r]));
+        }
+    }
+    if (!rc)
+        rc = sync_all(g);
+fail:
+    return rc;
 }
 
 /* one grouped in-place all-gather of y over all devices (n > 1) */
@@ -520,6 +746,10 @@ static int gather_y(spmv_mgpu *g) {
     int rc = 0;
     if (g->n < 2 && !g->force_exchange)
         return 0;
+    if (g->loopback)
+        return gather_y_loopback(g);
+    if (g->ragged)
+        return gather_y_ragged(g);
     /* every call inside the group is checked, and the group is ALWAYS closed
      * before an error leaves this function */
     NCCL_TRY(ncclGroupStart());
@@ -564,7 +794,7 @@ int spmv_mgpu_set_exchange(spmv_mgpu *g, int chunks, int force) {
     device_guard keep;
     g->chunks = chunks;
     g->force_exchange = force != 0;
-    const size_t ny = (size_t)g->rows_per_gpu * g->n;
+    const size_t ny = g->ragged ? 0 : y_len(g);
     for (int r = 0; r < g->n; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         (void)hipFree(g->stage[r]);
@@ -574,6 +804,34 @@ int spmv_mgpu_set_exchange(spmv_mgpu *g, int chunks, int force) {
     }
 fail:
     return rc;
+}
+
+/* how RAGGED fragments travel (see gather_y_ragged); the setting persists
+ * over reloads; an even partition keeps its in-place all-gather */
+int spmv_mgpu_set_ragged_exchange(spmv_mgpu *g, int kind) {
+    MG_OK(g);
+    if (kind != SPMV_MGPU_XCHG_P2P && kind != SPMV_MGPU_XCHG_BCAST &&
+        kind != SPMV_MGPU_XCHG_PADDED)
+        return -EINVAL;
+    device_guard keep;
+    const int rc0 = sync_all(g);
+    if (rc0)
+        return rc0;
+    g->xchg = kind;
+    return alloc_pad(g);
+}
+
+/* the partition in use: starts[ngpus + 1] row offsets, entries[ngpus] true
+ * entries per device (either may be NULL); returns 1 when the ranges differ
+ * (ragged fragments), 0 for the even partition */
+int spmv_mgpu_partition(const spmv_mgpu *g, int *starts, int64_t *entries) {
+    MG_OK(g);
+    for (int r = 0; r <= g->n && starts; ++r)
+        starts[r] = g->start[r];
+    for (int r = 0; r < g->n && entries; ++r)
+        entries[r] = g->hll[r] ? g->hll[r]->NZ
+                               : (g->csr[r] ? g->csr[r]->NZ : 0);
+    return g->ragged;
 }
 
 int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
@@ -600,19 +858,17 @@ int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
             *wall_ms_total = wall_ms_now();
         }
         if (staged(g, kernel)) {
-            /* events around the whole step of a device's compute stream: the
-             * chunk kernels and the un-staging copy (the gathers overlap) */
+            /* events around a device's chunk kernels: from before the first
+             * to right after the last, BEFORE its stream waits for the gathers
+             * (those overlap the kernels; the un-staging copy is exchange) */
+            std::vector<hipEvent_t> done((size_t)g->n, NULL);
             for (int r = 0; r < g->n && it >= 0; ++r) {
                 HIP_TRY(hipSetDevice(g->dev[r]));
                 HIP_TRY(hipEventRecord(ev[((size_t)r * steps + it) * 2],
                                        g->stream[r]));
+                done[r] = ev[((size_t)r * steps + it) * 2 + 1];
             }
-            rc = step_staged(g, kernel);
-            for (int r = 0; r < g->n && it >= 0 && !rc; ++r) {
-                HIP_TRY(hipSetDevice(g->dev[r]));
-                HIP_TRY(hipEventRecord(ev[((size_t)r * steps + it) * 2 + 1],
-                                       g->stream[r]));
-            }
+            rc = step_staged(g, kernel, it >= 0 ? done.data() : NULL);
             continue;
         }
         for (int r = 0; r < g->n && !rc; ++r) {
@@ -657,7 +913,7 @@ int spmv_mgpu_exchange_only(spmv_mgpu *g, int iters, double *ms_avg) {
         return -EINVAL;
     device_guard keep;
     *ms_avg = 0.0;
-    if (g->n < 2)
+    if (g->n < 2 && !g->force_exchange)
         return 0;
     int rc = gather_y(g); /* warm */
     if (!rc)
@@ -679,6 +935,8 @@ int spmv_mgpu_rccl_version(void) {
 
 int spmv_mgpu_comm_ranks(const spmv_mgpu *g) {
     MG_OK(g);
+    if (g->loopback)
+        return 0; /* a rehearsal handle has no communicator */
     if (!g || g->comm.empty() || !g->comm[0])
         return -EINVAL;
     int n = 0;
@@ -733,13 +991,16 @@ int spmv_mgpu_info(const spmv_mgpu *g, int *ngpus, int *rows_per_gpu,
         return -EINVAL;
     int64_t nz = 0, by = 0;
     for (int r = 0; r < g->n; ++r) {
+        int64_t b = 0;
         if (g->hll[r]) {
             nz += g->hll[r]->NZ;
-            by = spmv_hll_algorithmic_bytes(g->hll[r]);
+            b = spmv_hll_algorithmic_bytes(g->hll[r]);
         } else if (g->csr[r]) {
             nz += g->csr[r]->NZ;
-            by = spmv_csr_algorithmic_bytes(g->csr[r]);
+            b = spmv_csr_algorithmic_bytes(g->csr[r]);
         }
+        if (b > by) /* the heaviest shard bounds the step */
+            by = b;
     }
     if (ngpus)
         *ngpus = g->n;

@@ -2086,7 +2086,9 @@ int panels_from_hll(const spmv_hll_dev *H, int panel_cols, int sched,
 void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     spmv_panel_opts_default(o);
     o->sched = P->sweep ? 1 : P->chain ? 2 : 0;
-    o->panel_cols = 0;
+    /* the width actually used (a copy built with an explicit panel_cols is
+     * rebuilt with it, not with the default 2^18) */
+    o->panel_cols = 1 << P->shift;
     o->tile_rows = P->sweep ? 0 : P->tile_rows;
     o->sweep_wgs_per_cu = P->sweep ? P->wgs_per_cu : 0;
     o->reserve_cus = P->reserve_cus;

@@ -53,6 +53,10 @@ void log_prog_usage(const char *prog) {
             "  -o, --out <dir>         directory for serial.csv omp.csv cuda.csv\n"
             "  -d, --debug             validate every result against serial CSR\n"
             "  -g, --gpus <n>          row-partition over n GPUs + RCCL all-gather(y)\n"
+            "      --partition <p>     even (rows, default) | nnz (entries per GPU\n"
+            "                          balanced; ragged y fragments)\n"
+            "      --ragged-exchange <x>  p2p (default) | bcast | padded\n"
+            "      --exchange-chunks <k>  opt-in staged all-gather, k row chunks\n"
             "  -i, --iters <n>         timed GPU launches per kernel (default 20)\n"
             "      --no-cpu            skip the serial / OpenMP benchmarks\n"
             "      --only-multi-gpu    run only the -g <n> step (GPU-count sweeps)\n"

@@ -31,6 +31,20 @@ Exchange modes
                than the kernel of a banded matrix); a halo of 2^16 rows moves
                1 MB.
 
+Partitions
+  even (default)   equal row counts rounded up to 32 (even_row_partition).
+  nnz-balanced     `starts` from nnz_row_partition (the multi-GPU form of the
+                   reference's partition_csr_rows, csr.c:218-276; the C side
+                   is partition_rows_nnz_aligned, include/csr.h): ranks own
+                   DIFFERENT row counts, so the fragments of y are ragged and
+                   travel by one of
+    "p2p"     grouped isend/irecv of exactly each fragment (default; chunked
+              overlap allowed: chunk c of every rank travels under the kernel
+              of chunk c+1),
+    "bcast"   one broadcast per rank, in place (SURVEY 8e "general case"),
+    "padded"  ONE all-gather of fragments padded to the longest into a staging
+              buffer + a compaction copy back into row order.
+
 `compute` is pluggable so that the partition + exchange logic is testable on
 CPU with the gloo backend (tests/test_dist_gloo.py); the product binds it to
 the HIP launch.
@@ -46,6 +60,46 @@ def even_row_partition(total_rows, world, align=HACK):
     per = -(-total_rows // world)
     per = -(-per // align) * align
     return [min(per * k, total_rows) for k in range(world + 1)]
+
+
+def nnz_row_partition(irp, world, align=HACK):
+    """starts[world+1] of `world` contiguous row ranges holding near-equal
+    entry counts, boundaries multiples of `align`: cut k is the aligned
+    boundary whose prefix entry count is nearest to k/world of the total; no
+    range is empty while there are >= world aligned blocks.  Same arithmetic
+    as partition_rows_nnz_aligned (include/csr.h, csrc/csr.c) -- the tests
+    hold the two against each other.  irp = row offsets of the WHOLE matrix
+    (M + 1 entries, any integer dtype)."""
+    irp = np.asarray(irp)
+    M = len(irp) - 1
+    nb = -(-M // align)
+    edges = np.minimum(np.arange(nb + 1, dtype=np.int64) * align, M)
+    pre = irp[edges].astype(np.int64) - int(irp[0])
+    total = int(pre[-1]) if nb else 0
+    cut = [0]
+    for k in range(1, world):
+        if nb < world:
+            cut.append(min(k, nb))
+            continue
+        lo, hi = cut[-1] + 1, nb - (world - k)
+        tk = total * k
+        idx = int(np.searchsorted(pre * world, tk, side="right")) - 1
+        b = max(cut[-1], min(hi, idx))
+        c = b
+        if b < hi and int(pre[b + 1]) * world - tk < tk - int(pre[b]) * world:
+            c = b + 1
+        cut.append(min(max(c, lo), hi))
+    cut.append(nb)
+    return [min(c * align, M) for c in cut]
+
+
+def partition_balance(irp, starts):
+    """(entries per range, max / min over the non-empty ranges)"""
+    irp = np.asarray(irp)
+    per = [int(irp[starts[k + 1]]) - int(irp[starts[k]])
+           for k in range(len(starts) - 1)]
+    live = [v for v in per if v > 0]
+    return per, (max(live) / min(live) if live else 1.0)
 
 
 def chunk_bounds(rows, chunks, align=HACK):
@@ -169,6 +223,106 @@ class ShardExchange:
         return self.dist.batch_isend_irecv(ops)
 
 
+class RaggedExchange:
+    """Exchange of y fragments of DIFFERENT lengths: rank r owns
+    y[starts[r] : starts[r+1]] of the full-length y (starts[-1] rows)."""
+
+    def __init__(self, y, rank, world, starts, mode="p2p", group=None):
+        import torch.distributed as dist
+        if mode not in ("p2p", "bcast", "padded"):
+            raise ValueError("ragged fragments travel by p2p, bcast or padded")
+        self.dist, self.group = dist, group
+        self.y, self.rank, self.world = y, rank, world
+        self.starts = [int(v) for v in starts]
+        assert len(self.starts) == world + 1 and y.numel() == self.starts[-1]
+        self.mode = mode
+        self.mine = y[self.starts[rank]:self.starts[rank + 1]]
+        self.stage = None
+        if mode == "padded":
+            import torch
+            self.longest = max(self.starts[r + 1] - self.starts[r]
+                               for r in range(world))
+            self.stage = torch.empty(world, max(self.longest, 1),
+                                     dtype=y.dtype, device=y.device)
+
+    def frag(self, r):
+        return self.y[self.starts[r]:self.starts[r + 1]]
+
+    def _rehearsal(self):
+        """gloo backend with tensors on a GPU (ranks sharing a test box's one
+        card): see all_gather_fragments"""
+        return self.dist.get_backend(self.group) == "gloo" and self.y.is_cuda
+
+    def _rehearse_rows(self, mine_ab, peer_ab):
+        """host-staged stand-in for every mode: one CPU broadcast per rank"""
+        import torch
+        torch.cuda.current_stream().synchronize()
+        for r in range(self.world):
+            ab = mine_ab if r == self.rank else peer_ab(r)
+            if not ab or ab[1] <= ab[0]:
+                continue
+            dst = self.y[self.starts[r] + ab[0]:self.starts[r] + ab[1]]
+            host = (dst.cpu() if r == self.rank
+                    else torch.empty(ab[1] - ab[0], dtype=self.y.dtype))
+            self.dist.broadcast(host, r, group=self.group)
+            if r != self.rank:
+                dst.copy_(host)
+        return _Done()
+
+    def send_rows(self, mine_ab, peer_ab):
+        """grouped point-to-point: rows mine_ab = (a, b) of MY fragment to
+        every peer, rows peer_ab(r) of rank r's fragment from rank r (local
+        row numbers; None or an empty range: nothing travels)"""
+        if self._rehearsal():
+            return self._rehearse_rows(mine_ab, peer_ab)
+        ops = []
+        for step in range(1, self.world):
+            dst = (self.rank + step) % self.world
+            src = (self.rank - step) % self.world
+            if mine_ab and mine_ab[1] > mine_ab[0]:
+                ops.append(self.dist.P2POp(
+                    self.dist.isend, self.mine[mine_ab[0]:mine_ab[1]], dst,
+                    group=self.group))
+            ab = peer_ab(src)
+            if ab and ab[1] > ab[0]:
+                ops.append(self.dist.P2POp(
+                    self.dist.irecv,
+                    self.y[self.starts[src] + ab[0]:self.starts[src] + ab[1]],
+                    src, group=self.group))
+        return self.dist.batch_isend_irecv(ops) if ops else []
+
+    def gather_all(self, force=False):
+        """whole fragments; -> work handle(s) for wait_all, then finish()"""
+        if self.world == 1 and not force:
+            return None
+        if self._rehearsal() and self.mode != "padded":
+            return self._rehearse_rows(
+                (0, self.mine.numel()),
+                lambda r: (0, self.starts[r + 1] - self.starts[r]))
+        if self.mode == "p2p":
+            return self.send_rows(
+                (0, self.mine.numel()),
+                lambda r: (0, self.starts[r + 1] - self.starts[r]))
+        if self.mode == "bcast":
+            return [self.dist.broadcast(self.frag(r), r, group=self.group,
+                                        async_op=True)
+                    for r in range(self.world)
+                    if self.starts[r + 1] > self.starts[r]]
+        n = self.mine.numel()
+        self.stage[self.rank, :n].copy_(self.mine)
+        return all_gather_fragments(self.dist, self.stage.view(-1),
+                                    self.stage[self.rank], self.group)
+
+    def finish(self):
+        """padded mode: staging rows back into row order (the compaction)"""
+        if self.mode != "padded":
+            return
+        for r in range(self.world):
+            n = self.starts[r + 1] - self.starts[r]
+            if n and r != self.rank:
+                self.frag(r).copy_(self.stage[r, :n])
+
+
 def wait_all(work):
     if work is None:
         return
@@ -207,6 +361,14 @@ class StagedExchange:
             self.stage.transpose(0, 1))
 
 
+def _is_even(starts, rows_per_rank):
+    """does `starts` describe equal fragments of rows_per_rank rows?"""
+    if rows_per_rank is None:
+        return False
+    return all(int(starts[k]) == k * rows_per_rank
+               for k in range(len(starts)))
+
+
 class ShardedSpmv:
     """One rank's part of y = A x over `world` GPUs.
 
@@ -222,7 +384,7 @@ class ShardedSpmv:
 
     def __init__(self, mat, kernel, rank, world, rows_per_rank, x, y,
                  waves_per_block=0, chunks=1, mode=None, compute=None,
-                 force_exchange=False, halo_rows=0):
+                 force_exchange=False, halo_rows=0, starts=None):
         import torch
         self.torch = torch
         self.mats = list(mat) if isinstance(mat, (list, tuple)) else None
@@ -232,7 +394,16 @@ class ShardedSpmv:
         self.rank, self.world, self.rows = rank, world, rows_per_rank
         self.x, self.y = x, y
         self.waves = waves_per_block
-        self.row0 = rank * rows_per_rank
+        self.row0 = rank * rows_per_rank if rows_per_rank is not None else 0
+        self.compute = compute or self._launch
+        self.is_hll = hasattr(self.mats[0] if self.mats else mat, "num_blocks")
+        self.force_exchange = force_exchange
+        self.halo_rows = int(halo_rows)
+        self.staged = self.ex = None
+        self.ragged = None
+        if starts is not None and not _is_even(starts, rows_per_rank):
+            self._init_ragged(starts, chunks, mode)
+            return
         if self.mats is not None:
             L = len(self.mats)
             if rows_per_rank % L or (rows_per_rank // L) % HACK:
@@ -243,7 +414,6 @@ class ShardedSpmv:
             mat = self.mats[0]
         else:
             self.bounds = chunk_bounds(rows_per_rank, chunks)
-        self.halo_rows = int(halo_rows)
         if mode == "halo" and self.halo_rows <= 0:
             raise ValueError("mode 'halo' needs halo_rows > 0")
         if mode is None:
@@ -260,9 +430,62 @@ class ShardedSpmv:
                        if mode == "staged" else None)
         self.ex = ShardExchange(y, rank, world, rows_per_rank,
                                 "p2p" if mode == "p2p" else "allgather")
-        self.compute = compute or self._launch
-        self.is_hll = hasattr(mat, "num_blocks")
-        self.force_exchange = force_exchange
+
+    def _init_ragged(self, starts, chunks, mode):
+        """ranks own different row counts (nnz-balanced partition)"""
+        if self.mats is not None:
+            raise ValueError("logical shards need the even partition")
+        if mode == "halo":
+            raise ValueError("mode 'halo' needs the even partition")
+        starts = [int(v) for v in starts]
+        if len(starts) != self.world + 1 or starts[0] != 0 or any(
+                b < a for a, b in zip(starts, starts[1:])) or any(
+                v % HACK and v != starts[-1] for v in starts):
+            raise ValueError("starts: world+1 ascending row offsets from 0, "
+                             "multiples of %d (or the row count)" % HACK)
+        if mode in (None, "allgather", "staged"):
+            mode = "p2p"
+        self.mode = mode
+        self.rows = starts[self.rank + 1] - starts[self.rank]
+        self.row0 = starts[self.rank]
+        self.ragged = RaggedExchange(self.y, self.rank, self.world, starts,
+                                     mode)
+        # row chunks of EVERY rank's fragment (p2p only): the peers' bounds
+        # follow from starts, so no metadata travels
+        k = chunks if mode == "p2p" else 1
+        self.peer_bounds = [chunk_bounds(starts[r + 1] - starts[r], k)
+                            for r in range(self.world)]
+        self.bounds = self.peer_bounds[self.rank]
+        self.nsteps = max(len(b) - 1 for b in self.peer_bounds)
+
+    def _ragged_chunk(self, r, c):
+        b = self.peer_bounds[r]
+        return (b[c], b[c + 1]) if c + 1 < len(b) else None
+
+    def _ragged_step(self, events=None, kernels=True):
+        if events and kernels:
+            events[0].record()
+        exchange = self.world > 1 or self.force_exchange
+        pending = []
+        last = len(self.bounds) - 2
+        for c in range(self.nsteps):
+            mine = self._ragged_chunk(self.rank, c)
+            if mine and kernels and mine[1] > mine[0]:
+                self.compute(mine[0], mine[1])
+            if events and kernels and c == max(last, 0):
+                events[1].record()
+            if not exchange:
+                continue
+            if self.mode == "p2p":
+                pending.append(self.ragged.send_rows(
+                    mine, lambda r, c=c: self._ragged_chunk(r, c)))
+            else:  # whole fragments, one step
+                pending.append(self.ragged.gather_all(self.force_exchange))
+        if events and kernels and self.nsteps == 0:
+            events[1].record()
+        for w in pending:
+            wait_all(w)
+        self.ragged.finish()
 
     # product compute: the HIP kernel on torch's current stream; rows [a, b)
     # go to y (row order) or, when `out` is given, to out[0 : b-a]
@@ -320,6 +543,9 @@ class ShardedSpmv:
         exchange costs when nothing hides it)"""
         if self.world == 1 and not self.force_exchange:
             return
+        if self.ragged is not None:
+            self._ragged_step(kernels=False)
+            return
         if self.mode == "halo":
             wait_all(self.halo_exchange())
             return
@@ -342,6 +568,9 @@ class ShardedSpmv:
     def step(self, events=None):
         """one SpMV (+ exchange).  events = (start, stop) torch events
         recorded around the kernel launches on the current stream."""
+        if self.ragged is not None:
+            self._ragged_step(events)
+            return
         if events:
             events[0].record()
         if self.world == 1 and not self.force_exchange:

@@ -18,12 +18,75 @@ import _oracle as O  # noqa: E402
 from spmv_scpa_amd import dist as D  # noqa: E402
 
 
+def skewed_csr(M):
+    """the nlpkkt160 shape in miniature: a dense upper part (ragged rows of
+    mean 24) over a light lower part (mean 6), global columns"""
+    top = (M // 2) // 32 * 32 + 32
+    I1, J1, A1 = O.synth_csr(2, top, M, 24, 300, 42)
+    I2, J2, A2 = O.synth_csr(2, M - top, M, 6, 300, 43, row0=top)
+    IRP = np.concatenate([I1, I1[-1] + I2[1:]]).astype(np.int32)
+    return IRP, np.concatenate([J1, J2]), np.concatenate([A1, A2])
+
+
+def ragged(rank, world, mode, chunks, M):
+    """nnz-balanced partition: ranks own DIFFERENT row counts, the fragments
+    of y travel by p2p / bcast / padded (dist.RaggedExchange)"""
+    IRP, JA, AS = skewed_csr(M)
+    starts = D.nnz_row_partition(IRP, world)
+    rows = [starts[r + 1] - starts[r] for r in range(world)]
+    assert len(set(rows)) > 1, rows  # really ragged
+    assert all(v % 32 == 0 for v in starts[:-1]) and min(rows) > 0
+    _, bal = D.partition_balance(IRP, starts)
+    _, bal_even = D.partition_balance(IRP, D.even_row_partition(M, world))
+    assert bal < 1.25 and bal < bal_even, (bal, bal_even)
+    row0, mine = starts[rank], rows[rank]
+    x = torch.from_numpy(O.synth_x(7, 0, M))
+    y = torch.full((M,), float("nan"), dtype=torch.float64)
+    sub = np.ascontiguousarray(IRP[row0:row0 + mine + 1] - IRP[row0])
+    lo, hi = IRP[row0], IRP[row0 + mine]
+    calls = []
+
+    def compute(a, b, out=None):
+        assert out is None
+        calls.append((a, b))
+        s2 = np.ascontiguousarray(sub[a:b + 1] - sub[a])
+        y[row0 + a:row0 + b] = torch.from_numpy(O.csr_spmv(
+            s2, JA[lo + sub[a]:lo + sub[b]], AS[lo + sub[a]:lo + sub[b]],
+            x.numpy()))
+
+    sh = D.ShardedSpmv(None, 0, rank, world, None, x, y, chunks=chunks,
+                       mode=mode, compute=compute, starts=starts)
+    assert sh.mode == mode and sh.rows == mine and sh.row0 == row0
+    want = O.csr_spmv(IRP, JA, AS, x.numpy())
+    for it in range(3):
+        y.fill_(float("nan"))
+        del calls[:]
+        sh.step()
+        assert np.array_equal(y.numpy(), want), (rank, it)
+        assert calls[0][0] == 0 and calls[-1][1] == mine
+        assert len(calls) == (min(chunks, mine // 32) if mode == "p2p" else 1)
+    y.fill_(float("nan"))
+    y[row0:row0 + mine] = torch.from_numpy(want[row0:row0 + mine])
+    sh.exchange_only()
+    assert np.array_equal(y.numpy(), want), rank
+    # the even partition handed over as `starts` is the old, unragged path
+    ev = D.even_row_partition(M, world)
+    sh2 = D.ShardedSpmv(None, 0, rank, world, M // world, x, y, starts=ev,
+                        compute=lambda a, b, out=None: None)
+    assert sh2.ragged is None and sh2.mode == "allgather"
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     mode, chunks, rows_per_rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     kind, K, W = 2, 12, 500  # ragged family
     M = N = rows_per_rank * world
+    if mode.startswith("ragged_"):
+        return ragged(rank, world, mode[len("ragged_"):], chunks, M)
     starts = D.even_row_partition(M, world)
     assert starts[rank + 1] - starts[rank] == rows_per_rank
     row0 = starts[rank]

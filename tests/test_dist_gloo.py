@@ -66,11 +66,73 @@ def run_world(world, mode, chunks, rows):
                                                # config.rccl / per-rank times
                                                (2, "describe", 1),
                                                (3, "describe", 1),
+                                               # nnz-balanced partition: ragged
+                                               # fragments
+                                               (2, "ragged_p2p", 1),
+                                               (3, "ragged_p2p", 3),
+                                               (8, "ragged_p2p", 2),
+                                               (2, "ragged_bcast", 1),
+                                               (3, "ragged_bcast", 1),
+                                               (8, "ragged_bcast", 1),
+                                               (2, "ragged_padded", 1),
+                                               (3, "ragged_padded", 1),
+                                               (8, "ragged_padded", 1),
                                                (3, "halo", 64),
                                                (3, "halo", 960),
                                                (2, "halo", 32)])
 def test_sharded_spmv_gloo(world, mode, chunks):
     run_world(world, mode, chunks, rows=640)
+
+
+def test_nnz_partition_matches_the_library_and_balances():
+    """dist.nnz_row_partition == partition_rows_nnz_aligned (csr.h) on skewed
+    row-length profiles; aligned, ascending, no empty range, balanced"""
+    import numpy as np
+    import spmv_scpa_amd as S
+    rng = np.random.default_rng(5)
+    cases = []
+    for M in (1, 31, 32, 33, 100, 4096, 100_003):
+        for prof in ("flat", "kkt", "hub", "powerlaw", "empty"):
+            if prof == "flat":
+                ln = np.full(M, 7)
+            elif prof == "kkt":  # 42 entries above, 15 below (nlpkkt160)
+                ln = np.where(np.arange(M) < M // 2, 42, 15)
+            elif prof == "hub":
+                ln = rng.integers(1, 6, M)
+                ln[M // 3] = 20 * M + 5
+            elif prof == "powerlaw":
+                ln = np.minimum((rng.pareto(1.5, M) + 1).astype(np.int64), M)
+            else:
+                ln = np.zeros(M, dtype=np.int64)
+            cases.append((prof, np.concatenate([[0], np.cumsum(ln)])))
+    for prof, irp in cases:
+        M = len(irp) - 1
+        for world in (1, 2, 3, 4, 8):
+            got = D.nnz_row_partition(irp, world)
+            lib = S.partition_rows_nnz_aligned(irp.astype(np.int32), world)
+            assert got == [int(v) for v in lib], (prof, M, world)
+            assert got[0] == 0 and got[-1] == M and len(got) == world + 1
+            assert all(b >= a for a, b in zip(got, got[1:]))
+            assert all(v % 32 == 0 or v == M for v in got)
+            nb = -(-M // 32)
+            if nb >= world:  # no empty range
+                assert all(b > a for a, b in zip(got, got[1:])), (prof, M)
+            per, _ = D.partition_balance(irp, got)
+            if prof == "kkt" and M >= 4096 and world > 1:
+                # within one 32-row block of the ideal share
+                assert max(per) - min(per) <= 2 * 32 * 42, (M, world, per)
+                ev, _ = D.partition_balance(irp,
+                                            D.even_row_partition(M, world))
+                assert max(per) <= max(ev)
+    # the synthetic form cuts from the generator's row lengths
+    st = S.partition_synth_rows_nnz(S.SYNTH_KKT, 100_000, 100_000, 16, 4096,
+                                    42, 8)
+    A = S.csr_generate(S.SYNTH_KKT, 100_000, 100_000, 16, 4096, 0, 42)
+    IRP, _, _ = S.csr_arrays(A)
+    assert [int(v) for v in st] == D.nnz_row_partition(IRP, 8)
+    S.csr_free(A)
+    with pytest.raises(OSError):
+        S.partition_rows_nnz_aligned(np.zeros(2, dtype=np.int32), 0)
 
 
 def test_partition_helpers():

@@ -265,3 +265,151 @@ def test_native_staged_exchange_on_a_host_matrix(M):
             assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
         g.destroy()
     S.csr_free(A)
+
+
+def _skewed_csr(M):
+    """the nlpkkt160 shape in miniature: a dense upper part (ragged rows of
+    mean 40) over a light lower part (mean 14), global columns"""
+    top = (M // 2) // 32 * 32 + 32
+    I1, J1, A1 = O.synth_csr(S.SYNTH_RAGGED, top, M, 40, 3000, 42)
+    I2, J2, A2 = O.synth_csr(S.SYNTH_RAGGED, M - top, M, 14, 3000, 43, row0=top)
+    IRP = np.concatenate([I1, I1[-1] + I2[1:]]).astype(np.int32)
+    return IRP, np.concatenate([J1, J2]), np.concatenate([A1, A2])
+
+
+@pytest.mark.parametrize("nlog", [2, 3, 8])
+@pytest.mark.parametrize("as_hll", [False, True])
+def test_nnz_partition_on_logical_devices(nlog, as_hll):
+    """spmv_mgpu_load_csr_part(_PART_NNZ) on a REHEARSAL handle (nlog logical
+    devices on this box's card, copies instead of collectives): the ranges
+    are the library's nnz-balanced cut (= dist.nnz_row_partition), ragged,
+    32-aligned, entries per device within 10 % of each other where the even
+    cut is 2.5x apart; every logical device ends with the whole y, equal to
+    the oracle's; the selector's pick runs on the ragged shards too."""
+    from spmv_scpa_amd import dist as D
+    M = 100_003
+    IRP, JA, AS = _skewed_csr(M)
+    x = O.synth_x(7, 0, M)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("skew", M, M, IRP, JA, AS)
+    g = S.MultiGpu(nlog, rehearsal=True)
+    assert g.comm_ranks() == 0
+    g.load_csr(A, as_hll, partition="even")
+    st, ent, ragged = g.partition()
+    assert not ragged and st == D.even_row_partition(M, nlog)
+    assert max(ent) / min(ent) > 2.0
+    g.load_csr(A, as_hll, partition="nnz")
+    st, ent, ragged = g.partition()
+    assert ragged and st == D.nnz_row_partition(IRP, nlog)
+    assert sum(ent) == len(JA) and max(ent) / min(ent) < 1.10, ent
+    g.set_x(x)
+    g.spmv(iters=2)
+    for r in range(nlog):
+        y = g.get_y(r)
+        assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12, r
+    k = g.autotune()
+    g.spmv(kernel=k, iters=1)
+    y = g.get_y(nlog - 1)
+    assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
+    wall, kms = g.run(k, 1, 2)
+    assert wall > 0 and len(kms) == nlog and np.all(kms > 0)
+    g.destroy()
+    S.csr_free(A)
+
+
+def test_nnz_partition_of_a_generated_family_and_empty_ranges():
+    """generate(partition="nnz") cuts by the generator's row lengths (no
+    matrix on the host); more logical devices than hack blocks leaves the
+    trailing ranges empty and the launch skips them"""
+    g = S.MultiGpu(4, rehearsal=True)
+    rows = 32_000
+    M = rows * 4
+    g.generate(S.SYNTH_KKT, rows, 16, 4096, 42, as_hll=False, partition="nnz")
+    st, ent, ragged = g.partition()
+    assert ragged and st[0] == 0 and st[-1] == M
+    assert [int(v) for v in S.partition_synth_rows_nnz(
+        S.SYNTH_KKT, M, M, 16, 4096, 42, 4)] == st
+    assert max(ent) / min(ent) < 1.05
+    g.fill_x(7)
+    g.spmv(iters=1)
+    y = g.get_y(3)
+    for grow in (0, st[1] - 1, st[1], st[2], st[3] - 1, M - 1, 77_777):
+        want, sc = O.synth_row_dot(S.SYNTH_KKT, M, M, 16, 4096, 0, 42, 7, grow)
+        assert abs(y[grow] - want) <= 1e-12 * sc, grow
+    g.destroy()
+    # 70 rows = 3 hack blocks over 8 logical devices: five empty ranges
+    A = S.io_load_csr(G.mtx_path("sym70"))
+    IRP, JA, AS = (np.array(v) for v in S.csr_arrays(A))
+    x = O.synth_x(7, 0, 70)
+    for part in ("even", "nnz"):
+        for as_hll in (False, True):
+            g = S.MultiGpu(8, rehearsal=True)
+            g.load_csr(A, as_hll, partition=part)
+            st, ent, _ = g.partition()
+            assert st[-1] == 70 and ent.count(0) == 5, (part, st, ent)
+            g.set_x(x)
+            g.spmv(iters=1)
+            assert np.allclose(g.get_y(7), O.csr_spmv(IRP, JA, AS, x),
+                               rtol=0, atol=1e-12)
+            g.destroy()
+    S.csr_free(A)
+
+
+@pytest.mark.parametrize("xchg", ["bcast", "padded", "p2p"])
+def test_ragged_exchange_collectives_run_with_one_rank(xchg):
+    """the RCCL side of the ragged exchange on the 1-GPU box: an nnz partition
+    over ONE real device is handled as ragged (y holds exactly M rows), and
+    with force the exchange runs as 1-rank collectives -- ncclBroadcast in
+    place; the padded ncclAllGather through the staging buffer and back; p2p
+    has no peer.  y must survive it bit for bit, several steps in a row, and
+    the exchange can be timed alone."""
+    M = 100_003
+    IRP, JA, AS = _skewed_csr(M)
+    x = O.synth_x(7, 0, M)
+    y_ref = O.csr_spmv(IRP, JA, AS, x)
+    scale = O.csr_abs_spmv(IRP, JA, AS, x)
+    A = S.csr_from_arrays("skew", M, M, IRP, JA, AS)
+    g = S.MultiGpu(1)
+    g.set_ragged_exchange(xchg)
+    g.load_csr(A, True, partition="nnz")
+    st, ent, ragged = g.partition()
+    assert ragged and st == [0, M] and ent == [len(JA)]
+    g.set_exchange(1, force=True)
+    g.set_x(x)
+    g.spmv(kernel=1, warmup=1, iters=3)
+    y = g.get_y(0)
+    assert np.max(np.abs(y - y_ref) / np.maximum(scale, 1e-300)) <= 1e-12
+    assert g.exchange_only(5) >= 0.0
+    assert np.array_equal(g.get_y(0), y)
+    # switching the kind on a loaded handle (re)sizes the staging buffer
+    for other in ("padded", "bcast", "p2p"):
+        g.set_ragged_exchange(other)
+        g.spmv(kernel=2, warmup=0, iters=1)
+        assert np.max(np.abs(g.get_y(0) - y_ref)
+                      / np.maximum(scale, 1e-300)) <= 1e-12
+    with pytest.raises(KeyError):
+        g.set_ragged_exchange("ring")
+    assert S._lib.spmv_mgpu_set_ragged_exchange(g.h, 7) == -22
+    g.destroy()
+    S.csr_free(A)
+
+
+def test_driver_partition_flag(tmp_path):
+    """spmv_scpa_amd -g 1 --partition nnz -d: the C driver's option, its
+    per-GPU report, and y checked against the serial CSR result"""
+    drv = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
+    env = dict(os.environ, OMP_NUM_THREADS="4", SPMV_FORCE_MGPU="1")
+    for xchg in ("p2p", "bcast", "padded"):
+        r = subprocess.run(
+            [drv, "-m", G.mtx_path("sym70"), "-o", str(tmp_path), "-d",
+             "--iters", "3", "--no-cpu", "-g", "1", "--partition", "nnz",
+             "--ragged-exchange", xchg],
+            capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "partition nnz (ragged fragments)" in r.stdout
+        assert "GPU 0: rows [0, 70)" in r.stdout
+    r = subprocess.run([drv, "-m", G.mtx_path("sym70"), "-o", str(tmp_path),
+                        "-g", "1", "--partition", "rows"],
+                       capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode != 0 and "even or nnz" in (r.stdout + r.stderr)

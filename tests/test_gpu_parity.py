@@ -668,6 +668,30 @@ def test_pinned_layout_rebuilds_what_the_selector_settled_on(kind, M, K, W):
         d.free()
 
 
+@pytest.mark.parametrize("sched", ["chain", "sweep"])
+def test_pin_round_trips_a_non_default_panel_width(sched):
+    """a copy built with an explicit panel_cols (2^14, not the default 2^18)
+    reports THAT width in its pin (panels_get_opts said 0), and
+    build_panels_pinned / build_panels_like rebuild the same layout line"""
+    M = N = 400_000
+    A = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 16, 1 << 30, 0, 42)
+    B = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 16, 1 << 30, 0, 42)
+    Cm = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 16, 1 << 30, 0, 42)
+    A.build_panels(1 << 14, sched)
+    pin = A.panels_pin()
+    assert "panel_cols=16384" in pin, pin
+    assert "x 2^14 cols" in A.panels_describe()
+    B.build_panels_pinned(pin)
+    Cm.build_panels_like(A)
+    assert B.panels_pin() == pin and Cm.panels_pin() == pin
+    assert B.panels_describe() == A.panels_describe() == Cm.panels_describe()
+    D0 = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, 16, 1 << 30, 0, 42)
+    D0.build_panels(0, sched)  # the default width is another layout
+    assert D0.panels_describe() != A.panels_describe()
+    for m in (A, B, Cm, D0):
+        m.release()
+
+
 def test_release_source_keeps_only_the_blocked_copy(default_panel_schedule):
     """spmv_*_release_source: JA/AS freed, the blocked path still runs, every
     entry point that needs the source says -ENODATA."""

@@ -85,3 +85,54 @@ def test_the_abort_was_the_global_load_and_nothing_else():
                         code.replace("RTLD_GLOBAL", "RTLD_LOCAL")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "double free" not in r.stderr, r.stderr
+
+
+def test_elf_reader_and_runtime_report():
+    """the binding's ELF reader names what the loader will match on, and the
+    import-time check sees one runtime copy of each library"""
+    sys.path.insert(0, ROOT)
+    import spmv_scpa_amd as S
+    soname, needed = S._elf_dynamic(S.LIB_PATH)
+    assert any(n.startswith("libamdhip64.so.") for n in needed), needed
+    assert any(n.startswith("librccl.so.") for n in needed), needed
+    assert S._elf_dynamic(__file__) == (None, [])
+    assert S.ROCM_RUNTIME_ONCE is True
+    assert all(len(v) == 1 for v in S.mapped_rocm_runtimes().values())
+    if S.ROCM_RUNTIME_SHARED_WITH_TORCH:
+        for path in S.ROCM_RUNTIME_SHARED_WITH_TORCH:
+            name = os.path.basename(path)
+            assert S._elf_dynamic(path)[0] in [
+                n for n in needed if n.startswith(name)], path
+
+
+@needs_torch
+def test_a_bundled_runtime_with_another_soname_is_not_preloaded(tmp_path):
+    """a torch wheel whose libamdhip64 carries another SONAME
+    (another ROCm major) must not be preloaded -- the loader would not take it
+    for the library's DT_NEEDED name and two runtimes would be mapped.  Staged
+    with a fake `torch` package whose lib/ holds a copy of /opt/rocm's HIP
+    runtime patched to SONAME libamdhip64.so.6."""
+    src = "/opt/rocm/lib/libamdhip64.so"
+    if not os.path.exists(src):
+        pytest.skip("no /opt/rocm runtime to stage the fake wheel from")
+    pkg = tmp_path / "torch"
+    (pkg / "lib").mkdir(parents=True)
+    (pkg / "__init__.py").write_text("raise ImportError('fake torch')\n")
+    data = open(os.path.realpath(src), "rb").read()
+    assert data.count(b"libamdhip64.so.7\0") >= 1
+    (pkg / "lib" / "libamdhip64.so").write_bytes(
+        data.replace(b"libamdhip64.so.7\0", b"libamdhip64.so.6\0"))
+    code = ("import sys, warnings\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    import spmv_scpa_amd as S\n"
+            "print('SHARED', S.ROCM_RUNTIME_SHARED_WITH_TORCH)\n"
+            "print('WARNED', [str(x.message)[:60] for x in w])\n"
+            "print('MAPS', S.mapped_rocm_runtimes())\n" % (ROOT, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SHARED None" in r.stdout, r.stdout
+    assert "SONAME" in r.stdout and "libamdhip64.so.6" not in r.stdout.split(
+        "MAPS")[1], r.stdout
