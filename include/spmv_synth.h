@@ -266,35 +266,62 @@ SYNTH_FN void synth_window(const synth_spec *s, int64_t g, int64_t *plo,
  * synth_row_len(s, g).  Insertion sort for the random families: their rows
  * are short (K ~ 16..256); the power-law and hub families, whose rows reach
  * 10^4..10^5 entries, draw ascending columns directly.
+ *
+ * The _at form places element j at index SYNTH_AT(base + j, skew) of cols /
+ * vals, SYNTH_AT(p, k) = p + (p >> k): the device generator stages a range of
+ * rows in LDS at their final relative positions, one padding word per 32 so
+ * that lanes walking rows of 32 entries do not meet in one bank, and writes
+ * the range out with whole-line stores.  skew = 31 is the identity for every
+ * index a matrix can have (p < 2^31): the plain form.
  */
-SYNTH_FN void synth_fill_row(const synth_spec *s, int64_t g, int len,
-                             int *cols, double *vals) {
+#define SYNTH_AT(p, k) ((p) + ((p) >> (k)))
+SYNTH_FN void synth_fill_row_at(const synth_spec *s, int64_t g, int len,
+                                int *cols, double *vals, int base, int skew) {
+#define C_(j) cols[SYNTH_AT(base + (j), skew)]
     if (s->kind == SYNTH_STENCIL) {
-        synth_stencil_cols(s, g, cols);
+        /* neighbours in ascending order: synth_stencil_cols' loop, placed */
+        const int64_t nx = synth_grid_nx(s), nxy = nx * nx;
+        const int64_t ix = g % nx, iy = (g / nx) % nx, iz = g / nxy;
+        const int full = s->K > 7;
+        int n = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (!full && (dx != 0) + (dy != 0) + (dz != 0) > 1)
+                        continue;
+                    const int64_t jx = ix + dx, jy = iy + dy, jz = iz + dz;
+                    if (jx < 0 || jx >= nx || jy < 0 || jy >= nx || jz < 0)
+                        continue;
+                    const int64_t c = jz * nxy + jy * nx + jx;
+                    if (c >= (int64_t)s->N)
+                        continue;
+                    C_(n) = (int)c;
+                    ++n;
+                }
     } else if (s->kind == SYNTH_POWERLAW) {
         int64_t lo, hi;
         synth_window(s, g, &lo, &hi);
         for (int j = 0; j < len; ++j)
-            cols[j] = synth_col_strat(s, g, j, len, lo, hi);
+            C_(j) = synth_col_strat(s, g, j, len, lo, hi);
     } else if (s->kind == SYNTH_HUB) {
         if (g == synth_hub_row(s)) {
             for (int j = 0; j < len; ++j)
-                cols[j] = synth_col_strat(s, g, j, len, 0, s->N);
+                C_(j) = synth_col_strat(s, g, j, len, 0, s->N);
         } else {
             const int hub = synth_hub_has_col(s, g);
-            const int base = len - hub;
+            const int nbase = len - hub;
             int64_t lo, hi;
             synth_window(s, g, &lo, &hi);
-            for (int j = 0; j < base; ++j)
-                cols[j] = synth_col_strat(s, g, j, base, lo, hi);
+            for (int j = 0; j < nbase; ++j)
+                C_(j) = synth_col_strat(s, g, j, nbase, lo, hi);
             if (hub) { /* the hub column goes to its sorted place */
                 const int c = synth_hub_col(s);
-                int p = base;
-                while (p > 0 && cols[p - 1] > c) {
-                    cols[p] = cols[p - 1];
+                int p = nbase;
+                while (p > 0 && C_(p - 1) > c) {
+                    C_(p) = C_(p - 1);
                     --p;
                 }
-                cols[p] = c;
+                C_(p) = c;
             }
         }
     } else if (s->kind == SYNTH_BANDED) {
@@ -304,20 +331,26 @@ SYNTH_FN void synth_fill_row(const synth_spec *s, int64_t g, int len,
         if (st < 0)
             st = 0;
         for (int j = 0; j < len; ++j)
-            cols[j] = (int)(st + j);
+            C_(j) = (int)(st + j);
     } else {
         for (int t = 0; t < len; ++t) {
             int c = synth_col_draw(s, g, t);
             int p = t;
-            while (p > 0 && cols[p - 1] > c) {
-                cols[p] = cols[p - 1];
+            while (p > 0 && C_(p - 1) > c) {
+                C_(p) = C_(p - 1);
                 --p;
             }
-            cols[p] = c;
+            C_(p) = c;
         }
     }
+#undef C_
     for (int j = 0; j < len; ++j)
-        vals[j] = synth_val(s, g, j);
+        vals[SYNTH_AT(base + j, skew)] = synth_val(s, g, j);
+}
+
+SYNTH_FN void synth_fill_row(const synth_spec *s, int64_t g, int len,
+                             int *cols, double *vals) {
+    synth_fill_row_at(s, g, len, cols, vals, 0, 31);
 }
 
 #endif /* SPMV_SYNTH_H */

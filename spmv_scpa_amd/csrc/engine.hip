@@ -330,16 +330,54 @@ __host__ __device__ static inline bool synth_row_is_parallel(const synth_spec *s
             (s->kind == SYNTH_HUB && g == synth_hub_row(s)));
 }
 
-/* one lane per row; rows are short, the insertion sort runs in place */
-__global__ void k_synth_rows(synth_spec s, const int *irp, int *ja,
-                             double *as) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.M)
+/*
+ * One lane per row, one workgroup per SYNTH_WG consecutive rows -- whose
+ * entries are ONE contiguous range of JA / AS.  The range is generated in
+ * LDS, every row at its final position relative to the range start (a padding
+ * word per 32 -- SYNTH_AT -- keeps lanes that walk rows of 32 entries out of
+ * each other's bank; the insertion sort of the random families runs there),
+ * and then written out by the whole workgroup with consecutive lanes on
+ * consecutive entries.  Round 4 let every lane write its own row straight to
+ * HBM: 64 lanes x 4-byte stores to 64 different lines per instruction --
+ * 130 GB of write traffic for a 3.84 GB matrix, 36 ms
+ * (profiles/r04_wn_hll_tile_panels.md).  A range that does not fit the LDS
+ * budget (`cap` entries: long rows among the 128) falls back to direct
+ * stores; the same functions per entry either way, the same matrix.
+ */
+#define SYNTH_WG 128
+#define SYNTH_SKEW 5
+__global__ void __launch_bounds__(SYNTH_WG)
+    k_synth_rows(synth_spec s, const int *__restrict__ irp, int *ja, double *as,
+                 int cap) {
+    extern __shared__ double synth_lds[];
+    const int r0 = blockIdx.x * SYNTH_WG;
+    const int r1 = min(r0 + SYNTH_WG, s.M);
+    const int i = r0 + (int)threadIdx.x;
+    const int beg0 = irp[r0];
+    const int total = irp[r1] - beg0;
+    int beg = 0, len = 0;
+    bool mine = false;
+    if (i < r1) {
+        beg = irp[i];
+        len = irp[i + 1] - beg;
+        mine = !synth_row_is_parallel(&s, s.row0 + i, len); /* k_synth_long_rows */
+    }
+    if (total > cap) { /* workgroup-uniform: direct stores */
+        if (mine)
+            synth_fill_row(&s, s.row0 + i, len, ja + beg, as + beg);
         return;
-    int beg = irp[i], len = irp[i + 1] - beg;
-    if (synth_row_is_parallel(&s, s.row0 + i, len))
-        return; /* k_synth_long_rows */
-    synth_fill_row(&s, s.row0 + i, len, ja + beg, as + beg);
+    }
+    double *vals = synth_lds;
+    int *cols = (int *)(synth_lds + SYNTH_AT(cap, SYNTH_SKEW) + 1);
+    if (mine)
+        synth_fill_row_at(&s, s.row0 + i, len, cols, vals, beg - beg0,
+                          SYNTH_SKEW);
+    __syncthreads();
+    /* rows left to k_synth_long_rows are longer than cap: none in here */
+    for (int p = (int)threadIdx.x; p < total; p += SYNTH_WG) {
+        ja[beg0 + p] = cols[SYNTH_AT(p, SYNTH_SKEW)];
+        as[beg0 + p] = vals[SYNTH_AT(p, SYNTH_SKEW)];
+    }
 }
 
 /* grid (long rows, chunks): the workgroups of a row stride over its entries */
@@ -402,31 +440,92 @@ __global__ void k_hll_fill_wide(int M, int col_major, const int *wide_blocks,
     }
 }
 
-__global__ void k_hll_fill(int M, int col_major, const int *irp,
-                           const int *cja, const double *cas,
-                           const int64_t *off, int *ja, double *as,
-                           unsigned *padmask) {
-    int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= M)
-        return;
-    int b = row / 32, i = row % 32;
-    int rows = min(32, M - b * 32);
-    int64_t o = off[b];
-    int w = (int)((off[b + 1] - o) / rows);
-    if (w > HLL_FILL_WIDE)
-        return; /* k_hll_fill_wide */
-    int beg = irp[row], len = irp[row + 1] - beg;
-    int last = 0; /* pad -> previous valid column, or 0 (hip_hll.h) */
-    for (int j = 0; j < w; ++j) {
-        int64_t t = o + (col_major ? (int64_t)j * rows + i : (int64_t)i * w + j);
-        if (j < len) {
-            last = cja[beg + j];
-            ja[t] = last;
-            as[t] = cas[beg + j];
-        } else {
-            ja[t] = last;
-            as[t] = 0.0;
-            atomicOr(padmask + (t >> 5), 1u << (t & 31));
+/*
+ * HLL_FILL_BLOCKS hack blocks (128 rows) per workgroup.  Their CSR entries
+ * are one contiguous range of cja / cas: it is staged in LDS with whole-line
+ * loads (skewed a word per 32 so that lanes reading 32 different rows'
+ * j-th entries do not meet in one bank), then the workgroup walks the SLOTS
+ * of its blocks, consecutive lanes on consecutive slots in either layout --
+ * whole-line stores -- taking each slot's entry out of LDS.  Round 4's lane
+ * per row read cja / cas with a stride of the row length: 65.9 GB read to
+ * write 3.84 GB (profiles/r04_wn_hll_tile_panels.md).  A group whose entries
+ * exceed the LDS budget reads them from global memory instead (same slot
+ * walk); blocks wider than HLL_FILL_WIDE are k_hll_fill_wide's.  The pad
+ * bits of 64 consecutive slots are OR-ed in with at most three atomics per
+ * wavefront.
+ */
+#define HLL_FILL_BLOCKS 4
+#define HLL_FILL_SKEW 5
+__global__ void __launch_bounds__(256)
+    k_hll_fill(int M, int nb, int col_major, const int *__restrict__ irp,
+               const int *__restrict__ cja, const double *__restrict__ cas,
+               const int64_t *__restrict__ off, int *ja, double *as,
+               unsigned *padmask, int cap) {
+    extern __shared__ double fill_lds[];
+    __shared__ int s_irp[HLL_FILL_BLOCKS * 32 + 1];
+    const int b0 = blockIdx.x * HLL_FILL_BLOCKS;
+    const int b1 = min(b0 + HLL_FILL_BLOCKS, nb);
+    const int r0 = b0 * 32, r1 = min(b1 * 32, M);
+    for (int k = (int)threadIdx.x; k <= r1 - r0; k += 256)
+        s_irp[k] = irp[r0 + k];
+    __syncthreads();
+    const int beg0 = s_irp[0];
+    const int total = s_irp[r1 - r0] - beg0;
+    const bool staged = total <= cap;
+    double *vals = fill_lds;
+    int *cols = (int *)(fill_lds + SYNTH_AT(cap, HLL_FILL_SKEW) + 1);
+    if (staged) {
+        for (int p = (int)threadIdx.x; p < total; p += 256) {
+            cols[SYNTH_AT(p, HLL_FILL_SKEW)] = cja[beg0 + p];
+            vals[SYNTH_AT(p, HLL_FILL_SKEW)] = cas[beg0 + p];
+        }
+        __syncthreads();
+    }
+    const int lane = (int)threadIdx.x & 63;
+    for (int b = b0; b < b1; ++b) {
+        const int rows = min(32, M - b * 32);
+        const int64_t o = off[b];
+        const int64_t n = off[b + 1] - o;
+        const int w = (int)(n / rows);
+        if (w > HLL_FILL_WIDE)
+            continue; /* k_hll_fill_wide */
+        /* whole wavefronts enter every round: the pad ballot needs all lanes */
+        for (int64_t q0 = 0; q0 < n; q0 += 256) {
+            const int64_t q = q0 + (int64_t)threadIdx.x;
+            bool pad = false;
+            if (q < n) {
+                const int i = col_major ? (int)(q % rows) : (int)(q / w);
+                const int j = col_major ? (int)(q / rows) : (int)(q % w);
+                const int rb = s_irp[(b - b0) * 32 + i] - beg0;
+                const int len = s_irp[(b - b0) * 32 + i + 1] - beg0 - rb;
+                /* pad -> the row's last valid column, or 0 (hip_hll.h) */
+                pad = j >= len;
+                const int p = rb + (pad ? len - 1 : j);
+                int c = 0;
+                double v = 0.0;
+                if (p >= rb) { /* len > 0 */
+                    c = staged ? cols[SYNTH_AT(p, HLL_FILL_SKEW)] : cja[beg0 + p];
+                    if (!pad)
+                        v = staged ? vals[SYNTH_AT(p, HLL_FILL_SKEW)]
+                                   : cas[beg0 + p];
+                }
+                ja[o + q] = c;
+                as[o + q] = v;
+            }
+            const unsigned long long m = __ballot(pad);
+            if (m) { /* slots t0 .. t0 + 63 of this wavefront: <= 3 words */
+                const int64_t t0 = o + q0 + ((int64_t)threadIdx.x & ~63);
+                const int sh = (int)(t0 & 31);
+                unsigned word = 0;
+                if (lane == 0)
+                    word = (unsigned)(m << sh);
+                else if (lane == 1)
+                    word = (unsigned)(sh ? m >> (32 - sh) : m >> 32);
+                else if (lane == 2)
+                    word = sh ? (unsigned)(m >> (64 - sh)) : 0u;
+                if (lane < 3 && word)
+                    atomicOr(padmask + (t0 >> 5) + lane, word);
+            }
         }
     }
 }
@@ -659,9 +758,20 @@ int spmv_csr_generate(int kind, int M, int N, int K, int64_t W, int64_t row0,
         return rc;
     HIP_TRY(hipMemcpy(d->irp, irp.data(), ((size_t)M + 1) * sizeof(int),
                       hipMemcpyHostToDevice));
-    if (M > 0)
-        hipLaunchKernelGGL(k_synth_rows, dim3((M + 127) / 128), dim3(128), 0,
-                           0, s, d->irp, d->ja, d->as);
+    if (M > 0) {
+        /* LDS budget of a 128-row range: the nominal row length with a
+         * quarter of slack (the ragged family's longest row) + 8, at most
+         * 12288 entries (147 KiB); heavier ranges store directly */
+        const int per_row = K + K / 4 + 8;
+        const int cap = (int)std::min<long long>(12288, (long long)SYNTH_WG * per_row);
+        const size_t lds = ((size_t)SYNTH_AT(cap, SYNTH_SKEW) + 1) * 12 + 16;
+        if (lds > 64 * 1024) /* per device, per call: a one-off setup path */
+            HIP_TRY(hipFuncSetAttribute(
+                (const void *)k_synth_rows,
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_synth_rows, dim3((M + SYNTH_WG - 1) / SYNTH_WG),
+                           dim3(SYNTH_WG), lds, 0, s, d->irp, d->ja, d->as, cap);
+    }
     HIP_TRY(hipGetLastError());
     {
         std::vector<int> long_rows;
@@ -1215,9 +1325,24 @@ int spmv_hll_from_csr(const spmv_csr_dev *A, int is_col_major,
         goto fail;
     d->max_width = maxw;
     if (M > 0) {
-        hipLaunchKernelGGL(k_hll_fill, dim3((M + 255) / 256), dim3(256), 0, 0,
-                           M, d->col_major, A->irp, A->ja, A->as, d->off,
-                           d->ja, d->as, d->padmask);
+        {
+            /* LDS budget of a group of 128 rows: mean row length + 25 % + 8
+             * per row, 2048..12288 entries; heavier groups read global */
+            const long long mean = M > 0 ? (A->NZ + M - 1) / M : 0;
+            const int cap = (int)std::max<long long>(
+                2048, std::min<long long>(
+                          12288, HLL_FILL_BLOCKS * 32 * (mean + mean / 4 + 8)));
+            const size_t lds = ((size_t)SYNTH_AT(cap, HLL_FILL_SKEW) + 1) * 12 + 16;
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute(
+                    (const void *)k_hll_fill,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_hll_fill,
+                               dim3((nb + HLL_FILL_BLOCKS - 1) / HLL_FILL_BLOCKS),
+                               dim3(256), lds, 0, M, nb, d->col_major, A->irp,
+                               A->ja, A->as, d->off, d->ja, d->as, d->padmask,
+                               cap);
+        }
         HIP_TRY(hipGetLastError());
         std::vector<int> wide;
         for (int b = 0; b < nb; ++b)

@@ -203,22 +203,42 @@ __device__ __forceinline__ bool in_sorted(const int *__restrict__ rows, int n,
     return lo < n && rows[lo] == row;
 }
 
+/*
+ * Sort key of an entry: [bucket id | column in panel (shift bits) | row in
+ * tile (rbits bits)], value = the entry's fp64 value.  The radix sort runs
+ * over the bits ABOVE the row field only (begin_bit = rbits): buckets in id
+ * order, column-sorted inside, ties in source order (the sort is stable, the
+ * source row-major: a deterministic layout) -- and the row rides along, so
+ * that the sorted (key, value) pairs are everything the copy holds: placing
+ * them (k_place) is a pure stream.  Until round 5 the sort carried the
+ * source INDEX and a gather kernel fetched ja / as at sorted, i.e. random,
+ * positions and searched the row (a bisection per entry): 80.6 GB moved to
+ * write a 3.84 GB copy (profiles/r04_wn_hll_tile_panels.md).
+ */
+__device__ __forceinline__ uint64_t entry_key(uint64_t bucket, unsigned col_low,
+                                              unsigned row_in_tile, int shift,
+                                              int rbits) {
+    return (((bucket << shift) | col_low) << rbits) | row_in_tile;
+}
+
 __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
-                                int pm_grid, uint64_t nbuckets,
+                                int rbits, int pm_grid, uint64_t nbuckets,
                                 const int *__restrict__ long_row, int nlong,
                                 const int *__restrict__ irp,
-                                const int *__restrict__ ja, uint64_t *key,
-                                unsigned *idx) {
-    /* 8 lanes per row keep the writes reasonably coalesced */
+                                const int *__restrict__ ja,
+                                const double *__restrict__ as, uint64_t *key,
+                                double *val) {
+    /* 8 lanes per row keep the accesses reasonably coalesced */
     const int sub = threadIdx.x & 7;
     const unsigned low = (1u << shift) - 1u;
-    const uint64_t dropped = nbuckets << shift;
+    const uint64_t dropped = nbuckets << (shift + rbits);
     /* grid-stride over the rows: 8 work-items per row are more than one
      * launch holds (2^32) beyond 2^29 rows */
     const long long step = ((long long)gridDim.x * blockDim.x) >> 3;
     for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
          row < M; row += step) {
         const uint64_t tile = (uint64_t)(row / tile_rows);
+        const unsigned rit = (unsigned)(row - (long long)tile * tile_rows);
         /* a long row's entries live beside the copy: dropped from the buckets */
         const bool out = nlong > 0 && in_sorted(long_row, nlong, (int)row);
         /* 64-bit entry index: k + 8 next to INT32_MAX (the entry count's limit) */
@@ -226,10 +246,9 @@ __global__ void k_keys_from_csr(int M, int tile_rows, int panels, int shift,
              k += 8) {
             const unsigned c = (unsigned)ja[k];
             key[k] = out ? dropped
-                         : (bucket_id(tile, c >> shift, panels, pm_grid)
-                            << shift) |
-                               (c & low);
-            idx[k] = (unsigned)k;
+                         : entry_key(bucket_id(tile, c >> shift, panels, pm_grid),
+                                     c & low, rit, shift, rbits);
+            val[k] = as[k];
         }
     }
 }
@@ -288,23 +307,26 @@ __global__ void k_hll_keep_flags(int M, int nb, int64_t slots,
         atomicAdd(count, mine);
 }
 
-/* key of kept slot idx[r] (the list the compaction wrote, ascending) */
+/* key and value of kept slot idx[r] (the list the compaction wrote,
+ * ascending; identity: every stored slot is kept and no list exists) */
 __global__ void k_keys_from_hll(int M, int nb, int64_t n, int tile_rows,
-                                int panels, int shift, int pm_grid,
+                                int panels, int shift, int rbits, int pm_grid,
                                 int col_major, const int64_t *__restrict__ off,
-                                const int *__restrict__ ja, int identity,
-                                unsigned *idx, uint64_t *key) {
+                                const int *__restrict__ ja,
+                                const double *__restrict__ as, int identity,
+                                const unsigned *__restrict__ idx, uint64_t *key,
+                                double *val) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n)
         return;
-    if (identity) /* every stored slot is kept: no list was compacted */
-        idx[r] = (unsigned)r;
-    const int64_t t = idx[r];
+    const int64_t t = identity ? r : (int64_t)idx[r];
     const int row = hll_slot_row(t, M, nb, col_major, off);
     const uint64_t tile = (uint64_t)(row / tile_rows);
     const unsigned low = (1u << shift) - 1u;
     const unsigned c = (unsigned)ja[t];
-    key[r] = (bucket_id(tile, c >> shift, panels, pm_grid) << shift) | (c & low);
+    key[r] = entry_key(bucket_id(tile, c >> shift, panels, pm_grid), c & low,
+                       (unsigned)(row - (int)tile * tile_rows), shift, rbits);
+    val[r] = as[t];
 }
 
 /*
@@ -332,70 +354,25 @@ __device__ __forceinline__ int64_t block_val_slot(int64_t r) {
     return (r & ~(int64_t)255) + (u < 2 ? 2 * L + u : 128 + 2 * L + (u - 2));
 }
 
-/* row of a source position: CSR needs a search in irp, HLL decodes the slot */
-__global__ void k_tile_gather_csr(int64_t n, int M, int tile_rows, int shift,
-                                  const unsigned *__restrict__ idx,
-                                  const int *__restrict__ irp,
-                                  const int *__restrict__ ja,
-                                  const double *__restrict__ as,
-                                  const uint64_t *__restrict__ skey,
-                                  const int64_t *__restrict__ raw,
-                                  const int64_t *__restrict__ bptr,
-                                  unsigned *tent, double *tval) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+/* sorted pair k -> its slots of the copy: ENT = row in tile << shift | column
+ * in panel (both in the key), VAL = the value the sort carried.  Reads and
+ * writes whole lines (a wavefront's 64 pairs land inside one 256-slot block) */
+__global__ void k_place(int64_t n, int shift, int rbits,
+                        const uint64_t *__restrict__ skey,
+                        const double *__restrict__ sval,
+                        const int64_t *__restrict__ raw,
+                        const int64_t *__restrict__ bptr, unsigned *tent,
+                        double *tval) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n)
         return;
-    const unsigned t = idx[k];
-    const uint64_t bk = skey[k] >> shift; /* bucket */
-    const int64_t rk = k - raw[bk];       /* rank inside the bucket */
-    const int64_t dst = bptr[bk] + block_ent_slot(rk);
-    const int64_t vdst = bptr[bk] + block_val_slot(rk);
-    int lo = 0, hi = M; /* last row with irp[row] <= t */
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if ((unsigned)irp[mid] <= t)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    tent[dst] = ((unsigned)(lo % tile_rows) << shift) |
-                ((unsigned)ja[t] & ((1u << shift) - 1u));
-    tval[vdst] = as[t];
-}
-
-__global__ void k_tile_gather_hll(int64_t n, int M, int nb, int tile_rows,
-                                  int shift, int col_major,
-                                  const unsigned *__restrict__ idx,
-                                  const int64_t *__restrict__ off,
-                                  const int *__restrict__ ja,
-                                  const double *__restrict__ as,
-                                  const uint64_t *__restrict__ skey,
-                                  const int64_t *__restrict__ raw,
-                                  const int64_t *__restrict__ bptr,
-                                  unsigned *tent, double *tval) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n)
-        return;
-    const unsigned t = idx[k];
-    const uint64_t bk = skey[k] >> shift; /* bucket */
-    const int64_t rk = k - raw[bk];       /* rank inside the bucket */
-    const int64_t dst = bptr[bk] + block_ent_slot(rk);
-    const int64_t vdst = bptr[bk] + block_val_slot(rk);
-    int lo = 0, hi = nb; /* block holding slot t */
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (off[mid] <= (int64_t)t)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const int rows = min(32, M - lo * 32);
-    const unsigned rel = (unsigned)((int64_t)t - off[lo]);
-    const unsigned w = (unsigned)hack_block_width(off, lo, rows);
-    const int i = col_major ? (int)(rel % (unsigned)rows) : (int)(rel / w);
-    tent[dst] = ((unsigned)((lo * 32 + i) % tile_rows) << shift) |
-                ((unsigned)ja[t] & ((1u << shift) - 1u));
-    tval[vdst] = as[t];
+    const uint64_t kk = skey[k];
+    const uint64_t bk = kk >> (shift + rbits); /* bucket */
+    const int64_t rk = k - raw[bk];            /* rank inside the bucket */
+    const unsigned col = (unsigned)(kk >> rbits) & ((1u << shift) - 1u);
+    const unsigned rit = (unsigned)kk & ((1u << rbits) - 1u);
+    tent[bptr[bk] + block_ent_slot(rk)] = (rit << shift) | col;
+    tval[bptr[bk] + block_val_slot(rk)] = sval[k];
 }
 
 /* start of every (tile, panel) bucket: first position with bucket id >= b */
@@ -1062,9 +1039,10 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         return -EOVERFLOW;
     }
     uint64_t *key[2] = {NULL, NULL};
-    unsigned *idx[2] = {NULL, NULL};
+    double *sv[2] = {NULL, NULL}; /* the values the sort carries */
+    unsigned *idx = NULL;         /* HLL source with pads: kept slots */
     uint64_t *skey = NULL;
-    unsigned *sidx = NULL;
+    double *sval = NULL;
     void *tmp = NULL;
     size_t tmp_bytes = 0;
     int64_t *raw = NULL, *padded = NULL; /* unpadded bucket starts, scan input */
@@ -1102,19 +1080,21 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         const size_t na = (size_t)(n_sort > 0 ? n_sort : 1);
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(big_malloc((void **)&key[k], na * sizeof(uint64_t)));
-            HIP_TRY(big_malloc((void **)&idx[k], na * sizeof(unsigned)));
+            HIP_TRY(big_malloc((void **)&sv[k], na * sizeof(double)));
         }
+        if (!irp_or_null && n_sort != slots)
+            HIP_TRY(big_malloc((void **)&idx, na * sizeof(unsigned)));
     }
     skey = key[0];
-    sidx = idx[0];
+    sval = sv[0];
     if (slots > 0) {
         if (irp_or_null) {
             hipLaunchKernelGGL(k_keys_from_csr,
                                dim3((unsigned)std::min<long long>(
                                    ((long long)M * 8 + 255) / 256, 1 << 23)),
                                dim3(256), 0, 0, M, (int)tr, panels, shift,
-                               pm_grid, (uint64_t)nbuckets, P->long_row,
-                               P->nlong, irp_or_null, ja, key[0], idx[0]);
+                               rbits, pm_grid, (uint64_t)nbuckets, P->long_row,
+                               P->nlong, irp_or_null, ja, as, key[0], sv[0]);
         } else if (n_sort > 0) {
             const int identity = n_sort == slots; /* the format padded nothing */
             if (!identity) {
@@ -1123,11 +1103,11 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                 hipcub::CountingInputIterator<unsigned> every_slot(0u);
                 /* the count is known: d_count is only written again */
                 HIP_TRY(hipcub::DeviceSelect::Flagged(st, stb, every_slot, flag,
-                                                      idx[0], d_count,
+                                                      idx, d_count,
                                                       (int)slots, 0));
                 HIP_TRY(big_malloc(&st, stb ? stb : 16));
                 hipError_t e1 = hipcub::DeviceSelect::Flagged(
-                    st, stb, every_slot, flag, idx[0], d_count, (int)slots, 0);
+                    st, stb, every_slot, flag, idx, d_count, (int)slots, 0);
                 if (e1 == hipSuccess)
                     e1 = hipDeviceSynchronize();
                 big_free(st);
@@ -1138,28 +1118,32 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
             hipLaunchKernelGGL(k_keys_from_hll,
                                dim3((unsigned)((n_sort + 255) / 256)), dim3(256),
                                0, 0, M, nb, n_sort, (int)tr, panels, shift,
-                               pm_grid, col_major, off_or_null, ja, identity,
-                               idx[0], key[0]);
+                               rbits, pm_grid, col_major, off_or_null, ja, as,
+                               identity, idx, key[0], sv[0]);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         tp[1] = build_now_s();
         {
+            big_free(idx); /* the keys are built: the list is not needed */
+            idx = NULL;
             hipcub::DoubleBuffer<uint64_t> dk(key[0], key[1]);
-            hipcub::DoubleBuffer<unsigned> dv(idx[0], idx[1]);
+            hipcub::DoubleBuffer<double> dv(sv[0], sv[1]);
             /* sort only the bits in use: bucket ids up to tiles*panels (the
-             * id of dropped slots) above `shift` column bits */
-            int end_bit = shift + 1;
-            while (end_bit < 64 && (((uint64_t)nbuckets) >> (end_bit - shift)))
+             * id of dropped slots) above `shift` column bits; the row field
+             * below them rides along unsorted (entry_key) */
+            const int kb = shift + rbits;
+            int end_bit = kb + 1;
+            while (end_bit < 64 && (((uint64_t)nbuckets) >> (end_bit - kb)))
                 ++end_bit;
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
-                NULL, tmp_bytes, dk, dv, (int)n_sort, 0, end_bit, 0));
+                NULL, tmp_bytes, dk, dv, (int)n_sort, rbits, end_bit, 0));
             HIP_TRY(big_malloc(&tmp, tmp_bytes ? tmp_bytes : 16));
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(
-                tmp, tmp_bytes, dk, dv, (int)n_sort, 0, end_bit, 0));
+                tmp, tmp_bytes, dk, dv, (int)n_sort, rbits, end_bit, 0));
             HIP_TRY(hipDeviceSynchronize());
             skey = dk.Current();
-            sidx = dv.Current();
+            sval = dv.Current();
         }
     }
     tp[2] = build_now_s();
@@ -1173,7 +1157,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
                           ((size_t)buckets + 1) * sizeof(int64_t)));
         HIP_TRY(hipMalloc((void **)&P->blen, ((size_t)buckets + 1) * sizeof(int)));
         hipLaunchKernelGGL(k_bucket_bounds, dim3(gb), dim3(256), 0, 0, buckets,
-                           n_sort, shift, skey, raw);
+                           n_sort, shift + rbits, skey, raw);
         hipLaunchKernelGGL(k_bucket_sizes, dim3(gb), dim3(256), 0, 0, buckets,
                            (int64_t)256, raw, P->blen, padded);
         HIP_TRY(hipGetLastError());
@@ -1254,15 +1238,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     }
     if (P->nnz > 0) {
         const unsigned g = (unsigned)((P->nnz + 255) / 256);
-        if (irp_or_null)
-            hipLaunchKernelGGL(k_tile_gather_csr, dim3(g), dim3(256), 0, 0,
-                               P->nnz, M, (int)tr, shift, sidx, irp_or_null,
-                               ja, as, skey, raw, P->bptr, P->ent, P->val);
-        else
-            hipLaunchKernelGGL(k_tile_gather_hll, dim3(g), dim3(256), 0, 0,
-                               P->nnz, M, nb, (int)tr, shift, col_major, sidx,
-                               off_or_null, ja, as, skey, raw, P->bptr, P->ent,
-                               P->val);
+        hipLaunchKernelGGL(k_place, dim3(g), dim3(256), 0, 0, P->nnz, shift,
+                           rbits, skey, sval, raw, P->bptr, P->ent, P->val);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -1280,7 +1257,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     tp[4] = build_now_s();
     snprintf(g_build_phases, sizeof g_build_phases,
              "%lld of %lld slots sorted: alloc+keys %.3f s, sort %.3f, bucket "
-             "tables %.3f, gather %.3f",
+             "tables %.3f, place %.3f",
              (long long)n_sort, (long long)slots, tp[1] > 0 ? tp[1] - tp[0] : 0.0,
              tp[1] > 0 ? tp[2] - tp[1] : 0.0, tp[3] - tp[2], tp[4] - tp[3]);
     *out = P;
@@ -1288,8 +1265,9 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
 fail:
     for (int k = 0; k < 2; ++k) {
         big_free(key[k]);
-        big_free(idx[k]);
+        big_free(sv[k]);
     }
+    big_free(idx);
     big_free(tmp);
     big_free(flag);
     (void)hipFree(d_count);
