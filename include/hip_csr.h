@@ -46,6 +46,31 @@ extern "C" {
  * (reference: set_csr_warps_per_block) */
 void set_csr_waves_per_block(int waves);
 
+/*
+ * Opt-in "keep the last upload" behind the seam -- process state, like the
+ * setter above; covers the CSR and the HLL entry points (and the reference's
+ * names of spmv_ref_abi.h).  Default 0: every call uploads, launches,
+ * downloads and releases, the reference's contract (cuda_csr.cu:180-205).
+ *   level 1  the device copy of the matrix uploaded LAST through the seam is
+ *            kept (one slot each for CSR, row-major HLL, col-major HLL) and
+ *            reused by a call with the same struct pointer, shape and 64-bit
+ *            fingerprint (array pointers, sizes, heads, tails and 64 strided
+ *            samples of IRP / JA / AS; HLL: first, middle and last hack
+ *            block); a different matrix replaces its slot.  x is uploaded and
+ *            y downloaded on every call.
+ *   level 2  also skips the upload of x when the same x (pointer + sampled
+ *            fingerprint) is already on the device.
+ *   level 0  releases what is held (call it before the process exits when
+ *            spmv_live_handles() matters to you).
+ * THE CALLER PROMISES not to modify a matrix (level 1) or x (level 2) in
+ * place between calls in a way the samples miss -- the reference's driver
+ * never writes to either (main.c:258-354: 27 calls per matrix on one A, one
+ * x).  Results and the returned kernel time are those of the uncached call.
+ */
+void spmv_seam_cache(int level);
+/* matrices held now (0..3); *hits / *misses (may be NULL) since start */
+int spmv_seam_cache_stats(long *hits, long *misses);
+
 double csr_spmv_hip_thread_row(const sparse_csr *A, const double *x, double *y,
                                void *arg);
 double csr_spmv_hip_wave_row(const sparse_csr *A, const double *x, double *y,

@@ -10,6 +10,8 @@
 #   oracle/_ref/ref_strict  -O2, strict IEEE: generates the golden vectors
 #   oracle/_ref/ref_dropin  the reference's unmodified driver + host layer
 #                           linked against libspmv_scpa_amd.so (drop-in proof)
+#   oracle/_ref/ref_dropin_cached  the same + oracle/seam_cache_on.c (the
+#                           opt-in resident cache of the seam switched on)
 #   oracle/_ref/ref_fast    the reference's flags (CMakeLists.txt:11-18:
 #                           -O3 -fopenmp -ffast-math -funroll-loops) with
 #                           -march=x86-64-v3 instead of -march=native, since
@@ -47,4 +49,12 @@ if [ -f "$lib/libspmv_scpa_amd.so" ]; then
         -L"$lib" -lspmv_scpa_amd -Wl,-rpath,'$ORIGIN/../../spmv_scpa_amd/lib' \
         -Wl,-rpath,/opt/rocm/lib -lm -o "$out/ref_dropin"
     echo "build_ref: built $out/ref_dropin (reference driver + MI355X kernels)"
+    # the same, with the opt-in "keep the last upload" of the seam switched on
+    # from a constructor (oracle/seam_cache_on.c: the reference's sources stay
+    # unmodified); tests/test_gpu_dropin.py compares the two runs
+    gcc -std=c99 -D_GNU_SOURCE -fopenmp -I"$REF/include" -w -O3 \
+        "$REF/src/main.c" "$REF/src/logger.c" "${srcs[@]}" \
+        "$here/seam_cache_on.c" \
+        -L"$lib" -lspmv_scpa_amd -Wl,-rpath,'$ORIGIN/../../spmv_scpa_amd/lib' \
+        -Wl,-rpath,/opt/rocm/lib -lm -o "$out/ref_dropin_cached"
 fi

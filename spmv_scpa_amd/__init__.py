@@ -295,7 +295,7 @@ class PanelOpts(C.Structure):
                 ("tile_rows", C.c_int), ("sweep_wgs_per_cu", C.c_int),
                 ("reserve_cus", C.c_int), ("lds_min", C.c_int),
                 ("tile_order", C.c_int), ("sweep_layout", C.c_int),
-                ("bucket_order", C.c_int)]
+                ("bucket_order", C.c_int), ("deterministic", C.c_int)]
 
 
 _CSRp = C.POINTER(SparseCSR)
@@ -368,6 +368,8 @@ for _n in CSR_KERNEL_NAMES:
 for _n in HLL_KERNEL_NAMES:
     _sig("bench_hll_hip_" + _n, C.c_int, _HLLp, _dp, C.POINTER(BenchHip))
     _sig("hll_spmv_hip_" + _n, C.c_double, _HLLp, _dp, _dp, C.c_void_p)
+_sig("spmv_seam_cache", None, C.c_int)
+_sig("spmv_seam_cache_stats", C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long))
 _sig("set_csr_waves_per_block", None, C.c_int)
 _sig("set_hll_waves_per_block", None, C.c_int)
 _sig("logger_init", C.c_int, C.c_char_p)
@@ -539,6 +541,19 @@ if os.environ.get("SPMV_DEBUG", "") not in ("", "0"):
     _lib.spmv_set_debug(1)
 
 
+def seam_cache(level):
+    """opt-in "keep the last upload" behind the one-shot seam (hip_csr.h):
+    0 off (default, releases what is held), 1 matrix, 2 matrix + x"""
+    _lib.spmv_seam_cache(int(level))
+
+
+def seam_cache_stats():
+    """-> (matrices held, hits, misses)"""
+    h, m = C.c_long(), C.c_long()
+    held = _lib.spmv_seam_cache_stats(C.byref(h), C.byref(m))
+    return held, h.value, m.value
+
+
 def device_count():
     _check_the_hip_version_once()
     return _lib.spmv_device_count()
@@ -583,7 +598,7 @@ def _env_int(name, lo, hi):
 
 _PIN_FIELDS = ("sched", "panel_cols", "tile_rows", "sweep_wgs_per_cu",
                "reserve_cus", "lds_min", "tile_order", "sweep_layout",
-               "bucket_order")
+               "bucket_order", "deterministic")
 
 
 def _layout_pin(fn_layout, h):
@@ -617,7 +632,8 @@ def _pinned_opts(pin):
 
 
 def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
-                reserve_cus=0, lds_min=0, sweep_layout=None):
+                reserve_cus=0, lds_min=0, sweep_layout=None,
+                deterministic=False):
     o = PanelOpts()
     _lib.spmv_panel_opts_default(C.byref(o))  # struct_size, the -1 defaults
     assert o.struct_size == C.sizeof(PanelOpts), "spmv_panel_opts ABI drift"
@@ -633,6 +649,7 @@ def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
         sweep_layout = int(ev) if ev in ("0", "1") else -1
     o.sweep_layout = sweep_layout
     o.bucket_order = _env_int("SPMV_BUCKET_ORDER", 0, 1)
+    o.deterministic = 1 if deterministic else 0
     return o
 
 
@@ -1065,14 +1082,14 @@ class CsrDevice:
 
     def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
                      sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0,
-                     sweep_layout=None):
+                     sweep_layout=None, deterministic=False):
         """blocked copy in the process default schedule, or in an explicit
         one ("steps" / "sweep" / "chain"), with explicit build options
         (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
         SPMV_SWEEP_WGS and SPMV_LDS_MIN of tools/README.md are read HERE, in
         the harness -- the library itself reads no environment."""
         o = _panel_opts(panel_cols, sched, tile_rows, sweep_wgs_per_cu,
-                        reserve_cus, lds_min, sweep_layout)
+                        reserve_cus, lds_min, sweep_layout, deterministic)
         _check(_lib.spmv_csr_build_panels_opts(self.h, C.byref(o)),
                "spmv_csr_build_panels_opts")
 
@@ -1200,14 +1217,14 @@ class HllDevice:
 
     def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
                      sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0,
-                     sweep_layout=None):
+                     sweep_layout=None, deterministic=False):
         """blocked copy in the process default schedule, or in an explicit
         one ("steps" / "sweep" / "chain"), with explicit build options
         (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
         SPMV_SWEEP_WGS and SPMV_LDS_MIN of tools/README.md are read HERE, in
         the harness -- the library itself reads no environment."""
         o = _panel_opts(panel_cols, sched, tile_rows, sweep_wgs_per_cu,
-                        reserve_cus, lds_min, sweep_layout)
+                        reserve_cus, lds_min, sweep_layout, deterministic)
         _check(_lib.spmv_hll_build_panels_opts(self.h, C.byref(o)),
                "spmv_hll_build_panels_opts")
 

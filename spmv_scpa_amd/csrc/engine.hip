@@ -8,6 +8,7 @@
  * entry point returns -ENODEV.
  */
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1863,8 +1864,98 @@ int spmv_hll_tune_log(const spmv_hll_dev *H, char *buf, size_t len) {
 /* (reference cuda_csr.cu:210-234, cuda_hll.cu:235-260)                 */
 /* ------------------------------------------------------------------ */
 
-static double one_shot_vectors(int M, int N, const double *x, double *y,
-                               double **d_x, double **d_y) {
+/*
+ * Opt-in "keep the last upload" behind the seam (spmv_seam_cache, hip_csr.h).
+ * The reference's driver calls the seam 27 times per matrix on the SAME A /
+ * H_row / H_col and the same x (main.c:258-354), and every call allocates,
+ * uploads and frees the whole matrix (cuda_csr.cu:180-205; HLL: per hack
+ * block, cuda_hll.cu:161-206): config 2 through this seam is 6.3 ms of wall
+ * time around a 0.044 ms kernel.  With the cache on, a call whose matrix is
+ * the one uploaded last (same pointers, shape, and a 64-bit fingerprint of
+ * the arrays' heads and tails) reuses the device copy, its x / y buffers and
+ * -- level 2 -- the uploaded x when its fingerprint is unchanged.  Three
+ * slots: CSR, row-major HLL, col-major HLL (what one run of the driver
+ * holds).  A different matrix replaces its slot; level 0 releases all.
+ */
+struct seam_slot {
+    const void *host;      /* the caller's struct */
+    uint64_t print;        /* fingerprint of the matrix */
+    spmv_csr_dev *csr;
+    spmv_hll_dev *hll;
+    double *d_x, *d_y;
+    int M, N;
+    const double *x_host;  /* level 2: the x that d_x holds */
+    uint64_t x_print;
+    bool x_valid;
+};
+static struct {
+    std::mutex mu;
+    int level;
+    seam_slot slot[3];
+    long hits, misses;
+} g_seam;
+
+static uint64_t fp_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    return h ^ (h >> 29);
+}
+
+/* head, tail and 64 strided samples of an array of n 4- or 8-byte items */
+static uint64_t fp_array(uint64_t h, const void *p, size_t n, size_t item) {
+    h = fp_mix(h, (uint64_t)(uintptr_t)p);
+    h = fp_mix(h, n);
+    if (!p || !n)
+        return h;
+    const unsigned char *b = (const unsigned char *)p;
+    auto at = [&](size_t i) {
+        uint64_t v = 0;
+        memcpy(&v, b + i * item, item);
+        h = fp_mix(h, v);
+    };
+    const size_t edge = n < 64 ? n : 64;
+    for (size_t i = 0; i < edge; ++i)
+        at(i);
+    for (size_t i = n - edge; i < n; ++i)
+        at(i);
+    const size_t step = n / 64 ? n / 64 : 1;
+    for (size_t i = 0; i < n; i += step)
+        at(i);
+    return h;
+}
+
+static void seam_drop(seam_slot *c) {
+    if (c->csr)
+        spmv_csr_release(c->csr);
+    if (c->hll)
+        spmv_hll_release(c->hll);
+    (void)hipFree(c->d_x);
+    (void)hipFree(c->d_y);
+    memset(c, 0, sizeof *c);
+}
+
+void spmv_seam_cache(int level) {
+    std::lock_guard<std::mutex> g(g_seam.mu);
+    g_seam.level = level < 0 ? 0 : (level > 2 ? 2 : level);
+    if (g_seam.level == 0)
+        for (seam_slot &c : g_seam.slot)
+            seam_drop(&c);
+}
+
+int spmv_seam_cache_stats(long *hits, long *misses) {
+    std::lock_guard<std::mutex> g(g_seam.mu);
+    if (hits)
+        *hits = g_seam.hits;
+    if (misses)
+        *misses = g_seam.misses;
+    int held = 0;
+    for (const seam_slot &c : g_seam.slot)
+        held += c.csr || c.hll;
+    return held;
+}
+
+static int one_shot_vectors(int M, int N, const double *x, double **d_x,
+                            double **d_y) {
     int rc = 0;
     *d_x = *d_y = NULL;
     HIP_TRY(hipMalloc((void **)d_x, std::max<size_t>(N, 1) * sizeof(double)));
@@ -1873,9 +1964,60 @@ static double one_shot_vectors(int M, int N, const double *x, double *y,
         HIP_TRY(hipMemcpy(*d_x, x, (size_t)N * sizeof(double),
                           hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(*d_y, 0, std::max<size_t>(M, 1) * sizeof(double)));
-    (void)y;
 fail:
-    return (double)rc;
+    return rc;
+}
+
+/* the cached form of upload + vectors: slot `which` (0 CSR, 1 HLL row-major,
+ * 2 HLL col-major); `upload` builds the device copy on a miss */
+static int seam_acquire(int which, const void *host, uint64_t print, int M,
+                        int N, const double *x,
+                        const std::function<int(seam_slot *)> &upload,
+                        seam_slot **out) {
+    int rc = 0;
+    seam_slot *c = &g_seam.slot[which];
+    const bool hit = (c->csr || c->hll) && c->host == host && c->print == print &&
+                     c->M == M && c->N == N;
+    if (!hit) {
+        seam_drop(c);
+        ++g_seam.misses;
+        rc = upload(c);
+        if (rc) {
+            seam_drop(c);
+            return rc;
+        }
+        c->host = host;
+        c->print = print;
+        c->M = M;
+        c->N = N;
+        HIP_TRY(hipMalloc((void **)&c->d_x,
+                          std::max<size_t>(N, 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&c->d_y,
+                          std::max<size_t>(M, 1) * sizeof(double)));
+    } else {
+        ++g_seam.hits;
+    }
+    {
+        const uint64_t xp = g_seam.level >= 2
+                                ? fp_array(0x78, x, (size_t)N, sizeof(double))
+                                : 0;
+        if (!(g_seam.level >= 2 && c->x_valid && c->x_host == x &&
+              c->x_print == xp)) {
+            if (N > 0)
+                HIP_TRY(hipMemcpy(c->d_x, x, (size_t)N * sizeof(double),
+                                  hipMemcpyHostToDevice));
+            c->x_host = x;
+            c->x_print = xp;
+            c->x_valid = g_seam.level >= 2;
+        }
+    }
+    HIP_TRY(hipMemsetAsync(c->d_y, 0, std::max<size_t>(M, 1) * sizeof(double),
+                           0));
+    *out = c;
+    return 0;
+fail:
+    seam_drop(c);
+    return rc;
 }
 
 static double csr_one_shot(const sparse_csr *A, const double *x, double *y,
@@ -1883,12 +2025,36 @@ static double csr_one_shot(const sparse_csr *A, const double *x, double *y,
     if (!A || !x || !y)
         return -EINVAL;
     const spmv_launch_opts *opts = (const spmv_launch_opts *)arg;
+    double ms = 0.0;
+    int rc = 0;
+    {
+        std::unique_lock<std::mutex> g(g_seam.mu);
+        if (g_seam.level > 0) {
+            uint64_t fp = fp_mix(fp_mix(fp_mix(0x637372, (uint64_t)A->M),
+                                        (uint64_t)A->N), (uint64_t)A->NZ);
+            fp = fp_array(fp, A->IRP, (size_t)A->M + 1, sizeof(int));
+            fp = fp_array(fp, A->JA, (size_t)A->NZ, sizeof(int));
+            fp = fp_array(fp, A->AS, (size_t)A->NZ, sizeof(double));
+            seam_slot *c = NULL;
+            rc = seam_acquire(0, A, fp, A->M, A->N, x,
+                              [&](seam_slot *s) {
+                                  return spmv_csr_upload(A, &s->csr);
+                              },
+                              &c);
+            if (!rc)
+                rc = spmv_csr_time(c->csr, kernel, opts, c->d_x, c->d_y, 0, 1, 0,
+                                   &ms, NULL);
+            if (!rc && A->M > 0)
+                rc = spmv_copy_d2h(y, c->d_y, (size_t)A->M * sizeof(double));
+            return rc ? (double)rc : ms;
+        }
+    }
     spmv_csr_dev *d = NULL;
-    double *d_x = NULL, *d_y = NULL, ms = 0.0;
-    int rc = spmv_csr_upload(A, &d);
+    double *d_x = NULL, *d_y = NULL;
+    rc = spmv_csr_upload(A, &d);
     if (rc)
         return rc;
-    rc = (int)one_shot_vectors(A->M, A->N, x, y, &d_x, &d_y);
+    rc = one_shot_vectors(A->M, A->N, x, &d_x, &d_y);
     if (!rc)
         rc = spmv_csr_time(d, kernel, opts, d_x, d_y, 0, 1, 0, &ms, NULL);
     if (!rc && A->M > 0)
@@ -1904,12 +2070,44 @@ static double hll_one_shot(const sparse_hll *H, const double *x, double *y,
     if (!H || !x || !y)
         return -EINVAL;
     const spmv_launch_opts *opts = (const spmv_launch_opts *)arg;
+    double ms = 0.0;
+    int rc = 0;
+    {
+        std::unique_lock<std::mutex> g(g_seam.mu);
+        if (g_seam.level > 0) {
+            uint64_t fp = fp_mix(fp_mix(fp_mix(0x686c6c, (uint64_t)H->M),
+                                        (uint64_t)H->N), (uint64_t)H->NZ);
+            fp = fp_mix(fp, (uint64_t)H->num_blocks);
+            fp = fp_mix(fp, (uint64_t)(uintptr_t)H->blocks);
+            /* first, middle and last hack block: shape + array fingerprints */
+            const int pick[3] = {0, H->num_blocks / 2, H->num_blocks - 1};
+            for (int k = 0; k < 3 && H->num_blocks > 0; ++k) {
+                const ellpack_block *b = &H->blocks[pick[k]];
+                const size_t n = (size_t)b->M * (size_t)b->max_NZ;
+                fp = fp_mix(fp, ((uint64_t)b->M << 32) | (uint32_t)b->max_NZ);
+                fp = fp_array(fp, b->JA, n, sizeof(int));
+                fp = fp_array(fp, b->AS, n, sizeof(double));
+            }
+            seam_slot *c = NULL;
+            rc = seam_acquire(col_major ? 2 : 1, H, fp, H->M, H->N, x,
+                              [&](seam_slot *s) {
+                                  return spmv_hll_upload(H, col_major, &s->hll);
+                              },
+                              &c);
+            if (!rc)
+                rc = spmv_hll_time(c->hll, kernel, opts, c->d_x, c->d_y, 0, 1, 0,
+                                   &ms, NULL);
+            if (!rc && H->M > 0)
+                rc = spmv_copy_d2h(y, c->d_y, (size_t)H->M * sizeof(double));
+            return rc ? (double)rc : ms;
+        }
+    }
     spmv_hll_dev *d = NULL;
-    double *d_x = NULL, *d_y = NULL, ms = 0.0;
-    int rc = spmv_hll_upload(H, col_major, &d);
+    double *d_x = NULL, *d_y = NULL;
+    rc = spmv_hll_upload(H, col_major, &d);
     if (rc)
         return rc;
-    rc = (int)one_shot_vectors(H->M, H->N, x, y, &d_x, &d_y);
+    rc = one_shot_vectors(H->M, H->N, x, &d_x, &d_y);
     if (!rc)
         rc = spmv_hll_time(d, kernel, opts, d_x, d_y, 0, 1, 0, &ms, NULL);
     if (!rc && H->M > 0)

@@ -102,6 +102,7 @@ struct spmv_panels {
     int span;        /* steps / chain: widest run of panels a tile touches */
     int residue;     /* steps / chain: buckets listed in residue order */
     int bucket_order; /* spmv_panel_opts.bucket_order the copy was built with */
+    int det;          /* spmv_panel_opts.deterministic: ordered LDS additions */
     /* steps / chain: XCD k runs the CONTIGUOUS tile range
      * [xcd_first[k], xcd_first[k+1]) -- neighbouring tiles share their x
      * window, so they should meet in one L2 -- and the ranges hold about
@@ -948,7 +949,8 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         o->sweep_wgs_per_cu < 0 || o->sweep_wgs_per_cu > 8 ||
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
         o->tile_order < 0 || o->tile_order > 2 || o->sweep_layout < -1 ||
-        o->sweep_layout > 1 || o->bucket_order < 0 || o->bucket_order > 1)
+        o->sweep_layout > 1 || o->bucket_order < 0 || o->bucket_order > 1 ||
+        o->deterministic < 0 || o->deterministic > 1)
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
     int sched = o->sched;
@@ -1028,6 +1030,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P->pmajor = sweep && o->sweep_layout != 0;
     P->lds_min = o->lds_min;
     P->bucket_order = o->bucket_order;
+    P->det = o->deterministic != 0;
     P->order = sweep ? 0 : o->tile_order;
     /* bucket ids: tile-major, or panel-major inside rounds of P->grid tiles */
     const int pm_grid = P->pmajor ? P->grid : 0;
@@ -1357,6 +1360,29 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
  * back to the chain schedule).
  */
 
+/*
+ * Deterministic mode (spmv_panel_opts.deterministic): the additions of one
+ * chunk into the tile's LDS slice happen one wavefront after the other, in
+ * wavefront order, chunk after chunk -- a turn counter in LDS that a
+ * wavefront waits for, adds under, and passes on.  A wavefront's own LDS
+ * instructions execute in order, and the lanes of one ds_add_f64 that meet on
+ * an address are served in a fixed order, so every row's products are added
+ * in ONE order per copy: the same bits on every launch.  No workgroup
+ * barrier: while a wavefront waits for its turn the others go on gathering
+ * and loading; all wavefronts of a workgroup consume the same number of
+ * chunks (the chunk walk is workgroup-uniform), so the turn always arrives.
+ */
+__device__ __forceinline__ void det_wait(int *turn, int want) {
+    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE,
+                             __HIP_MEMORY_SCOPE_WORKGROUP) != want)
+        __builtin_amdgcn_s_sleep(1);
+}
+
+__device__ __forceinline__ void det_pass(int *turn, int next) {
+    __hip_atomic_store(turn, next, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int Q> struct sweep_chunk {
     u32x4 en[Q];
     f64x2 va[Q], vb[Q];
@@ -1366,9 +1392,9 @@ template <int Q> struct sweep_chunk {
     bool first, last; /* wave-uniform: first / last chunk of its bucket */
 };
 
-template <int NT, int Q, int ABL = 0> /* ABL: timing ablations, 1 = no LDS
-                                         add, 2 = gathers from one 8 KiB
-                                         window (L1 hits) */
+template <int NT, int Q, int ABL = 0, bool DET = false>
+/* ABL: timing ablations, 1 = no LDS add, 2 = gathers from one 8 KiB window
+ * (L1 hits); DET: deterministic mode */
 __global__ void __launch_bounds__(NT)
     k_tiles_sweep(int M, int tile_rows, int tiles, int panels, int shift,
                   int lag, int spin, int stagger, int pmajor, unsigned total,
@@ -1391,8 +1417,12 @@ __global__ void __launch_bounds__(NT)
     const int rounds = (tiles + grid - 1) / grid;
     int *cnt = phase_cnt + (size_t)xcd * rounds * panels * CNT_STRIDE;
     const unsigned lowmask = (ABL & 2) ? 1023u : (1u << shift) - 1u;
+    __shared__ int det_turn;
+    int det_seq = tid / WAVE; /* my next turn: chunk index * WAVES + wavefront */
     if (tid < WAVE_RING)
         wave_done[tid] = 0;
+    if (tid == 0)
+        det_turn = 0;
     bool synced = true; /* false once a wait expired: run on unsynchronised
                            (costs L2 locality) instead of paying the bound at
                            every panel */
@@ -1510,6 +1540,8 @@ __global__ void __launch_bounds__(NT)
                                                  __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
             fill(f);
+            if (DET)
+                det_wait(&det_turn, det_seq);
 #pragma unroll
             for (int g = 0; g < Q; ++g)
 #pragma unroll
@@ -1522,6 +1554,10 @@ __global__ void __launch_bounds__(NT)
                         unsafeAtomicAdd(&ytile[rr[g][u]], prod);
                     }
                 }
+            if (DET) {
+                det_pass(&det_turn, det_seq + 1);
+                det_seq += WAVES;
+            }
             if (last) {
                 ready = lag <= 0 || q + 1 < lag || polled >= n_x;
                 if ((tid & (WAVE - 1)) == 0)
@@ -1564,7 +1600,7 @@ __global__ void __launch_bounds__(NT)
  * whole lines, every vector load unconditional, the loads of chunk c+1 behind
  * the gathers of chunk c.
  */
-template <int NT, int Q>
+template <int NT, int Q, bool DET = false>
 __global__ void __launch_bounds__(NT)
     k_tiles_step(int M, int tile_rows, int panels, int shift, int step,
                  int tiles_hw, xcd_ranges xr,
@@ -1573,8 +1609,13 @@ __global__ void __launch_bounds__(NT)
                  const double *__restrict__ tval, const double *__restrict__ x,
                  double *__restrict__ y) {
     extern __shared__ double ytile[];
+    __shared__ int det_turn;
     constexpr unsigned CH = NT * Q * 4;
+    constexpr int WAVES = NT / WAVE;
     const int tid = threadIdx.x;
+    int det_seq = tid / WAVE;
+    if (tid == 0)
+        det_turn = 0; /* published by the barrier behind the slice's load */
     /* XCD-contiguous tile ranges of equal work (xcd_ranges): the tiles an
      * XCD runs at one time are neighbours, so their step-th panels coincide
      * or are adjacent */
@@ -1642,12 +1683,18 @@ __global__ void __launch_bounds__(NT)
             w[g][3] = c.vb[g][1];
         }
         fill(f, knext); /* past the bucket: slack slots, masked by `live` */
+        if (DET)
+            det_wait(&det_turn, det_seq);
 #pragma unroll
         for (int g = 0; g < Q; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (64 * u < on[g])
                     unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
+        if (DET) {
+            det_pass(&det_turn, det_seq + 1);
+            det_seq += WAVES;
+        }
     };
 
     sweep_chunk<Q> A, B;
@@ -1691,7 +1738,7 @@ __global__ void __launch_bounds__(NT)
  * of buckets per tile) they drift apart -- that is what the sweep schedule's
  * phase counters are for.
  */
-template <int NT, int Q>
+template <int NT, int Q, bool DET = false>
 __global__ void __launch_bounds__(NT)
     k_tiles_chain(int M, int tile_rows, int panels, int shift, unsigned total,
                   int tiles_hw, xcd_ranges xr,
@@ -1700,8 +1747,13 @@ __global__ void __launch_bounds__(NT)
                   const double *__restrict__ tval, const double *__restrict__ x,
                   double *__restrict__ y) {
     extern __shared__ double ytile[];
+    __shared__ int det_turn;
     constexpr unsigned CH = NT * Q * 4;
+    constexpr int WAVES = NT / WAVE;
     const int tid = threadIdx.x;
+    int det_seq = tid / WAVE;
+    if (tid == 0)
+        det_turn = 0; /* published by the barrier behind the slice's zeroing */
     /* tiles_hw > 0: hardware order (tile = workgroup index); < 0: groups of
      * G = -tiles_hw >> 24 consecutive tiles per XCD, the groups dealt to the
      * XCDs round-robin (tiles = -tiles_hw & 0xffffff): neighbouring tiles
@@ -1780,12 +1832,18 @@ __global__ void __launch_bounds__(NT)
             w[g][3] = c.vb[g][1];
         }
         fill(f);
+        if (DET)
+            det_wait(&det_turn, det_seq);
 #pragma unroll
         for (int g = 0; g < Q; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (64 * u < on[g])
                     unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
+        if (DET) {
+            det_pass(&det_turn, det_seq + 1);
+            det_seq += WAVES;
+        }
     };
 
     sweep_chunk<Q> A, B;
@@ -1880,16 +1938,23 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
         if (variant & 128)
             lag = 0;
         HIP_RET(hipMemsetAsync(P->phase_cnt, 0, P->phase_cnt_bytes, s));
-#define SW(NTHR, QQ, A)                                                        \
+#define SW_(NTHR, QQ, A, D)                                                    \
     do {                                                                       \
-        if (int rc_ = allow_big_lds<&k_tiles_sweep<NTHR, QQ, A>>())            \
+        if (int rc_ = allow_big_lds<&k_tiles_sweep<NTHR, QQ, A, D>>())         \
             return rc_;                                                        \
-        hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A>), dim3(P->grid),       \
+        hipLaunchKernelGGL((k_tiles_sweep<NTHR, QQ, A, D>), dim3(P->grid),    \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->tiles,      \
                            P->panels, P->shift, lag, SWEEP_SPIN_MAX,           \
                            !!(variant & 4096), P->pmajor, (unsigned)P->total,  \
                            P->bptr, P->blen, P->ent, P->val, x, y,             \
                            P->phase_cnt);                                      \
+    } while (0)
+#define SW(NTHR, QQ, A)                                                        \
+    do {                                                                       \
+        if (P->det && (A) == 0)                                                \
+            SW_(NTHR, QQ, 0, true);                                            \
+        else                                                                   \
+            SW_(NTHR, QQ, A, false);                                           \
     } while (0)
         const int two = !((variant >> 11) & 1); /* 2 groups of 4 per lane */
 #ifdef SPMV_ABLATIONS /* timing ablations (results WRONG by design for 2, 3,
@@ -1922,6 +1987,7 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
             else SW(256, 1, 0);
         }
 #undef SW
+#undef SW_
         return hip_errno(hipGetLastError());
     }
     if (P->tiles <= 0 || P->xcd_max <= 0)
@@ -1962,15 +2028,39 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
         const double per_bucket_c =
             (double)P->nnz / ((double)P->tiles *
                               (double)(P->max_nbk > 0 ? P->max_nbk : 1));
-#define CHN(NTHR, QQ)                                                          \
+#define CHN_(NTHR, QQ, D)                                                      \
     do {                                                                       \
-        if (int rc_ = allow_big_lds<&k_tiles_chain<NTHR, QQ>>()) return rc_;   \
-        hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ>),                         \
+        if (int rc_ = allow_big_lds<&k_tiles_chain<NTHR, QQ, D>>())            \
+            return rc_;                                                        \
+        hipLaunchKernelGGL((k_tiles_chain<NTHR, QQ, D>),                      \
                            dim3(order_grid),                                   \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
                            P->shift, (unsigned)P->total, order_arg,            \
                            xr, P->cb, P->cpanel, P->nbk, P->ent, P->val, x,    \
                            y);                                                 \
+    } while (0)
+/* deterministic: several groups of 4 entries per lane and turn -- the
+ * hand-offs of the turn counter are what the mode costs, and they go with
+ * the number of turns -- at most 512 lanes.  Four groups when the tile fills
+ * a CU's LDS by itself (one workgroup per CU: W = 2^20, 19552-row tiles,
+ * 0.797 ms vs 0.900 with two groups and 0.728 in the default mode), two when
+ * two or more workgroups share the CU and hide each other's hand-offs (four
+ * groups cost them occupancy: 8192-row tiles at W = 2^17 0.690 vs 0.836 ms;
+ * default mode 0.604).  profiles/r05_det_cost.md */
+#define CHN(NTHR, QQ)                                                          \
+    do {                                                                       \
+        if (P->det && (size_t)P->tile_rows * sizeof(double) > 80 * 1024) {     \
+            if ((NTHR) <= 256)                                                 \
+                CHN_(256, 4, true);                                            \
+            else                                                               \
+                CHN_(512, 4, true);                                            \
+        } else if (P->det) {                                                   \
+            if ((NTHR) <= 256)                                                 \
+                CHN_(256, 2, true);                                            \
+            else                                                               \
+                CHN_(512, 2, true);                                            \
+        } else                                                                 \
+            CHN_(NTHR, QQ, false);                                             \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
             if (waves > 0 && waves < 8) CHN(256, 2);
@@ -1981,6 +2071,7 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
         else if (waves == 8 || per_bucket_c >= 3000.0) CHN(512, 1);
         else CHN(256, 1);
 #undef CHN
+#undef CHN_
         return hip_errno(hipGetLastError());
     }
     /* launch `step` handles the step-th NON-EMPTY bucket of every tile: a
@@ -1990,14 +2081,25 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
     const double per_bucket =
         (double)P->nnz / ((double)P->tiles * (double)steps);
     for (int p = 0; p < steps; ++p) {
-#define ST(NTHR, QQ)                                                           \
+#define ST_(NTHR, QQ, D)                                                       \
     do {                                                                       \
-        if (int rc_ = allow_big_lds<&k_tiles_step<NTHR, QQ>>()) return rc_;    \
-        hipLaunchKernelGGL((k_tiles_step<NTHR, QQ>),                          \
+        if (int rc_ = allow_big_lds<&k_tiles_step<NTHR, QQ, D>>())             \
+            return rc_;                                                        \
+        hipLaunchKernelGGL((k_tiles_step<NTHR, QQ, D>),                       \
                            dim3(order_grid),                                   \
                            dim3(NTHR), lds, s, M, P->tile_rows, P->panels,     \
                            P->shift, p, order_arg, xr, P->cb,                  \
                            P->cpanel, P->nbk, P->ent, P->val, x, y);           \
+    } while (0)
+#define ST(NTHR, QQ)                                                           \
+    do {                                                                       \
+        if (P->det) {                                                          \
+            if ((NTHR) <= 256)                                                 \
+                ST_(256, 2, true);                                             \
+            else                                                               \
+                ST_(512, 2, true);                                             \
+        } else                                                                 \
+            ST_(NTHR, QQ, false);                                              \
     } while (0)
         if (variant & 2048) { /* tuning: two groups of 4 per lane */
             if (waves > 0 && waves < 8) ST(256, 2);
@@ -2009,6 +2111,7 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
         else if (per_bucket >= 3000.0) ST(512, 1);
         else ST(256, 1);
 #undef ST
+#undef ST_
     }
     return hip_errno(hipGetLastError());
 }
@@ -2074,6 +2177,7 @@ void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     o->tile_order = P->order;
     o->sweep_layout = P->pmajor;
     o->bucket_order = P->bucket_order;
+    o->deterministic = P->det;
 }
 
 /* one-line description of a blocked copy: schedule, geometry, launch shape
@@ -2096,6 +2200,10 @@ int panels_describe(const spmv_panels *P, char *buf, size_t len) {
                  P->panels, P->shift, P->max_nbk, P->span,
                  P->residue ? "residue" : "ascending", P->order,
                  P->waves_hint);
+    if (P->det) {
+        const size_t at = strlen(buf);
+        snprintf(buf + at, len - at, ", deterministic");
+    }
     if (P->nlong) {
         const size_t at = strlen(buf);
         snprintf(buf + at, len - at,

@@ -97,3 +97,104 @@ def test_product_driver_on_the_irregular_classes(family, rows, k, window,
     assert len(times) >= 9, times
     slow = {k: v for k, v in times.items() if v > 2.0}
     assert not slow, slow
+
+
+DROPIN_CACHED = os.path.join(S.ROOT, "oracle", "_ref", "ref_dropin_cached")
+
+
+@pytest.mark.parametrize("name", ["ragged100", "hub96", "tail40"])
+def test_reference_driver_with_the_seam_cache_on(name, tmp_path):
+    """the reference's unmodified driver + oracle/seam_cache_on.c (the one
+    line `spmv_seam_cache(2)` as a constructor): its own -d validation passes
+    on all 27 calls and the CSVs name the same grid as the uncached run"""
+    if not os.path.exists(DROPIN_CACHED):
+        pytest.skip("oracle/_ref/ref_dropin_cached not built")
+    env = dict(os.environ, OMP_NUM_THREADS="40")
+    grids = []
+    for exe, sub in ((DROPIN, "plain"), (DROPIN_CACHED, "cached")):
+        out = tmp_path / sub
+        out.mkdir()
+        r = subprocess.run([exe, "-m", G.mtx_path(name), "-o", str(out), "-d"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        rows = open(out / "cuda.csv").read().splitlines()
+        assert len(rows) == 1 + 27
+        grids.append([line.split(",")[:8] for line in rows])
+        for line in rows[1:]:
+            assert float(line.split(",")[-2]) > 0.0
+    assert grids[0] == grids[1]
+
+
+def test_seam_cache_keeps_the_last_upload_and_notices_a_change():
+    """spmv_seam_cache (hip_csr.h): hits on the same matrix, bit-equal y,
+    a miss when the matrix changes (other struct, other content at the head),
+    x re-uploaded when it changes; level 0 releases every handle; and a call
+    on a 1M-row matrix costs about the kernel + the y download, not the
+    6 ms of upload it costs uncached (VERDICT r04 weak #10)."""
+    import time
+
+    import numpy as np
+
+    import _oracle as O
+    M = N = 1_000_000
+    A = S.csr_generate(S.SYNTH_BANDED, M, N, 16, 0, 0, 42)
+    IRP, JA, AS = S.csr_arrays(A)
+    x = O.synth_x(7, 0, N)
+    base = S._lib.spmv_live_handles()
+    y0, k0 = S.csr_spmv_hip(A, x, kernel=4)         # uncached
+    assert S._lib.spmv_live_handles() == base
+    S.seam_cache(2)
+    try:
+        held0, h0, m0 = S.seam_cache_stats()
+        y1, _ = S.csr_spmv_hip(A, x, kernel=4)      # miss: uploads, keeps
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            y2, kms = S.csr_spmv_hip(A, x, kernel=4)
+        wall = (time.perf_counter() - t0) * 1e3 / reps
+        held, h, m = S.seam_cache_stats()
+        assert (held, h - h0, m - m0) == (1, reps, 1)
+        assert np.array_equal(y0, y1) and np.array_equal(y0, y2)
+        assert S._lib.spmv_live_handles() == base + 1
+        # other kernels of the same matrix hit too
+        for k in (0, 1, 2, 3):
+            yk, _ = S.csr_spmv_hip(A, x, kernel=k)
+            assert np.allclose(yk, y0, rtol=1e-12, atol=1e-12)
+        assert S.seam_cache_stats()[1] - h0 == reps + 4
+        # x changed in another buffer -> uploaded; same buffer, new content
+        # at the head -> the fingerprint notices
+        x2 = x * 2.0
+        y3, _ = S.csr_spmv_hip(A, x2, kernel=4)
+        assert np.allclose(y3, 2.0 * y0, rtol=1e-13, atol=0)
+        x2[:8] = 0.0
+        y4, _ = S.csr_spmv_hip(A, x2, kernel=4)
+        ref = O.csr_spmv(np.array(IRP), np.array(JA), np.array(AS), x2)
+        assert np.allclose(y4, ref, rtol=1e-12, atol=1e-12)
+        # the matrix changed in place (first value): re-uploaded, not stale
+        AS[0] *= 3.0
+        m_before = S.seam_cache_stats()[2]
+        y5, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert S.seam_cache_stats()[2] == m_before + 1
+        ref = O.csr_spmv(np.array(IRP), np.array(JA), np.array(AS), x)
+        assert np.allclose(y5, ref, rtol=1e-12, atol=1e-12)
+        # HLL slots: row-major and col-major copies are held side by side
+        Hr, Hc = S.csr_to_hll(A, False), S.csr_to_hll(A, True)
+        for _ in range(2):
+            yr, _ = S.hll_spmv_hip(Hr, x, kernel=0)
+            yc, _ = S.hll_spmv_hip(Hc, x, kernel=1)
+            assert np.allclose(yr, ref, rtol=1e-12, atol=1e-12)
+            assert np.allclose(yc, ref, rtol=1e-12, atol=1e-12)
+        assert S.seam_cache_stats()[0] == 3
+        assert S._lib.spmv_live_handles() == base + 3
+        S.hll_free(Hr)
+        S.hll_free(Hc)
+    finally:
+        S.seam_cache(0)
+    assert S.seam_cache_stats()[0] == 0
+    assert S._lib.spmv_live_handles() == base
+    S.csr_free(A)
+    # a resident call = x is there (level 2), memset y, one event-timed launch,
+    # 8 MB of y back over PCIe: well under a millisecond of host time beyond
+    # the download; uncached it was 6.3 ms (DESIGN, one-shot seam)
+    print("seam cache: %.3f ms per call, kernel %.4f ms" % (wall, kms))
+    assert wall < 2.5, wall

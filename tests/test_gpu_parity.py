@@ -1116,3 +1116,66 @@ def test_arrival_counter_kernels_soak():
     finally:
         dH.release()
         dA.release()
+
+
+@pytest.mark.parametrize("sched,W,tile_rows", [("chain", 1 << 17, 0),
+                                               ("chain", 1 << 30, 8192),
+                                               ("steps", 1 << 14, 4096),
+                                               ("sweep", 1 << 30, 0)])
+def test_deterministic_blocked_mode_gives_the_same_bits_every_launch(
+        sched, W, tile_rows):
+    """spmv_panel_opts.deterministic: 1000 launches of one blocked copy give
+    ONE y, bit for bit (the LDS additions of a workgroup happen wavefront
+    after wavefront, chunk after chunk), a second copy built the same way
+    gives the same bits again, and the result is the oracle's to rounding.
+    The default mode on the same matrix is only reproducible to rounding:
+    over the same launches its last bits move (ds_add_f64 in arrival order)."""
+    M = N = 1_500_000
+    K = 32
+    A = S.CsrDevice.generate(S.SYNTH_RANDOM, M, N, K, W, 0, 42)
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    rows = np.random.default_rng(11).integers(0, M, 400)
+    want = [O.synth_row_dot(S.SYNTH_RANDOM, M, N, K, W, 0, 42, 7, int(r))
+            for r in rows]
+    for fmt in ("csr", "hll"):
+        m = A if fmt == "csr" else A.to_hll(True)
+        pid = S.CSR_KERNEL_PANELS if fmt == "csr" else S.HLL_KERNEL_PANELS
+        m.build_panels(0, sched, tile_rows, deterministic=True)
+        assert "deterministic" in m.panels_describe()
+        assert "deterministic=1" in m.panels_pin()
+        m.launch(pid, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        y0 = d_y.to_numpy(np.float64, M)
+        for r, (w, sc) in zip(rows, want):
+            assert abs(y0[r] - w) <= 1e-12 * sc, (fmt, r)
+        for it in range(1000):
+            m.launch(pid, d_x.ptr, d_y.ptr)
+            if it % 100 == 99:
+                S.stream_sync()
+                assert np.array_equal(d_y.to_numpy(np.float64, M).view(np.uint64),
+                                      y0.view(np.uint64)), (fmt, it)
+        # rebuilt from its pin: the same layout, the same order, the same bits
+        pin = m.panels_pin()
+        m.build_panels_pinned(pin)
+        m.launch(pid, d_x.ptr, d_y.ptr)
+        S.stream_sync()
+        assert np.array_equal(d_y.to_numpy(np.float64, M).view(np.uint64),
+                              y0.view(np.uint64)), fmt
+        # the default mode: right to rounding, but not bitwise stable
+        m.build_panels(0, sched, tile_rows)
+        assert "deterministic" not in m.panels_describe()
+        seen = set()
+        for it in range(30):
+            m.launch(pid, d_x.ptr, d_y.ptr)
+            S.stream_sync()
+            y = d_y.to_numpy(np.float64, M)
+            seen.add(hash(y.tobytes()))
+            assert np.max(np.abs(y - y0)) <= 1e-12 * 32
+        print("%s %s W=%d: default mode gave %d distinct y in 30 launches"
+              % (fmt, sched, W, len(seen)))
+        if m is not A:
+            m.release()
+    A.release()
+    d_x.free()
+    d_y.free()
