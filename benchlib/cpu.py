@@ -1,0 +1,147 @@
+"""cpu_baseline leg: the reference's own serial + OpenMP code (oracle/_ref/
+ref_fast) timed on the GPU box's host cores beside the GPU line."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+from .common import (MATRIX_SEED, REF_LADDER, ROOT, X_SEED, _ENV0,
+                     host_cpus)
+
+
+# ---------------------------------------------------------------- CPU baseline
+def thread_ladder(nproc, quota=None):
+    """serial is always timed; OpenMP at the reference's counts (src/main.c:
+    176-180) and at "all cores": every visible hardware thread, or -- under a
+    cgroup CPU quota smaller than that -- the quota, which is all the cores
+    this process can actually run on (256 threads on 16 CPUs of quota measured
+    1.3 GFLOP/s in round 3: an oversubscription figure, not a baseline)"""
+    allc = nproc if not quota or quota >= nproc else max(1, int(quota + 0.999))
+    return sorted({t for t in REF_LADDER if t <= nproc} | {allc})
+
+
+def log_cpu_rows(S, out_dir, name, M, N, nnz, runs, hll_blocks=0):
+    """append the runs to serial.csv / omp.csv through the product's logger
+    (reference schema, logger.c:19-54)"""
+    import ctypes as C
+    os.makedirs(out_dir, exist_ok=True)
+    if S._lib.logger_init(os.fsencode(out_dir)) != 0:
+        return None
+    hdr = S.SparseCSR()
+    hdr.name = name.encode()[:63]
+    hdr.M, hdr.N, hdr.NZ = M, N, nnz
+    hh = S.SparseHLL()
+    hh.name = name.encode()[:63]
+    hh.M, hh.N, hh.NZ = M, N, nnz
+    hh.hack_size, hh.num_blocks = S.HACK_SIZE, hll_blocks
+    for r in runs:
+        b = S.Bench()
+        b.duration_ms, b.gflops = r["median_ms"], r["gflops"]
+        hll = r["format"] == "HLL"
+        if r["bench"] == "serial":
+            if hll:
+                S._lib.log_hll_serial_benchmark(C.byref(hh), b)
+            else:
+                S._lib.log_csr_serial_benchmark(C.byref(hdr), b)
+        else:
+            bo = S.BenchOmp()
+            bo.name = r["bench"].encode()
+            bo.bench, bo.num_threads = b, r["threads"]
+            if hll:
+                S._lib.log_hll_omp_benchmark(C.byref(hh), bo)
+            else:
+                S._lib.log_csr_omp_benchmark(C.byref(hdr), bo)
+    S._lib.logger_close()
+    return out_dir
+
+
+CPU_WINDOW_MS = 300  # >= 3 CFS periods of 100 ms per sample
+
+
+def cpu_baseline(S, kind, M, N, K, W, csv_dir, name, reps=3):
+    """The reference's own serial + OpenMP path (oracle/_ref/ref_fast, built
+    from /root/reference/src by oracle/build_ref.sh with the reference's
+    flags) on the SAME full-size input: CSR at the thread ladder {1, 2, 4, 8,
+    16, 32, 40, all cores} (src/main.c:176-180), then the HLL legs
+    (hll.c:127-150, 178-211) after ONE csr_to_hll: serial and OpenMP at the
+    SAME ladder, as the reference's driver runs them (main.c:176-253), inside
+    a 15 s box (counts that did not fit are named in hll_skipped_threads).  EVERY leg: median of `reps` (>= 3)
+    samples, a sample = the reference's single-shot bench repeated until
+    CPU_WINDOW_MS of run time is covered -- round 3's driver line carried a
+    one-shot 44 ms HLL run at 40 threads under a 16-CPU quota (14.4 GFLOP/s;
+    6.3 on another box): shorter than one CFS period, it ran on burst credit.
+    `value` = the best median, CSR or HLL.  OMP_PROC_BIND=close.  Falls back
+    to the oracle port."""
+    nproc, quota = host_cpus()
+    ladder = thread_ladder(nproc, quota)
+    qtxt = ("cgroup quota %g CPUs of %d visible hardware threads" %
+            (quota, nproc)) if quota else "%d hardware threads" % nproc
+    sample = ("full size: %s %dx%d, %d nnz/row, W=%s, same generator and "
+              "seeds as the GPU run; CSR serial + omp_guided + omp_nnz at "
+              "threads %s, then HLL serial + omp_guided at the same thread "
+              "counts (15 s box); every leg: median of %d samples, each the "
+              "single-shot bench repeated over >= %d ms; %s"
+              % (name, M, N, K, "N" if W >= 2 * N else str(W),
+                 "/".join(str(t) for t in ladder), reps, CPU_WINDOW_MS, qtxt))
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_fast")
+    env = dict(_ENV0, OMP_NUM_THREADS=str(max(ladder)),
+               OMP_PROC_BIND="close", OMP_PLACES="cores",
+               REF_TIME_HLL="ladder", REF_TIME_HLL_BUDGET_MS="15000",
+               REF_TIME_WINDOW_MS=str(CPU_WINDOW_MS))
+    env.pop("OMP_WAIT_POLICY", None)  # the reference runs libgomp's default
+    err = "oracle/_ref/ref_fast not present"
+    if os.path.exists(ref):
+        try:
+            t0 = time.time()
+            out = subprocess.run(
+                [ref, "time", str(kind), str(M), str(N), str(K), str(W),
+                 str(MATRIX_SEED), str(X_SEED), str(reps)]
+                + [str(t) for t in ladder],
+                capture_output=True, text=True, timeout=900, env=env,
+                check=True)
+            res = json.loads(out.stdout)
+            runs = res["runs"]
+            best = max(runs, key=lambda r: r["gflops"])
+            serial = [r for r in runs if r["bench"] == "serial"
+                      and r["format"] == "CSR"][0]
+            hll = [r for r in runs if r["format"] == "HLL"]
+            logged = log_cpu_rows(S, csv_dir, name, M, N, res["nnz"], runs,
+                                  res.get("hll_blocks", 0))
+            # cores = what the best leg could really run on: its threads,
+            # capped by the cgroup CPU quota (40 threads under a 16-CPU quota
+            # are 16 cores' worth of time); `threads` = what it asked for
+            cores = best["threads"] if not quota else max(
+                1, min(best["threads"], int(quota + 0.999)))
+            return {"value": round(best["gflops"], 3), "unit": "GFLOP/s",
+                    "cores": cores, "threads": best["threads"],
+                    "kind": "reference",
+                    "sample": sample,
+                    "best": "%s %s" % (best["format"], best["bench"]),
+                    "serial_csr_gflops": round(serial["gflops"], 3),
+                    "best_hll_gflops": round(max(r["gflops"] for r in hll), 3)
+                    if hll else None,
+                    "host_threads": nproc, "cpu_quota": quota,
+                    "reps": reps, "window_ms": CPU_WINDOW_MS,
+                    "ladder": [[r["format"], r["bench"], r["threads"],
+                                round(r["gflops"], 3)] for r in runs],
+                    "hll_convert_s": round(res.get("hll_prep_ms", 0) / 1e3, 1),
+                    "hll_skipped_threads": res.get("hll_skipped_threads", []),
+                    "csv_dir": logged, "wall_s": round(time.time() - t0, 1)}
+        except Exception as e:  # pragma: no cover - depends on the box
+            err = "ref_fast failed: %r" % (e,)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    rows = min(M, 2_000_000)  # the port is serial numpy/C glue: keep it short
+    IRP, JA, AS = O.synth_csr(kind, rows, N, K, W, MATRIX_SEED)
+    x = O.synth_x(X_SEED, 0, N)
+    ms1 = O.time_csr_ms(IRP, JA, AS, x, 1, 3)
+    msn = O.time_csr_ms(IRP, JA, AS, x, nproc, 3)
+    best_ms, thr = (ms1, 1) if ms1 <= msn else (msn, nproc)
+    return {"value": round(2.0 * len(JA) / (best_ms * 1e6), 3),
+            "unit": "GFLOP/s", "kind": "port", "threads": thr,
+            "cores": thr if not quota else max(1, min(thr, int(quota + 0.999))),
+            "sample": "first %d rows of: %s" % (rows, sample), "note": err,
+            "host_threads": nproc}
+

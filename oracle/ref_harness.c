@@ -303,9 +303,16 @@ static int cmd_time(int argc, char **a) {
      * them bounded instead: ONE conversion after the CSR ladder, then
      * bench_hll_serial and bench_hll_omp at the thread count that was best
      * for CSR, `reps` samples each like every other leg (hll.c:127-150,
-     * 178-211). */
+     * 178-211).  REF_TIME_HLL=ladder does the same conversion after the CSR
+     * ladder and then runs bench_hll_omp at EVERY thread count of the ladder,
+     * as the reference's driver does (main.c:176-253), for as long as the HLL
+     * legs stay inside REF_TIME_HLL_BUDGET_MS (default 15000); the counts
+     * that did not fit are listed in "hll_skipped_threads". */
     const char *eh = getenv("REF_TIME_HLL");
-    const int hll_best = eh && !strcmp(eh, "best");
+    const int hll_ladder = eh && !strcmp(eh, "ladder");
+    const int hll_best = hll_ladder || (eh && !strcmp(eh, "best"));
+    const char *eb = getenv("REF_TIME_HLL_BUDGET_MS");
+    const double hll_budget_ms = eb ? atof(eb) : 15000.0;
     const int with_hll = !hll_best && !(eh && eh[0] == '0');
     sparse_hll *H = with_hll ? csr_to_hll(A, false) : NULL;
     if (with_hll && IS_ERR(H))
@@ -370,6 +377,7 @@ static int cmd_time(int argc, char **a) {
         }
     }
     double hll_prep = 0.0;
+    int skipped[16], nskip = 0;
     if (hll_best) {
         double t1 = wall_ms();
         H = csr_to_hll(A, false);
@@ -379,7 +387,24 @@ static int cmd_time(int argc, char **a) {
         LEG(lt, reps, window_ms, bench b, bench_hll_serial(H, x.data, &b),
             b.duration_ms, vec_put(&b.data));
         EMIT("HLL", "serial", 1);
-        if (best_thr > 1) {
+        if (hll_ladder) {
+            const double t2 = wall_ms();
+            for (int k = 8; k < argc; ++k) {
+                const int thr = atoi(a[k]);
+                if (thr < 2 || thr > omp_get_max_threads())
+                    continue;
+                if (wall_ms() - t2 > hll_budget_ms) { /* out of the time box */
+                    if (nskip < 16)
+                        skipped[nskip++] = thr;
+                    continue;
+                }
+                OMP_WARMUP(thr);
+                LEG(lt, reps, window_ms, bench_omp bo = {.num_threads = thr},
+                    bench_hll_omp(H, x.data, &bo), bo.bench.duration_ms,
+                    vec_put(&bo.bench.data));
+                EMIT("HLL", "omp_guided", thr);
+            }
+        } else if (best_thr > 1) {
             OMP_WARMUP(best_thr);
             LEG(lt, reps, window_ms, bench_omp bo = {.num_threads = best_thr},
                 bench_hll_omp(H, x.data, &bo), bo.bench.duration_ms,
@@ -387,8 +412,11 @@ static int cmd_time(int argc, char **a) {
             EMIT("HLL", "omp_guided", best_thr);
         }
     }
-    printf("], \"hll_prep_ms\": %.3f, \"hll_blocks\": %d}\n", hll_prep,
-           H ? H->num_blocks : 0);
+    printf("], \"hll_prep_ms\": %.3f, \"hll_blocks\": %d, "
+           "\"hll_skipped_threads\": [", hll_prep, H ? H->num_blocks : 0);
+    for (int k = 0; k < nskip; ++k)
+        printf("%s%d", k ? ", " : "", skipped[k]);
+    printf("]}\n");
     return 0;
 }
 

@@ -79,3 +79,25 @@ def test_gpu_count_sweep_passes_g_and_reruns_only_the_multi_gpu_step(tmp_path):
             "-i", "1"])
     (only,) = [c.split() for c in open(log).read().splitlines()]
     assert "-g" not in only and only[:2] == ["-m", str(mdir / "gen.mtx")]
+
+
+def test_partition_option_reaches_the_driver(tmp_path):
+    """run_all.py --gpus N --partition nnz: the driver gets `--partition nnz
+    --ragged-exchange <x>` on every invocation; the default stays silent"""
+    R = load_runner()
+    log = tmp_path / "calls.txt"
+    exe = tmp_path / "fake_driver.sh"
+    exe.write_text("#!/bin/sh\necho \"$@\" >> %s\n" % log)
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    mdir = tmp_path / "mtx"
+    mdir.mkdir()
+    os.symlink(G.mtx_path("gen"), mdir / "gen.mtx")
+    rc = R.main(["-exe", str(exe), "-m", str(mdir), "-res", str(tmp_path / "r"),
+                 "-i", "1", "--gpus", "1,2", "--assume-gpus", "2",
+                 "--partition", "nnz", "--ragged-exchange", "bcast"])
+    assert rc == 0
+    calls = [c.split() for c in open(log).read().splitlines()]
+    assert len(calls) == 2
+    for c in calls:
+        assert c[c.index("--partition") + 1] == "nnz"
+        assert c[c.index("--ragged-exchange") + 1] == "bcast"

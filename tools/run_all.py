@@ -89,6 +89,14 @@ def main(argv=None):
                     help="comma-separated GPU counts, e.g. 1,2,4,8: each "
                          "matrix also runs row-partitioned over that many "
                          "GPUs (driver flag -g)")
+    ap.add_argument("--partition", default="even", choices=["even", "nnz"],
+                    help="--gpus: row ranges of equal row counts, or of "
+                         "near-equal entry counts (driver flag --partition; "
+                         "the multi-GPU form of the reference's "
+                         "partition_csr_rows, csr.c:218-276)")
+    ap.add_argument("--ragged-exchange", default="p2p",
+                    choices=["p2p", "bcast", "padded"],
+                    help="--partition nnz: how the ragged y fragments travel")
     ap.add_argument("--assume-gpus", type=int, default=-1,
                     help="do not query the device count (tests, remote exe)")
     ap.add_argument("--synthetic", action="append", default=[],
@@ -121,7 +129,9 @@ def main(argv=None):
             print("[NOTE] %d GPU(s) visible: skipping the counts %s"
                   % (have, ",".join(map(str, skipped))))
     extra = ["-o", a.res] + (["-d"] if a.debug else []) + \
-        (["--no-cpu"] if a.no_cpu else [])
+        (["--no-cpu"] if a.no_cpu else []) + \
+        (["--partition", a.partition, "--ragged-exchange", a.ragged_exchange]
+         if a.partition != "even" else [])
     failed = 0
     for label, argv_ in plan(jobs, counts, a.i, extra):
         print(label, flush=True)
