@@ -440,7 +440,7 @@ class RankJob:
         one broadcast per rank, all-gather padded to the longest fragment +
         compaction -- so that one scaling run prices every exchange"""
         D = self.D
-        if self.L != 1 or self.halo:
+        if self.halo:
             return None
         out = {}
         for mode in ("p2p", "bcast", "padded"):
@@ -658,7 +658,9 @@ def run_rank(args, argv, omp_team):
             "nnz_per_row": job.K, "nnz_global": job.nnz_global,
             "stored_slots_per_gpu": job.slots,
             "partition": ("nnz-balanced contiguous row ranges (32-aligned; "
-                          "reference csr.c:218-276), ragged fragments"
+                          "reference csr.c:218-276), %s"
+                          % ("ragged fragments" if job.ragged else
+                             "which for these rows ARE the equal row counts")
                           if a.partition == "nnz" else
                           "contiguous row ranges of equal row counts")
             + ", x replicated, y exchanged over RCCL" if world > 1

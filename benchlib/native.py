@@ -53,6 +53,8 @@ def native_mgpu_bench(args, argv, omp_team):
     t_tune = None
     if args.kernel >= 0:
         kernel = args.kernel
+        if labels[kernel] == "tile_panels":  # fixed: default layout
+            g.build_panels()
     else:
         t_tune = time.time()
         kernel = g.autotune()

@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include "csr.h"
+#include "spmv_engine.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -137,6 +138,11 @@ int spmv_mgpu_shard_info(const spmv_mgpu *g, int rank, int64_t *stored,
 /* measured kernel choice for the loaded shards (spmv_*_autotune per device,
  * device 0's pick for all); pass *kernel to spmv_mgpu_spmv() */
 int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel);
+
+/* the 2-D blocked copy (spmv_engine.h) on every shard with one set of build
+ * options (NULL: defaults): needed before naming the blocked kernel id in
+ * spmv_mgpu_spmv / _run without spmv_mgpu_autotune */
+int spmv_mgpu_build_panels(spmv_mgpu *g, const spmv_panel_opts *opts);
 
 /* the gathered y as device `rank` holds it (M doubles, row order) */
 int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host);

@@ -1372,6 +1372,7 @@ _sig("spmv_mgpu_generate_part", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
      C.c_int64, C.c_uint64, C.c_int, C.c_int)
 _sig("spmv_mgpu_set_ragged_exchange", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_mgpu_partition", C.c_int, C.c_void_p, _ip, C.POINTER(C.c_int64))
+_sig("spmv_mgpu_build_panels", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
 _sig("spmv_mgpu_fill_x", C.c_int, C.c_void_p, C.c_uint64)
 _sig("spmv_mgpu_spmv", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _dp)
@@ -1454,6 +1455,13 @@ class MultiGpu:
 
     def fill_x(self, seed=7):
         _check(_lib.spmv_mgpu_fill_x(self.h, seed), "spmv_mgpu_fill_x")
+
+    def build_panels(self, sched=None, tile_rows=0, deterministic=False):
+        """the blocked copy on every shard (needed before running the blocked
+        kernel id without autotune())"""
+        o = _panel_opts(0, sched, tile_rows, deterministic=deterministic)
+        _check(_lib.spmv_mgpu_build_panels(self.h, C.byref(o)),
+               "spmv_mgpu_build_panels")
 
     def autotune(self):
         """-> kernel id measured fastest for the loaded shards"""

@@ -478,6 +478,24 @@ fail:
     return rc;
 }
 
+/* the 2-D blocked copy on every shard with the same options (NULL: the
+ * defaults): what a caller that names the blocked kernel id needs before
+ * spmv_mgpu_spmv / _run (spmv_mgpu_autotune builds it by itself) */
+int spmv_mgpu_build_panels(spmv_mgpu *g, const spmv_panel_opts *opts) {
+    MG_OK(g);
+    int rc = 0;
+    device_guard keep;
+    for (int r = 0; r < g->n && !rc; ++r) {
+        if (!g->hll[r] && !g->csr[r])
+            continue;
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        rc = g->is_hll ? spmv_hll_build_panels_opts(g->hll[r], opts)
+                       : spmv_csr_build_panels_opts(g->csr[r], opts);
+    }
+fail:
+    return rc;
+}
+
 static int launch_shard(spmv_mgpu *g, int r, int kernel);
 static int sync_all(spmv_mgpu *g);
 static int gather_y(spmv_mgpu *g);

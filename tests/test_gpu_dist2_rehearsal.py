@@ -146,8 +146,9 @@ def test_nnz_partition_as_the_main_line_and_a_failing_leg_costs_nothing():
     base = [sys.executable, os.path.join(S.ROOT, "bench.py"), "--gpus", "2",
             "--backend", "gloo", "--steps", "2", "--warmup", "1",
             "--no-cpu-baseline", "--no-extras", "--kkt-n", "24"]
-    r = subprocess.run(base + ["--rows-per-gpu", "320000", "--family", "kkt",
-                               "--nnz-row", "16", "--window", "4096",
+    # the hub family: one row of 131 072 entries in rank 0's half moves the cut
+    r = subprocess.run(base + ["--rows-per-gpu", "320000", "--family", "hub",
+                               "--nnz-row", "6", "--window", "4096",
                                "--format", "csr", "--partition", "nnz",
                                "--kernel", "2"],
                        capture_output=True, text=True, env=env, timeout=900)
@@ -158,6 +159,7 @@ def test_nnz_partition_as_the_main_line_and_a_failing_leg_costs_nothing():
     per = c["nnz_per_rank"]
     assert len(per) == 2 and max(per) / min(per) < 1.05, per
     assert c["row_starts"][0] == 0 and c["row_starts"][2] == 640000
+    assert c["row_starts"][1] != 320000 and c["row_starts"][1] % 32 == 0
     assert sum(per) == c["nnz_global"] and j["legs_failed"] == []
     assert j["native"]["nnz_per_rank"] == per
     # config 4 over two ranks, nnz-balanced
@@ -180,3 +182,30 @@ def test_nnz_partition_as_the_main_line_and_a_failing_leg_costs_nothing():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["value"] > 0 and j["native"] is None
     assert len(j["legs_failed"]) == 1 and "native_mgpu" in j["legs_failed"][0]
+
+
+def test_under_torchrun_rank0_starts_the_native_child_itself():
+    """The driver launches N > 1 as `python -m torch.distributed.run ...
+    bench.py --gpus N`: there is no parent of ours, so rank 0 -- after every
+    rank has freed its HBM and the process group is gone -- starts the
+    library's own multi-GPU path as a child and merges it into its line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", os.path.join(S.ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--rows-per-gpu", "320000", "--window", "65536", "--kkt-n", "24",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["legs_failed"] == [], j["legs_failed"]
+    nat = j["native"]
+    assert nat and nat["backend"].startswith("native REHEARSAL")
+    assert nat["kernel"] == j["config"]["kernel"] or nat["kernel"]
+    assert set(j["legs_s"]) >= {"exchange_alone", "exchange_alternatives",
+                                "partition_kkt", "native_mgpu"}
+    assert j["config"]["partition_kkt"]["speedup_nnz_over_even"] > 0
