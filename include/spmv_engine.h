@@ -360,6 +360,14 @@ void spmv_hll_release_checked(spmv_hll_dev *H, uint64_t generation);
 
 /* Library self-description: "spmv_scpa_amd <version> gfx950". */
 const char *spmv_version(void);
+/* TEST HOOKS: leave in every last-arriver counter of the handle (long rows,
+ * wide hack blocks, the long rows beside a blocked copy) what a launch that
+ * never completed would have left.  Later launches must give the right y all
+ * the same: the counters carry the launch's number and an arrival that finds
+ * another number starts from zero.  Returns the counters touched. */
+int spmv_csr_debug_stale_arrivals(spmv_csr_dev *A);
+int spmv_hll_debug_stale_arrivals(spmv_hll_dev *H);
+
 /* HIP_VERSION (major * 10^7 + minor * 10^5 + patch) of the headers the library
  * was built with / of the runtime the process has bound it to (-EIO when the
  * runtime does not answer).  Majors must agree. */

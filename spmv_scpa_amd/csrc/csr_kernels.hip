@@ -321,7 +321,8 @@ __global__ void __launch_bounds__(STREAM_THREADS)
                  const unsigned char *__restrict__ mode,
                  const int *__restrict__ irp, const int *__restrict__ ja,
                  const double *__restrict__ as, const double *__restrict__ x,
-                 double *__restrict__ y, double *seg_partial, int *seg_count) {
+                 double *__restrict__ y, double *seg_partial,
+                 unsigned long long *seg_count, unsigned epoch) {
     __shared__ double s_val[STREAM_LDS]; /* AS (transposed) or products */
     __shared__ int s_ja[STREAM_LDS];
     __shared__ double part[STREAM_THREADS / WAVE];
@@ -359,10 +360,12 @@ __global__ void __launch_bounds__(STREAM_THREADS)
         /* The row's segments are consecutive ranges rb0 .. rb0 + nseg - 1.
          * Each leaves its partial sum; the LAST to arrive (counter at the
          * row's first range) adds them up in a fixed order -- the same
-         * whatever the arrival order, so the result is deterministic -- writes
-         * y and re-arms the counter for the next launch.  Agent-scope
-         * atomics: the segments run on different XCDs, whose L2s are not
-         * coherent for plain loads and stores. */
+         * whatever the arrival order, so the result is deterministic -- and
+         * writes y.  The counter carries the launch's epoch (epoch_arrive,
+         * hip_common.h): nothing is re-armed, and arrivals a launch that
+         * never completed left behind do not count.  Agent-scope atomics:
+         * the segments run on different XCDs, whose L2s are not coherent for
+         * plain loads and stores. */
         __shared__ int s_last;
         if (tid == 0) {
             double t = 0.0;
@@ -378,9 +381,8 @@ __global__ void __launch_bounds__(STREAM_THREADS)
                 const int rb0 = rb - (beg - b0) / STREAM_SEG;
                 __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-                const int seen = __hip_atomic_fetch_add(
-                    seg_count + rb0, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = seen == nseg - 1 ? nseg : 0;
+                const unsigned seen = epoch_arrive(seg_count + rb0, epoch);
+                s_last = seen == (unsigned)nseg ? nseg : 0;
             }
         }
         __syncthreads();
@@ -388,11 +390,8 @@ __global__ void __launch_bounds__(STREAM_THREADS)
             const int n = s_last;
             const int first = rb - (beg - irp[row_a]) / STREAM_SEG;
             const double sum = wave_ordered_sum(seg_partial + first, n, lane);
-            if (lane == 0) {
+            if (lane == 0)
                 y[row_a] = sum;
-                __hip_atomic_store(seg_count + first, 0, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
         return;
     }
@@ -524,7 +523,8 @@ __global__ void __launch_bounds__(STREAM_THREADS)
                    const int *__restrict__ irp,
                    const int *__restrict__ ja, const double *__restrict__ as,
                    const double *__restrict__ x, double *__restrict__ y,
-                   double *seg_partial, int *seg_count) {
+                   double *seg_partial, unsigned long long *seg_count,
+                   unsigned epoch) {
     __shared__ double part[STREAM_THREADS / WAVE];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int rb = long_rb[blockIdx.x];
@@ -551,20 +551,16 @@ __global__ void __launch_bounds__(STREAM_THREADS)
             const int rb0 = rb - (beg - b0) / STREAM_SEG;
             __hip_atomic_store(seg_partial + rb, t, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            const int seen = __hip_atomic_fetch_add(
-                seg_count + rb0, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = seen == nseg - 1 ? nseg : 0;
+            const unsigned seen = epoch_arrive(seg_count + rb0, epoch);
+            s_last = seen == (unsigned)nseg ? nseg : 0;
         }
     }
     __syncthreads();
     if (s_last && tid < WAVE) {
         const int first = rb - (beg - irp[row]) / STREAM_SEG;
         const double sum = wave_ordered_sum(seg_partial + first, s_last, lane);
-        if (lane == 0) {
+        if (lane == 0)
             y[row] = sum;
-            __hip_atomic_store(seg_count + first, 0, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -663,6 +659,9 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
         remap |= 0x100;
     if (r0 == r1)
         return 0;
+    /* this launch's number for the last-arriver counters of the long rows */
+    const unsigned epoch =
+        A->seg_count ? next_launch_epoch(&A->launch_epoch) : 0u;
     const int threads = waves * WAVE;
     const int rows = r1 - r0;
     /* rows beyond STREAM_NNZ entries (they own a range of the stream table):
@@ -766,13 +765,13 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
                                    dim3(STREAM_THREADS), 0, s, A->n_rowblk, grp,
                                    (const int2 *)A->rowblk, A->rowblk_mode,
                                    A->irp, A->ja, A->as, x, y, A->seg_partial,
-                                   A->seg_count);
+                                   A->seg_count, epoch);
             else
                 hipLaunchKernelGGL(k_csr_stream<true>, dim3(grid),
                                    dim3(STREAM_THREADS), 0, s, A->n_rowblk, grp,
                                    (const int2 *)A->rowblk, A->rowblk_mode,
                                    A->irp, A->ja, A->as, x, y, A->seg_partial,
-                                   A->seg_count);
+                                   A->seg_count, epoch);
         }
         break;
     }
@@ -783,6 +782,7 @@ int csr_launch_kernel(const spmv_csr_dev *A, int kernel, int waves, int group,
         hipLaunchKernelGGL(k_csr_long_seg, dim3(A->n_long_rb),
                            dim3(STREAM_THREADS), 0, s, r0, r1, A->long_rb,
                            (const int2 *)A->rowblk, A->rowblk_mode, A->irp,
-                           A->ja, A->as, x, y, A->seg_partial, A->seg_count);
+                           A->ja, A->as, x, y, A->seg_partial, A->seg_count,
+                           epoch);
     return hip_errno(hipGetLastError());
 }

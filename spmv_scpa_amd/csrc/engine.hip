@@ -187,6 +187,37 @@ uint64_t spmv_handle_generation(const void *handle) {
     return it == live().handles.end() ? 0 : it->second;
 }
 
+/*
+ * TEST HOOK: overwrite every last-arriver counter of the handle (the long
+ * rows of the CSR kernels / the wide hack blocks of the HLL kernels / the long
+ * rows beside a blocked copy) with what an INCOMPLETE launch leaves behind:
+ * a foreign launch number and a count.  The next launches must not care
+ * (epoch_arrive, hip_common.h).  Returns the counters touched, < 0 on error.
+ */
+int spmv_csr_debug_stale_arrivals(spmv_csr_dev *A) {
+    HANDLE_OK(A);
+    int n = 0;
+    if (A->seg_count && A->n_rowblk > 0) {
+        HIP_RET(hipMemset(A->seg_count, 0x01,
+                          (size_t)A->n_rowblk * sizeof(unsigned long long)));
+        n += A->n_rowblk;
+    }
+    const int p = panels_debug_stale_arrivals(A->panels);
+    return p < 0 ? p : n + p;
+}
+
+int spmv_hll_debug_stale_arrivals(spmv_hll_dev *H) {
+    HANDLE_OK(H);
+    int n = 0;
+    if (H->wide_cnt && H->n_wide_seg > 0) {
+        HIP_RET(hipMemset(H->wide_cnt, 0x01,
+                          (size_t)H->n_wide_seg * sizeof(unsigned long long)));
+        n += H->n_wide_seg;
+    }
+    const int p = panels_debug_stale_arrivals(H->panels);
+    return p < 0 ? p : n + p;
+}
+
 /* 1..16; 0 (or less) returns to the size-based default above */
 void set_csr_waves_per_block(int waves) {
     g_csr_waves = waves < 1 ? 0 : (waves > 16 ? 16 : waves);
@@ -619,9 +650,10 @@ static int finish_csr_handle(spmv_csr_dev *d, const int *host_irp) {
     if (segs) { /* partial sums + arrival counters of the long rows' ranges */
         const size_t n = (size_t)d->n_rowblk + 1;
         HIP_TRY(hipMalloc((void **)&d->seg_partial, n * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&d->seg_count, n * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d->seg_count,
+                          n * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d->seg_partial, 0, n * sizeof(double)));
-        HIP_TRY(hipMemset(d->seg_count, 0, n * sizeof(int)));
+        HIP_TRY(hipMemset(d->seg_count, 0, n * sizeof(unsigned long long)));
     }
 fail:
     return rc;
@@ -1230,10 +1262,12 @@ static int hll_alloc_dev(int M, int N, int64_t NZ, int nb, int col_major,
                               hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc((void **)&d->wide_part,
                               seg.size() * HACK_SIZE * sizeof(double)));
-            HIP_TRY(hipMalloc((void **)&d->wide_cnt, seg.size() * sizeof(int)));
+            HIP_TRY(hipMalloc((void **)&d->wide_cnt,
+                              seg.size() * sizeof(unsigned long long)));
             HIP_TRY(hipMemset(d->wide_part, 0,
                               seg.size() * HACK_SIZE * sizeof(double)));
-            HIP_TRY(hipMemset(d->wide_cnt, 0, seg.size() * sizeof(int)));
+            HIP_TRY(hipMemset(d->wide_cnt, 0,
+                              seg.size() * sizeof(unsigned long long)));
         }
     }
     *out = d;

@@ -112,8 +112,11 @@ struct spmv_csr_dev {
     unsigned char *rowblk_mode; /* per range: 0 transposed, 1 cooperative,
                                    2 segment of a long row */
     double *seg_partial; /* [n_rowblk] partial sum of a segment's range */
-    int *seg_count;      /* [n_rowblk] arrivals, at a long row's first range;
-                            both NULL when no row is that long */
+    unsigned long long *seg_count; /* [n_rowblk] (launch epoch << 32 |
+                            arrivals), at a long row's first range
+                            (epoch_arrive below); both NULL when no row is
+                            that long */
+    unsigned launch_epoch; /* number of the last launch that counted arrivals */
     int *long_rb;        /* [n_long_rb] indices of the ranges that hold (a
                             segment of) ONE row of more than STREAM_NNZ
                             entries: kernels 0-3 leave such rows to a second
@@ -168,12 +171,53 @@ struct spmv_hll_dev {
     int4 *wide_seg;    /* [n_wide_seg] (block, segment width, segment, segments) */
     int n_wide_seg;
     double *wide_part; /* [n_wide_seg * 32] partial row sums */
-    int *wide_cnt;     /* [n_wide_seg] arrivals, at a block's first segment */
+    unsigned long long *wide_cnt; /* [n_wide_seg] (launch epoch << 32 |
+                          arrivals), at a block's first segment */
+    unsigned launch_epoch;
     double tune_ms[8];   /* last spmv_hll_autotune: best median per kernel id */
     char *tune_log;
 };
 
+/* The next launch number of a handle, never 0 (a zeroed counter belongs to
+ * no launch).  The handle is `const` to the launch path but this one field
+ * moves; launches of ONE handle are stream-ordered by contract, the atomic
+ * only keeps two host threads that break it from tearing the number. */
+static inline unsigned next_launch_epoch(const unsigned *field) {
+    unsigned *f = const_cast<unsigned *>(field);
+    unsigned e = __atomic_add_fetch(f, 1u, __ATOMIC_RELAXED);
+    if (e == 0)
+        e = __atomic_add_fetch(f, 1u, __ATOMIC_RELAXED);
+    return e;
+}
+
 #if defined(__HIPCC__)
+/*
+ * Arrival at a last-arriver counter.  The counter holds (launch epoch << 32 |
+ * arrivals of that launch): an arrival that finds ANOTHER epoch starts the
+ * count from zero, so whatever an earlier launch left behind -- a launch that
+ * did not complete (a fault, a process killed between the main kernel and its
+ * side launch) used to leave a count that made every later launch of the
+ * handle reduce too early, a wrong y[row] with no error -- is
+ * simply not counted, and nobody has to re-arm anything.  Returns this
+ * arrival's number, 1 .. n; the caller that gets n is the last.  Agent scope:
+ * the arrivals come from different XCDs.
+ */
+__device__ __forceinline__ unsigned epoch_arrive(unsigned long long *cnt,
+                                                 unsigned epoch) {
+    unsigned long long old =
+        __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const unsigned long long base =
+            (unsigned)(old >> 32) == epoch ? old
+                                           : (unsigned long long)epoch << 32;
+        const unsigned long long nw = base + 1;
+        if (__hip_atomic_compare_exchange_strong(cnt, &old, nw, __ATOMIC_ACQ_REL,
+                                                 __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            return (unsigned)nw;
+    }
+}
+
 /* part[first * stride], part[(first + step) * stride], ... (indices below n)
  * added up in THAT order, U loads in flight at a time.  The partial sums were
  * written by other workgroups, on other XCDs: agent-scope atomic loads, each a
@@ -311,6 +355,7 @@ int panels_tile_rows(const spmv_panels *P);
 int panels_is_chain(const spmv_panels *P);
 void panels_set_chain(spmv_panels *P, int chain);
 void panels_set_waves(spmv_panels *P, int waves);
+int panels_debug_stale_arrivals(spmv_panels *P);
 void panels_set_order(spmv_panels *P, int order);
 int panels_waves(const spmv_panels *P);
 int panels_launch(const spmv_panels *P, int M, int waves, int variant,

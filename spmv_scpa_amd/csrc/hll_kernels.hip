@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256)
                const int4 *__restrict__ seg, const int64_t *__restrict__ off,
                const int *__restrict__ ja, const double *__restrict__ as,
                const double *__restrict__ x, double *__restrict__ y,
-               double *part, int *cnt) {
+               double *part, unsigned long long *cnt, unsigned epoch) {
     __shared__ double red[8][HACK];
     __shared__ int s_seen;
     const int g = blockIdx.x, tid = threadIdx.x;
@@ -438,11 +438,10 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     const int g0 = g - kseg;
-    if (tid == 0)
-        s_seen = __hip_atomic_fetch_add(cnt + g0, 1, __ATOMIC_ACQ_REL,
-                                        __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) /* epoch_arrive (hip_common.h): 1 .. nseg, nothing to re-arm */
+        s_seen = (int)epoch_arrive(cnt + g0, epoch);
     __syncthreads();
-    if (s_seen != nseg - 1)
+    if (s_seen != nseg)
         return;
     /* the block's last segment: 8 lanes per row add every 8th segment's
      * partial, then the eight are added in lane order -- a fixed order */
@@ -461,8 +460,6 @@ __global__ void __launch_bounds__(256)
             sum += red[c][tid];
         y[(int64_t)b * HACK + tid] = sum;
     }
-    if (tid == 0)
-        __hip_atomic_store(cnt + g0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* ------------------------------------------------------------------ */
@@ -596,6 +593,7 @@ int hll_launch_kernel(const spmv_hll_dev *H, int kernel, int waves,
     if (wide > 0)
         hipLaunchKernelGGL(k_hll_wide, dim3(H->n_wide_seg), dim3(256), 0, s,
                            H->M, b0, b1, H->col_major, H->wide_seg, H->off,
-                           H->ja, H->as, x, y, H->wide_part, H->wide_cnt);
+                           H->ja, H->as, x, y, H->wide_part, H->wide_cnt,
+                           next_launch_epoch(&H->launch_epoch));
     return hip_errno(hipGetLastError());
 }

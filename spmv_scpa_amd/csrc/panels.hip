@@ -138,7 +138,9 @@ struct spmv_panels {
     int2 *long_seg;   /* DEVICE [nlong_seg] (index into long_row, first entry) */
     int *long_seg0;   /* DEVICE [nlong] first segment of each row */
     double *long_part; /* DEVICE [nlong_seg] partial sums */
-    int *long_cnt;    /* DEVICE [nlong] arrivals */
+    unsigned long long *long_cnt; /* DEVICE [nlong] (launch epoch << 32 |
+                         arrivals): epoch_arrive, hip_common.h */
+    unsigned launch_epoch;
 };
 /* threshold: the second launch costs ~8 us; a row inside the copy costs its
  * tile ~1.3 ns per entry of serialised accumulation -- power-law 1M x 3 with
@@ -716,7 +718,8 @@ __global__ void __launch_bounds__(256)
                 const int *__restrict__ long_ptr,
                 const int *__restrict__ seg0, const int *__restrict__ lja,
                 const double *__restrict__ las, const double *__restrict__ x,
-                double *__restrict__ y, double *part, int *cnt) {
+                double *__restrict__ y, double *part, unsigned long long *cnt,
+                unsigned epoch) {
     __shared__ double wsum[4];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int h = seg[g].x, beg = seg[g].y;
@@ -736,19 +739,14 @@ __global__ void __launch_bounds__(256)
         const int n =
             (row_end - long_ptr[h] + PANELS_LONG_SEG - 1) / PANELS_LONG_SEG;
         __hip_atomic_store(part + g, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int seen = __hip_atomic_fetch_add(cnt + h, 1, __ATOMIC_ACQ_REL,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-        s_last = seen == n - 1 ? n : 0;
+        s_last = epoch_arrive(cnt + h, epoch) == (unsigned)n ? n : 0;
     }
     __syncthreads();
     if (s_last && tid < WAVE) { /* one wavefront adds the row's partial sums,
                                    in a fixed order (hip_common.h) */
         const double sum = wave_ordered_sum(part + g0, s_last, tid);
-        if (tid == 0) {
+        if (tid == 0)
             y[long_row[h]] = sum;
-            __hip_atomic_store(cnt + h, 0, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -812,9 +810,11 @@ static int long_rows_extract(spmv_panels *P, int M, int nb,
     HIP_TRY(hipMalloc((void **)&P->long_ja, (size_t)P->long_nnz * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&P->long_as, (size_t)P->long_nnz * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&P->long_part, h_seg.size() * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&P->long_cnt, h_row.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&P->long_cnt,
+                      h_row.size() * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(P->long_part, 0, h_seg.size() * sizeof(double)));
-    HIP_TRY(hipMemset(P->long_cnt, 0, h_row.size() * sizeof(int)));
+    HIP_TRY(hipMemset(P->long_cnt, 0,
+                      h_row.size() * sizeof(unsigned long long)));
     HIP_TRY(hipMemcpy(P->long_row, h_row.data(), h_row.size() * sizeof(int),
                       hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(P->long_ptr, h_ptr.data(), h_ptr.size() * sizeof(int),
@@ -1899,7 +1899,7 @@ int panels_launch(const spmv_panels *P, int M, int waves, int variant,
     hipLaunchKernelGGL(k_long_rows, dim3(P->nlong_seg), dim3(256), 0, s,
                        P->long_seg, P->nlong_seg, P->long_row, P->long_ptr,
                        P->long_seg0, P->long_ja, P->long_as, x, y, P->long_part,
-                       P->long_cnt);
+                       P->long_cnt, next_launch_epoch(&P->launch_epoch));
     return hip_errno(hipGetLastError());
 }
 
@@ -2229,6 +2229,16 @@ void panels_set_waves(spmv_panels *P, int waves) {
         P->waves_hint = waves > 0 ? waves : 0;
 }
 int panels_tile_rows(const spmv_panels *P) { return P ? P->tile_rows : 0; }
+
+/* test hook (spmv_*_debug_stale_arrivals): what a launch that never
+ * completed leaves in the long rows' arrival counters */
+int panels_debug_stale_arrivals(spmv_panels *P) {
+    if (!P || !P->nlong)
+        return 0;
+    HIP_RET(hipMemset(P->long_cnt, 0x01,
+                      (size_t)P->nlong * sizeof(unsigned long long)));
+    return P->nlong;
+}
 
 /* entries the copy stands for: in the buckets + in the long rows beside it */
 int64_t panels_nnz(const spmv_panels *P) {

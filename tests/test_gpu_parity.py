@@ -6,6 +6,8 @@ CSR path.  Written out below as REL_TOL; the kernels are additionally held to
 TIGHT = 1e-12 of the row scale sum_j |a_ij x_j| (summation order differs from
 the serial loop, nothing else may).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -1100,6 +1102,17 @@ def test_arrival_counter_kernels_soak():
             for rep in range(n_rep):
                 if rep % 50 == 0:  # poison now and then: y must be rewritten
                     S._lib.spmv_dev_memset(d_y.ptr, 0xFF, M * 8, None)
+                if rep % 70 == 35:
+                    # what a launch that never completed leaves behind in the
+                    # arrival counters (a foreign launch number + a count):
+                    # the counters carry the launch's own number, so the next
+                    # launch must not care (it used to reduce
+                    # early, a wrong y[row] with no error, for ever after)
+                    S.stream_sync()
+                    fn = (S._lib.spmv_hll_debug_stale_arrivals
+                          if m is dH else S._lib.spmv_csr_debug_stale_arrivals)
+                    fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
+                    assert fn(m.h) > 0, tag
                 m.launch(k, d_x.ptr, d_y.ptr)
                 if rep % 10 and rep != n_rep - 1:
                     continue  # back-to-back launches in between
