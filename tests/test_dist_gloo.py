@@ -84,6 +84,29 @@ def test_sharded_spmv_gloo(world, mode, chunks):
     run_world(world, mode, chunks, rows=640)
 
 
+@pytest.mark.parametrize("mode", ["ragged_p2p", "ragged_bcast",
+                                  "ragged_padded"])
+def test_ragged_exchange_with_empty_ranges(mode):
+    """96 rows = 3 hack blocks over 6 ranks: three ranks own nothing, compute
+    nothing and still take part in the exchange (a matrix smaller
+    than the node)"""
+    port = free_port()
+    world = 6
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        # the worker builds M = rows_per_rank * world rows: 16 * 6 = 96 = 3 blocks
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_dist_worker.py"), mode, "2",
+             "16"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+            text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0 and "rank %d ok" % r in out, out
+
+
 def test_nnz_partition_matches_the_library_and_balances():
     """dist.nnz_row_partition == partition_rows_nnz_aligned (csr.h) on skewed
     row-length profiles; aligned, ascending, no empty range, balanced"""
