@@ -7,7 +7,6 @@ import argparse
 import json
 import os
 import subprocess
-import sys
 import tempfile
 import time
 

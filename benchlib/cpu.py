@@ -4,7 +4,6 @@ import json
 import os
 import subprocess
 import sys
-import tempfile
 import time
 
 from .common import (MATRIX_SEED, REF_LADDER, ROOT, X_SEED, _ENV0,

@@ -3,12 +3,9 @@
 import json
 import os
 import subprocess
-import sys
-import tempfile
 import time
 
 from .common import *  # noqa: F401,F403
-from .common import _ENV0  # noqa: F401
 from .cpu import cpu_baseline
 
 
