@@ -82,6 +82,10 @@ int64_t hll_num_slots(const sparse_hll *H);
 
 /* 1 if block storage is one contiguous slab pair in block order. */
 int hll_is_contiguous(const sparse_hll *H);
+/* copy the blocks of a block-by-block matrix into two slabs (block b at
+ * off[b], off[nb] = hll_num_slots(H)), in parallel */
+void hll_pack_slabs(const sparse_hll *H, const int64_t *off, int *ja,
+                    double *as);
 
 /* ---- CPU benchmarks (reference hll.c:214-224); row-major input ---- */
 int bench_hll_serial(const sparse_hll *H, const double *x, bench *out);

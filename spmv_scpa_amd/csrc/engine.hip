@@ -1305,15 +1305,36 @@ int spmv_hll_upload(const sparse_hll *H, int is_col_major,
             HIP_TRY(hipMemcpy(d->as, H->blocks[0].AS,
                               (size_t)d->slots * sizeof(double),
                               hipMemcpyHostToDevice));
-        } else { /* blocks allocated one by one: pack while copying */
-            for (int b = 0; b < nb; ++b) {
-                size_t n = (size_t)(off[(size_t)b + 1] - off[b]);
-                if (!n)
-                    continue;
-                HIP_TRY(hipMemcpy(d->ja + off[b], H->blocks[b].JA,
-                                  n * sizeof(int), hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(d->as + off[b], H->blocks[b].AS,
-                                  n * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            /* blocks allocated one by one (the reference's csr_to_hll): pack
+             * them into two host slabs in parallel, then two copies -- a copy
+             * pair per block is 625 000 hipMemcpy calls at config 3.  Without
+             * the host memory for the slabs: block by block after all. */
+            int *pj = (int *)malloc((size_t)d->slots * sizeof(int));
+            double *pa = (double *)malloc((size_t)d->slots * sizeof(double));
+            if (pj && pa) {
+                hll_pack_slabs(H, off.data(), pj, pa);
+                hipError_t e = hipMemcpy(d->ja, pj, (size_t)d->slots * sizeof(int),
+                                         hipMemcpyHostToDevice);
+                if (e == hipSuccess)
+                    e = hipMemcpy(d->as, pa, (size_t)d->slots * sizeof(double),
+                                  hipMemcpyHostToDevice);
+                free(pj);
+                free(pa);
+                HIP_TRY(e);
+            } else {
+                free(pj);
+                free(pa);
+                for (int b = 0; b < nb; ++b) {
+                    size_t n = (size_t)(off[(size_t)b + 1] - off[b]);
+                    if (!n)
+                        continue;
+                    HIP_TRY(hipMemcpy(d->ja + off[b], H->blocks[b].JA,
+                                      n * sizeof(int), hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(d->as + off[b], H->blocks[b].AS,
+                                      n * sizeof(double),
+                                      hipMemcpyHostToDevice));
+                }
             }
         }
         rc = hll_fix_pads_dev(d, 0);

@@ -1192,3 +1192,53 @@ def test_deterministic_blocked_mode_gives_the_same_bits_every_launch(
     A.release()
     d_x.free()
     d_y.free()
+
+
+def test_one_shot_upload_of_reference_style_hll_blocks():
+    """The reference's csr_to_hll allocates every hack block by itself
+    (hll.c:56-70), so what its driver hands to the seam is NOT slab-backed:
+    the upload packs such blocks into two host slabs in parallel and copies
+    twice (hll_pack_slabs) instead of twice per block.  Same y, bit for bit,
+    as from the slab-backed matrix of this repo's converter, for both
+    layouts, and a 31 250-block matrix uploads in tens of milliseconds."""
+    import time
+    M = N = 1_000_000
+    A = S.csr_generate(S.SYNTH_RAGGED, M, N, 16, 4096, 0, 42)
+    x = O.synth_x(7, 0, N)
+    for col_major, kernel in ((True, 1), (False, 0)):
+        H = S.csr_to_hll(A, col_major)
+        h = H.contents
+        nb = h.num_blocks
+        keep = []  # one allocation pair per block, like the reference
+        blocks = (S.EllpackBlock * nb)()
+        for b in range(nb):
+            src = h.blocks[b]
+            n = src.M * src.max_NZ
+            ja = np.ctypeslib.as_array(src.JA, (max(n, 1),))[:n].copy()
+            av = np.ctypeslib.as_array(src.AS, (max(n, 1),))[:n].copy()
+            keep.append((ja, av))
+            blocks[b].M, blocks[b].N = src.M, src.N
+            blocks[b].NZ, blocks[b].max_NZ = src.NZ, src.max_NZ
+            blocks[b].JA = ja.ctypes.data_as(C.POINTER(C.c_int))
+            blocks[b].AS = av.ctypes.data_as(C.POINTER(C.c_double))
+        R = S.SparseHLL()
+        R.name, R.M, R.N, R.NZ = h.name, h.M, h.N, h.NZ
+        R.hack_size, R.num_blocks = h.hack_size, nb
+        R.blocks = C.cast(blocks, C.POINTER(S.EllpackBlock))
+        Rp = C.pointer(R)
+        assert S._lib.hll_is_contiguous(Rp) == 0
+        y0, _ = S.hll_spmv_hip(H, x, kernel=kernel)
+        t0 = time.perf_counter()
+        S.hll_spmv_hip(H, x, kernel=kernel)
+        wall_slab = (time.perf_counter() - t0) * 1e3
+        S.hll_spmv_hip(Rp, x, kernel=kernel)  # warm
+        t0 = time.perf_counter()
+        y1, _ = S.hll_spmv_hip(Rp, x, kernel=kernel)
+        wall = (time.perf_counter() - t0) * 1e3
+        assert np.array_equal(y0, y1)
+        print("block-by-block HLL, %d blocks, col_major=%s: one-shot call "
+              "%.1f ms (slab-backed: %.1f ms)" % (nb, col_major, wall,
+                                                  wall_slab))
+        assert wall < 400.0, wall  # 62 500 hipMemcpy calls took ~ 1 s
+        S.hll_free(H)
+    S.csr_free(A)
