@@ -75,6 +75,9 @@ static inline double compute_gflops(double duration_ms, int nnz) {
 /* posix_memalign(ALIGNMENT); NULL on failure.  size 0 still yields a
  * unique pointer that free() accepts. */
 void *aligned_malloc(size_t size);
+/* team size of the library's own host loops: min(OpenMP's default, the
+ * cgroup CPU quota) -- see utils.c */
+int spmv_host_threads(void);
 
 /* 0 when ||expected - res||_2 <= 0.1 (the reference's -d check,
  * utils.c:39-60); -1 on length mismatch or a larger distance. */

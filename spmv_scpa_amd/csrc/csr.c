@@ -273,7 +273,7 @@ static int read_whole_file(const char *path, char **buf, size_t *len) {
 static int parse_entries_parallel(const char *text, size_t off, size_t len,
                                   int nz0, int pattern, int *ei, int *ej,
                                   double *ev, int *complete) {
-    int T = omp_get_max_threads();
+    int T = spmv_host_threads();
     if (T > 64)
         T = 64;
     if (T < 2 || nz0 < 100000)
@@ -451,7 +451,7 @@ sparse_csr *io_load_csr(const char *path) {
      * row is the sequential one, rows have one writer, no atomics -- and the
      * fresh pages of JA/AS are first touched by the thread that fills them. */
     {
-        int T = nz0 >= 100000 ? omp_get_max_threads() : 1;
+        int T = nz0 >= 100000 ? spmv_host_threads() : 1;
         if (T > 64)
             T = 64;
 #pragma omp parallel num_threads(T)
@@ -582,10 +582,10 @@ static int csr_arrays_valid(const sparse_csr *A) {
     if (A->IRP[0] != 0 || A->IRP[M] != NZ)
         return 0;
     int bad = 0;
-#pragma omp parallel for reduction(| : bad) schedule(static)
+#pragma omp parallel for reduction(| : bad) schedule(static) num_threads(spmv_host_threads())
     for (int i = 0; i < M; ++i)
         bad |= A->IRP[i + 1] < A->IRP[i];
-#pragma omp parallel for reduction(| : bad) schedule(static)
+#pragma omp parallel for reduction(| : bad) schedule(static) num_threads(spmv_host_threads())
     for (int k = 0; k < NZ; ++k)
         bad |= (unsigned)A->JA[k] >= (unsigned)N;
     return !bad;
@@ -637,7 +637,7 @@ static sparse_csr *csr_read_bin(const char *path, const struct stat *src) {
         const uint64_t total = nI + nJ + nV, piece = (uint64_t)32 << 20;
         const long long pieces = (long long)((total + piece - 1) / piece);
         int bad = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad) num_threads(spmv_host_threads())
         for (long long k = 0; k < pieces; ++k) {
             uint64_t a = (uint64_t)k * piece;
             const uint64_t z = a + piece < total ? a + piece : total;
@@ -722,7 +722,7 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
 /* a team is opened only for work that pays for it: bench.py's result
          * check regenerates single rows, and a full-width team per 1-row call
          * burned a 16-CPU cgroup quota on a 256-thread host */
-#pragma omp parallel for schedule(static) reduction(+ : nz) if (M > 4096)
+#pragma omp parallel for schedule(static) reduction(+ : nz) if (M > 4096) num_threads(spmv_host_threads())
         for (int i = 0; i < M; ++i)
             nz += synth_row_len(&s, row0 + i);
     }
@@ -737,7 +737,7 @@ sparse_csr *csr_generate(int kind, int M, int N, int K, int64_t W,
         return A;
     for (int i = 0; i < M; ++i)
         A->IRP[i + 1] = A->IRP[i] + synth_row_len(&s, row0 + i);
-#pragma omp parallel for schedule(dynamic, 4096) if (M > 4096)
+#pragma omp parallel for schedule(dynamic, 4096) if (M > 4096) num_threads(spmv_host_threads())
     for (int i = 0; i < M; ++i)
         synth_fill_row(&s, row0 + i, A->IRP[i + 1] - A->IRP[i],
                        A->JA + A->IRP[i], A->AS + A->IRP[i]);
@@ -934,7 +934,7 @@ int *partition_synth_rows_nnz(int kind, int M, int N, int K, int64_t W,
         return ERR_PTR(-ENOMEM);
     }
     const synth_spec s = {kind, M, N, K, W, 0, seed};
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(spmv_host_threads())
     for (int b = 0; b < nb; ++b) {
         const long long r0 = (long long)b * align;
         const long long r1 = r0 + align < M ? r0 + align : M;

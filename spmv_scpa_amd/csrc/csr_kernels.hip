@@ -362,8 +362,8 @@ __global__ void __launch_bounds__(STREAM_THREADS)
          * row's first range) adds them up in a fixed order -- the same
          * whatever the arrival order, so the result is deterministic -- and
          * writes y.  The counter carries the launch's epoch (epoch_arrive,
-         * hip_common.h): nothing is re-armed, and arrivals a launch that
-         * never completed left behind do not count.  Agent-scope atomics:
+         * hip_common.h): arrivals a launch that never completed left behind
+         * do not count; the last arriver leaves (epoch, 0) for a replay.  Agent-scope atomics:
          * the segments run on different XCDs, whose L2s are not coherent for
          * plain loads and stores. */
         __shared__ int s_last;
@@ -390,8 +390,10 @@ __global__ void __launch_bounds__(STREAM_THREADS)
             const int n = s_last;
             const int first = rb - (beg - irp[row_a]) / STREAM_SEG;
             const double sum = wave_ordered_sum(seg_partial + first, n, lane);
-            if (lane == 0)
+            if (lane == 0) {
                 y[row_a] = sum;
+                epoch_rearm(seg_count + first, epoch);
+            }
         }
         return;
     }
@@ -559,8 +561,10 @@ __global__ void __launch_bounds__(STREAM_THREADS)
     if (s_last && tid < WAVE) {
         const int first = rb - (beg - irp[row]) / STREAM_SEG;
         const double sum = wave_ordered_sum(seg_partial + first, s_last, lane);
-        if (lane == 0)
+        if (lane == 0) {
             y[row] = sum;
+            epoch_rearm(seg_count + first, epoch);
+        }
     }
 }
 

@@ -198,9 +198,10 @@ static inline unsigned next_launch_epoch(const unsigned *field) {
  * did not complete (a fault, a process killed between the main kernel and its
  * side launch) used to leave a count that made every later launch of the
  * handle reduce too early, a wrong y[row] with no error -- is
- * simply not counted, and nobody has to re-arm anything.  Returns this
- * arrival's number, 1 .. n; the caller that gets n is the last.  Agent scope:
- * the arrivals come from different XCDs.
+ * simply not counted.  Returns this arrival's number, 1 .. n; the caller
+ * that gets n is the last and calls epoch_rearm(): a launch REPLAYED with the
+ * same number (a captured hipGraph freezes the kernel arguments) then counts
+ * from zero again.  Agent scope: the arrivals come from different XCDs.
  */
 __device__ __forceinline__ unsigned epoch_arrive(unsigned long long *cnt,
                                                  unsigned epoch) {
@@ -216,6 +217,13 @@ __device__ __forceinline__ unsigned epoch_arrive(unsigned long long *cnt,
                                                  __HIP_MEMORY_SCOPE_AGENT))
             return (unsigned)nw;
     }
+}
+
+/* the last arriver leaves (epoch, 0 arrivals): see epoch_arrive */
+__device__ __forceinline__ void epoch_rearm(unsigned long long *cnt,
+                                            unsigned epoch) {
+    __hip_atomic_store(cnt, (unsigned long long)epoch << 32, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* part[first * stride], part[(first + step) * stride], ... (indices below n)

@@ -40,7 +40,7 @@ sparse_hll *csr_to_hll(const sparse_csr *A, bool is_col_major) {
         goto nomem;
 
     /* pass 1 (parallel): per-block longest row and entry count */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(spmv_host_threads())
     for (int b = 0; b < nb; ++b) {
         int r0 = b * HACK_SIZE, rows = block_rows(M, b);
         int longest = 0;
@@ -64,7 +64,7 @@ sparse_hll *csr_to_hll(const sparse_csr *A, bool is_col_major) {
 
     /* pass 2 (parallel): pad with (-1, 0.0), then place the entries
      * (reference hll.c:73-90) */
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(spmv_host_threads())
     for (int b = 0; b < nb; ++b) {
         ellpack_block *blk = &H->blocks[b];
         int r0 = b * HACK_SIZE, rows = blk->M, width = blk->max_NZ;
@@ -161,7 +161,13 @@ int hll_is_contiguous(const sparse_hll *H) {
  */
 void hll_pack_slabs(const sparse_hll *H, const int64_t *off, int *ja,
                     double *as) {
-#pragma omp parallel for schedule(dynamic, 512)
+    /* a copy loop: a handful of threads saturate the memory system, and a
+     * team sized from the affinity mask (256 on the GPU box) under a 16-CPU
+     * cgroup quota spends its time being throttled */
+    int team = spmv_host_threads();
+    if (team > 8)
+        team = 8;
+#pragma omp parallel for schedule(dynamic, 512) num_threads(team)
     for (int b = 0; b < H->num_blocks; ++b) {
         const size_t n = (size_t)(off[b + 1] - off[b]);
         if (!n)

@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     const int g0 = g - kseg;
-    if (tid == 0) /* epoch_arrive (hip_common.h): 1 .. nseg, nothing to re-arm */
+    if (tid == 0) /* epoch_arrive (hip_common.h): 1 .. nseg */
         s_seen = (int)epoch_arrive(cnt + g0, epoch);
     __syncthreads();
     if (s_seen != nseg)
@@ -460,6 +460,8 @@ __global__ void __launch_bounds__(256)
             sum += red[c][tid];
         y[(int64_t)b * HACK + tid] = sum;
     }
+    if (tid == 0)
+        epoch_rearm(cnt + g0, epoch);
 }
 
 /* ------------------------------------------------------------------ */

@@ -745,8 +745,10 @@ __global__ void __launch_bounds__(256)
     if (s_last && tid < WAVE) { /* one wavefront adds the row's partial sums,
                                    in a fixed order (hip_common.h) */
         const double sum = wave_ordered_sum(part + g0, s_last, tid);
-        if (tid == 0)
+        if (tid == 0) {
             y[long_row[h]] = sum;
+            epoch_rearm(cnt + h, epoch);
+        }
     }
 }
 

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
 #include "utils.h"
 
 void *aligned_malloc(size_t size) {
@@ -69,6 +70,40 @@ void print_result_vector(const vec res) {
     for (size_t i = 0; i < res.len; ++i)
         printf("  y[%zu] = %.4f\n", i, res.data[i]);
     printf("\n");
+}
+
+/*
+ * Team size of the library's OWN host loops (loader, generators, converters,
+ * packing): libgomp sizes a team from the affinity mask -- 256 hardware
+ * threads on the MI355X boxes -- not from the cgroup CPU quota (16 CPUs
+ * there), and a 256-thread team on 16 CPUs of quota spends its time being
+ * throttled (a 240 MB packing loop: 183 ms with the default team, 60 ms with
+ * 8 threads).  min(omp_get_max_threads(), cgroup v2 quota), cached.  The CPU
+ * BENCHMARKS are not affected: they run the thread counts they are asked for.
+ */
+int spmv_host_threads(void) {
+    static int cached;
+    int t = __atomic_load_n(&cached, __ATOMIC_RELAXED);
+    if (t > 0)
+        return t;
+    t = omp_get_max_threads();
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") &&
+            period > 0) {
+            const long quota = atol(q);
+            const int cpus = (int)((quota + period - 1) / period);
+            if (cpus >= 1 && cpus < t)
+                t = cpus;
+        }
+        fclose(f);
+    }
+    if (t < 1)
+        t = 1;
+    __atomic_store_n(&cached, t, __ATOMIC_RELAXED);
+    return t;
 }
 
 void omp_warmup(int num_threads) {

@@ -44,7 +44,7 @@ void vec_fill_synth(vec *v, uint64_t seed, int64_t first) {
     if (!v || !v->data)
         return;
     int64_t n = (int64_t)v->len;
-#pragma omp parallel for schedule(static) if (n > 65536)
+#pragma omp parallel for schedule(static) if (n > 65536) num_threads(spmv_host_threads())
     for (int64_t i = 0; i < n; ++i)
         v->data[i] = synth_x(seed, first + i);
 }
