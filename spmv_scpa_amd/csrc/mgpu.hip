@@ -12,6 +12,7 @@
  * this is the path of `spmv_scpa_amd -g N`.
  */
 #include <mutex>
+#include <thread>
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -439,17 +440,36 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
     if (!g->hll[0] && !g->csr[0])
         return -EINVAL; /* nothing loaded */
-    for (int r = 0; r < g->n && !rc; ++r) {
-        if (!g->hll[r] && !g->csr[r])
-            continue; /* an empty range */
-        HIP_TRY(hipSetDevice(g->dev[r]));
-        double *yfrag = g->y[r] + (size_t)g->start[r];
-        int k = -1;
-        rc = g->is_hll
-                 ? spmv_hll_autotune(g->hll[r], g->x[r], yfrag, 1, &k, NULL)
-                 : spmv_csr_autotune(g->csr[r], g->x[r], yfrag, 1, &k, NULL);
-        if (r == 0)
-            pick = k;
+    {
+        /* one host thread per device: the selectors run side by side (a
+         * handle per device, a device per thread -- the concurrency the engine
+         * supports, tests/test_gpu_threads.py); one after the other they were
+         * ngpus x the 0.5..3 s of a selector run */
+        std::vector<int> rcs((size_t)g->n, 0), picks((size_t)g->n, -1);
+        std::vector<std::thread> th;
+        for (int r = 0; r < g->n; ++r) {
+            if (!g->hll[r] && !g->csr[r])
+                continue; /* an empty range */
+            th.emplace_back([g, r, &rcs, &picks]() {
+                if (hipSetDevice(g->dev[r]) != hipSuccess) {
+                    rcs[(size_t)r] = -ENODEV;
+                    return;
+                }
+                double *yfrag = g->y[r] + (size_t)g->start[r];
+                int k = -1;
+                rcs[(size_t)r] =
+                    g->is_hll ? spmv_hll_autotune(g->hll[r], g->x[r], yfrag, 1,
+                                                  &k, NULL)
+                              : spmv_csr_autotune(g->csr[r], g->x[r], yfrag, 1,
+                                                  &k, NULL);
+                picks[(size_t)r] = k;
+            });
+        }
+        for (std::thread &t : th)
+            t.join();
+        for (int r = 0; r < g->n && !rc; ++r)
+            rc = rcs[(size_t)r];
+        pick = picks[0];
     }
     /* device 0's blocked copy is the model: every other shard is rebuilt
      * with its schedule, tile height and build options unless it already
