@@ -142,6 +142,9 @@ def test_seam_cache_keeps_the_last_upload_and_notices_a_change():
     x = O.synth_x(7, 0, N)
     base = S._lib.spmv_live_handles()
     y0, k0 = S.csr_spmv_hip(A, x, kernel=4)         # uncached
+    t0 = time.perf_counter()
+    S.csr_spmv_hip(A, x, kernel=4)                  # uncached, allocations warm
+    wall_uncached = (time.perf_counter() - t0) * 1e3
     assert S._lib.spmv_live_handles() == base
     S.seam_cache(2)
     try:
@@ -196,5 +199,7 @@ def test_seam_cache_keeps_the_last_upload_and_notices_a_change():
     # a resident call = x is there (level 2), memset y, one event-timed launch,
     # 8 MB of y back over PCIe: well under a millisecond of host time beyond
     # the download; uncached it was 6.3 ms (DESIGN, one-shot seam)
-    print("seam cache: %.3f ms per call, kernel %.4f ms" % (wall, kms))
-    assert wall < 2.5, wall
+    print("seam cache: %.3f ms per call (uncached %.3f), kernel %.4f ms"
+          % (wall, wall_uncached, kms))
+    # 0.7 vs 6.4 ms on a quiet box; on a busy host both stretch
+    assert wall < 2.5 or wall < 0.6 * wall_uncached, (wall, wall_uncached)
