@@ -2085,22 +2085,32 @@ static double csr_one_shot(const sparse_csr *A, const double *x, double *y,
     {
         std::unique_lock<std::mutex> g(g_seam.mu);
         if (g_seam.level > 0) {
+            const double t0s = panels_ops::now_s();
             uint64_t fp = fp_mix(fp_mix(fp_mix(0x637372, (uint64_t)A->M),
                                         (uint64_t)A->N), (uint64_t)A->NZ);
             fp = fp_array(fp, A->IRP, (size_t)A->M + 1, sizeof(int));
             fp = fp_array(fp, A->JA, (size_t)A->NZ, sizeof(int));
             fp = fp_array(fp, A->AS, (size_t)A->NZ, sizeof(double));
             seam_slot *c = NULL;
+            const double t1 = panels_ops::now_s();
             rc = seam_acquire(0, A, fp, A->M, A->N, x,
                               [&](seam_slot *s) {
                                   return spmv_csr_upload(A, &s->csr);
                               },
                               &c);
+            const double t2 = panels_ops::now_s();
             if (!rc)
                 rc = spmv_csr_time(c->csr, kernel, opts, c->d_x, c->d_y, 0, 1, 0,
                                    &ms, NULL);
+            const double t3 = panels_ops::now_s();
             if (!rc && A->M > 0)
                 rc = spmv_copy_d2h(y, c->d_y, (size_t)A->M * sizeof(double));
+            if (live().debug) /* where a cached call spends its host time */
+                fprintf(stderr,
+                        "spmv seam cache (csr): fingerprint %.3f ms, acquire "
+                        "%.3f, launch + sync %.3f, y download %.3f\n",
+                        (t1 - t0s) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3,
+                        (panels_ops::now_s() - t3) * 1e3);
             return rc ? (double)rc : ms;
         }
     }
