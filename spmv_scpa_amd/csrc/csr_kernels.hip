@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(STREAM_THREADS)
          * whatever the arrival order, so the result is deterministic -- and
          * writes y.  The counter carries the launch's epoch (epoch_arrive,
          * hip_common.h): arrivals a launch that never completed left behind
-         * do not count; the last arriver leaves (epoch, 0) for a replay.  Agent-scope atomics:
+         * do not count; the last arriver leaves the word the next launch expects.  Agent-scope atomics:
          * the segments run on different XCDs, whose L2s are not coherent for
          * plain loads and stores. */
         __shared__ int s_last;

@@ -1242,3 +1242,30 @@ def test_one_shot_upload_of_reference_style_hll_blocks():
         assert wall < 400.0, wall  # 62 500 hipMemcpy calls took ~ 1 s
         S.hll_free(H)
     S.csr_free(A)
+
+
+def test_long_row_arrivals_stay_cheap():
+    """Perf guard (round 5 lost 4x here without a test noticing): the 128
+    segments of a hub row arrive at ONE counter; with a compare-and-swap loop
+    per arrival they serialised on it -- hub 1M 0.030 -> 0.116 ms for the
+    blocked path, 0.044 -> 0.116 for the stream kernel.  The arrival is one
+    fetch-and-add again (epoch_arrive, hip_common.h); generous bounds, event-
+    timed medians of 20 launches on an exclusive GPU."""
+    M = N = 1_000_000
+    dA = S.CsrDevice.generate(S.SYNTH_HUB, M, N, 6, 4096, 0, 42)
+    d_x, d_y = S.DevBuffer(N * 8), S.DevBuffer(M * 8)
+    S.dev_fill_synth(d_x.ptr, N, 7)
+    dA.build_panels(0, "chain", 4096)
+    flush = 1 << 30  # 103 MB of matrix: out of the Infinity Cache
+    blocked = float(np.median(dA.time(S.CSR_KERNEL_PANELS, d_x.ptr, d_y.ptr, 3,
+                                      20, flush)))
+    stream = float(np.median(dA.time(4, d_x.ptr, d_y.ptr, 3, 20, flush)))
+    subwave = float(np.median(dA.time(2, d_x.ptr, d_y.ptr, 3, 20, flush)))
+    print("hub 1M: blocked %.4f ms, stream %.4f, subwave + long seg %.4f"
+          % (blocked, stream, subwave))
+    assert blocked < 0.075, blocked   # 0.030 measured
+    assert stream < 0.095, stream     # 0.044
+    assert subwave < 0.16, subwave    # 0.078
+    dA.release()
+    d_x.free()
+    d_y.free()

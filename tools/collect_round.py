@@ -46,7 +46,8 @@ def main():
     j = json.load(open(os.path.join(ROOT, "profiles", rnd + "_bench_full.json")))
     r = j["roofline"]
     print("headline: %.1f GFLOP/s, %.3f ms per step, frac %.4f, traffic %.3f GB"
-          % (j["value"], j["ms_per_step"], r["frac"], r["traffic"] / 1e9))
+          % (j["value"], j["ms_per_step"], r["frac"],
+             (r["traffic"] or float("nan")) / 1e9))
     print("secondary:", r.get("secondary"))
     for k, v in j.get("extras", {}).items():
         print("  ", k, v)

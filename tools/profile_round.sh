@@ -14,6 +14,10 @@ part="${2:-all}"   # all | passes | rest  (two gpurun calls when one is too long
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$root"
 mkdir -p gpurun_out profiles
+# only what THIS call writes goes back (the snapshot also holds the round's
+# committed files: copying those would put stale records over fresh ones)
+touch gpurun_out/.round_start
+keep() { mkdir -p gpurun_out/profiles_${round}; find profiles -maxdepth 1 -name "${round}_*" -newer gpurun_out/.round_start -exec cp -f {} gpurun_out/profiles_${round}/ \; ; }
 step() { echo "== $*"; "$@" || { echo "FAILED: $*"; exit 1; }; }
 prof() {  # prof <tag> <bench args...>
     local tag="$1"; shift
@@ -35,7 +39,7 @@ prof powerlaw4M --family powerlaw --rows-per-gpu 4000000 --nnz-row 3
 prof hub1M --family hub --rows-per-gpu 1000000 --nnz-row 6 --window 4096
 fi
 if [ "$part" = "passes" ]; then
-    mkdir -p gpurun_out/profiles_${round} && cp -f profiles/${round}_* gpurun_out/profiles_${round}/
+    keep
     echo "== passes done"; exit 0
 fi
 # counter passes run the layout of an UN-profiled selector run (--blocked-pin)
@@ -79,6 +83,5 @@ python3 bench.py --strong --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-bas
 python3 bench.py --config 2 --steps 30 > "profiles/${round}_bench_config2.json" 2> /dev/null || exit 1
 python3 bench.py --config 4 --steps 20 > "profiles/${round}_bench_config4.json" 2> /dev/null || exit 1
 python3 bench.py --steps 20 --warmup 5 > "profiles/${round}_bench_full.json" 2> /dev/null || exit 1
-cp -f profiles/${round}_* gpurun_out/ 2>/dev/null
-mkdir -p gpurun_out/profiles_${round} && cp -f profiles/${round}_* gpurun_out/profiles_${round}/
+keep
 echo "== done"
