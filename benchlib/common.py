@@ -196,6 +196,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-native-leg", action="store_true",
                     help="N>1: skip `native` (the library's own multi-GPU "
                          "path in a child process after the ranks are done)")
+    ap.add_argument("--no-arrangement-choice", action="store_true",
+                    help="--native-mgpu: do not build and time the logical-"
+                         "shard arrangement next to the plain one")
     ap.add_argument("--native-rehearsal", action="store_true",
                     help="--native-mgpu on a REHEARSAL handle: --gpus N "
                          "logical devices on the visible card(s), copies "

@@ -58,6 +58,51 @@ def native_mgpu_bench(args, argv, omp_team):
         t_tune = time.time()
         kernel = g.autotune()
         t_tune = time.time() - t_tune
+    # ---- the exchange arrangement, chosen by measurement like the torch
+    # path's: (a) every device's kernel, then the exchange; (b) the rows of a
+    # device as LOGICAL SHARDS (4; a sweep pick: 2, on a grid that leaves
+    # --reserve-cus CUs to RCCL), shard c all-gathered on a second stream
+    # while shard c+1 computes (spmv_mgpu_set_logical_shards).  Both are
+    # built and timed (5 steps), the faster one runs the K timed steps.
+    arrangement = None
+    L_used = 1
+    if ((n > 1 or args.force_exchange) and not ragged and chunks == 1
+            and Mloc % (4 * 32) == 0 and not args.no_arrangement_choice):
+        try:
+            _, _, lay = g.shard_info(0)
+            sweep = lay.startswith("sweep")
+            L2, res = (2, args.reserve_cus) if sweep else (4, 0)
+            g.spmv(kernel, 1, 1)
+            t_a = g.run(kernel, 1, 5)[0] / 5
+            g2 = S.MultiGpu(n, rehearsal=args.native_rehearsal)
+            g2.set_logical_shards(L2, res)
+            g2.generate(kind, Mloc, K, W, MATRIX_SEED,
+                        as_hll=args.format == "hll")
+            g2.fill_x(X_SEED)
+            g2.set_exchange(1, args.force_exchange)
+            if args.kernel >= 0:
+                k2 = args.kernel
+                if labels[k2] == "tile_panels":
+                    g2.build_panels()
+            else:
+                k2 = g2.autotune()
+            g2.spmv(k2, 1, 1)
+            t_b = g2.run(k2, 1, 5)[0] / 5
+            arrangement = (
+                "exchange after the kernels %.3f ms/step vs %d logical shards "
+                "per device%s with the all-gather of shard c under the kernel "
+                "of c+1 %.3f ms/step" % (
+                    t_a, L2, " on %d fewer CUs" % res if res else "", t_b))
+            if t_b < t_a:
+                g.destroy()
+                g, kernel, L_used = g2, k2, L2
+                starts, nnz_per_rank, ragged = g.partition()
+                arrangement += " -> logical shards"
+            else:
+                g2.destroy()
+                arrangement += " -> exchange after the kernels"
+        except OSError as e:
+            arrangement = "logical-shard arrangement not built (%s)" % e
     kname = prefix + labels[kernel]
     t_setup = time.time() - t_setup
 
@@ -123,7 +168,8 @@ def native_mgpu_bench(args, argv, omp_team):
             "blocked_layout": layout or None,
             "kernel_source": kernel_source_ident(kname),
             "kernel_launches_per_step": 1,
-            "rows_per_gpu": Mloc, "logical_shards_per_gpu": 1,
+            "rows_per_gpu": Mloc, "logical_shards_per_gpu": L_used,
+            "exchange_arrangement": arrangement,
             "nnz_per_row": K, "nnz_global": nnz_global,
             "stored_slots_per_gpu": stored,
             "partition": ("nnz-balanced contiguous row ranges (32-aligned; "
@@ -135,8 +181,11 @@ def native_mgpu_bench(args, argv, omp_team):
             "row_starts": starts if ragged else None,
             "nnz_per_rank": nnz_per_rank if n > 1 else None,
             "chunks": chunks,
-            "exchange": ("staged: %d chunks, all-gather of chunk c under the "
-                         "kernel of c+1" % chunks)
+            "exchange": ("staged: %d logical shards per device, all-gather "
+                         "of shard c under the kernel of c+1" % L_used)
+            if L_used > 1 else
+            ("staged: %d chunks, all-gather of chunk c under the "
+             "kernel of c+1" % chunks)
             if chunks > 1 and labels[kernel] not in ("tile_panels", "stream")
             and Mloc % (chunks * 32) == 0 and (n > 1 or args.force_exchange)
             and not ragged
@@ -194,6 +243,7 @@ def native_leg(args, n, timeout_s=240):
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     c, roof = j["config"], j["roofline"]
     return {"backend": c["backend"], "value": j["value"],
+            "exchange_arrangement": c.get("exchange_arrangement"),
             "ms_per_step": j["ms_per_step"], "kernel": c["kernel"],
             "blocked_layout": c.get("blocked_layout"),
             "kernel_ms_per_rank": roof.get("kernel_ms_per_rank"),

@@ -79,6 +79,19 @@ int spmv_mgpu_generate_part(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
                             int64_t W, uint64_t seed, int as_hll,
                             int partition);
 
+/* LOGICAL SHARDS: from the next load / generate on, every device holds its
+ * rows as `shards` matrices of rows / shards rows each (1 = off, up to 16;
+ * even partition, rows per device divisible by shards * 32, else the load
+ * answers -EINVAL).  A kernel that runs whole matrices only -- the blocked
+ * path -- then overlaps all the same: logical shard c of every device is
+ * all-gathered on the second stream while shard c + 1 computes (the staged
+ * pipeline with chunk = shard).  reserve_cus: compute units a sweep copy
+ * leaves OUT of its persistent grid so that RCCL's kernels run beside it
+ * (spmv_mgpu_autotune rebuilds the picked sweep layout with it when
+ * shards > 1).  What bench.py --native-mgpu times against the plain
+ * arrangement, keeping the faster (config.exchange_arrangement). */
+int spmv_mgpu_set_logical_shards(spmv_mgpu *g, int shards, int reserve_cus);
+
 /* how RAGGED fragments travel (enum spmv_mgpu_ragged_exchange; default
  * _XCHG_P2P).  Persists over reloads; the even partition keeps its in-place
  * all-gather.  With force (spmv_mgpu_set_exchange) _BCAST and _PADDED run

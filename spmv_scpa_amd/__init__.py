@@ -1371,6 +1371,7 @@ _sig("spmv_mgpu_load_csr_part", C.c_int, C.c_void_p, _CSRp, C.c_int, C.c_int)
 _sig("spmv_mgpu_generate_part", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
      C.c_int64, C.c_uint64, C.c_int, C.c_int)
 _sig("spmv_mgpu_set_ragged_exchange", C.c_int, C.c_void_p, C.c_int)
+_sig("spmv_mgpu_set_logical_shards", C.c_int, C.c_void_p, C.c_int, C.c_int)
 _sig("spmv_mgpu_partition", C.c_int, C.c_void_p, _ip, C.POINTER(C.c_int64))
 _sig("spmv_mgpu_build_panels", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
@@ -1434,6 +1435,13 @@ class MultiGpu:
             self.h, kind, rows_per_gpu, K, W, seed, int(as_hll),
             self.PARTITIONS[partition]), "spmv_mgpu_generate_part")
         self.M = rows_per_gpu * self.n
+
+    def set_logical_shards(self, shards=1, reserve_cus=0):
+        """from the next load / generate on: every device's rows as `shards`
+        matrices (the blocked path then overlaps shard c's all-gather with
+        shard c+1's kernel); reserve_cus: CUs a sweep copy leaves to RCCL"""
+        _check(_lib.spmv_mgpu_set_logical_shards(self.h, shards, reserve_cus),
+               "spmv_mgpu_set_logical_shards")
 
     def set_ragged_exchange(self, kind="p2p"):
         """how ragged fragments travel: p2p | bcast | padded"""

@@ -38,8 +38,10 @@ static struct {
     int partition; /* SPMV_MGPU_PART_EVEN / _NNZ */
     int xchg;      /* SPMV_MGPU_XCHG_*: how ragged fragments travel */
     int chunks;    /* > 1: opt-in staged exchange (even partition only) */
+    int shards;    /* > 1: opt-in logical shards per GPU (overlap for the
+                      blocked path too; even partition only) */
 } opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, 0, false,
-         SPMV_MGPU_PART_EVEN, SPMV_MGPU_XCHG_P2P, 1};
+         SPMV_MGPU_PART_EVEN, SPMV_MGPU_XCHG_P2P, 1, 1};
 
 static sparse_csr *A;
 static sparse_hll *H_row, *H_col;
@@ -305,8 +307,19 @@ static void run_multi_gpu(void) {
                 break;
         }
         rc = spmv_mgpu_set_ragged_exchange(g, opt.xchg);
-        if (!rc)
+        if (!rc) /* a sweep pick leaves 8 CUs to RCCL (spmv_mgpu.h) */
+            rc = spmv_mgpu_set_logical_shards(g, opt.shards, 8);
+        if (!rc) {
             rc = spmv_mgpu_load_csr_part(g, A, fmt, opt.partition);
+            if (rc == -EINVAL && opt.shards > 1) {
+                LOG_WARN("rows per GPU do not split into %d logical shards of "
+                         "whole hack blocks: running one shard per GPU",
+                         opt.shards);
+                rc = spmv_mgpu_set_logical_shards(g, 1, 0);
+                if (!rc)
+                    rc = spmv_mgpu_load_csr_part(g, A, fmt, opt.partition);
+            }
+        }
         if (!rc) /* 1: the exchange follows the kernels (default) */
             rc = spmv_mgpu_set_exchange(g, opt.chunks, 0);
         if (!rc)
@@ -390,6 +403,7 @@ int main(int argc, char **argv) {
         {"partition", required_argument, NULL, 1004},
         {"ragged-exchange", required_argument, NULL, 1005},
         {"exchange-chunks", required_argument, NULL, 1006},
+        {"logical-shards", required_argument, NULL, 1007},
         {"no-cpu", no_argument, NULL, 'C'},
         {"debug", no_argument, NULL, 'd'},
         {"help", no_argument, NULL, 'h'},
@@ -433,6 +447,13 @@ int main(int argc, char **argv) {
             opt.chunks = atoi(optarg);
             if (opt.chunks < 1 || opt.chunks > 16) {
                 LOG_ERR("--exchange-chunks takes 1..16");
+                return EXIT_FAILURE;
+            }
+            break;
+        case 1007:
+            opt.shards = atoi(optarg);
+            if (opt.shards < 1 || opt.shards > 16) {
+                LOG_ERR("--logical-shards takes 1..16");
                 return EXIT_FAILURE;
             }
             break;

@@ -31,8 +31,17 @@ struct spmv_mgpu {
     std::vector<int> dev;
     std::vector<hipStream_t> stream;
     std::vector<ncclComm_t> comm;
-    std::vector<spmv_csr_dev *> csr;
-    std::vector<spmv_hll_dev *> hll;
+    std::vector<spmv_csr_dev *> csr; /* [device]: the shard -- with logical */
+    std::vector<spmv_hll_dev *> hll; /* shards, logical shard 0 of the device */
+    /* LOGICAL SHARDS (spmv_mgpu_set_logical_shards): a device's rows as L
+     * matrices of rows / L rows each (global columns, local rows), so that a
+     * kernel that runs whole matrices only -- the blocked path -- still
+     * overlaps: logical shard c of every device is all-gathered on the second
+     * stream while shard c+1 computes (the staged pipeline, chunk = shard).
+     * Shards 1 .. L-1 of device r live at [r * (L - 1) + c - 1]. */
+    int L, want_L, reserve_cus;
+    std::vector<spmv_csr_dev *> xcsr;
+    std::vector<spmv_hll_dev *> xhll;
     std::vector<double *> x, y;
     /* overlapped exchange (spmv_mgpu_set_exchange): the shard's rows in
      * `chunks` equal pieces; chunk c of every device is written into the
@@ -129,10 +138,24 @@ struct device_guard {
     }
 };
 
+/* logical shard c of device r (c = 0: the device's own slot) */
+static spmv_csr_dev *&csr_at(spmv_mgpu *g, int r, int c) {
+    return c == 0 ? g->csr[(size_t)r] : g->xcsr[(size_t)r * (g->L - 1) + c - 1];
+}
+static spmv_hll_dev *&hll_at(spmv_mgpu *g, int r, int c) {
+    return c == 0 ? g->hll[(size_t)r] : g->xhll[(size_t)r * (g->L - 1) + c - 1];
+}
+
 /* shards and vectors of a previous load / generate on this handle */
 static void drop_shards(spmv_mgpu *g) {
     for (int r = 0; r < g->n; ++r) {
         (void)hipSetDevice(g->dev[r]);
+        for (int c = 1; c < g->L; ++c) {
+            if (csr_at(g, r, c))
+                spmv_csr_release(csr_at(g, r, c));
+            if (hll_at(g, r, c))
+                spmv_hll_release(hll_at(g, r, c));
+        }
         if (g->csr[r])
             spmv_csr_release(g->csr[r]);
         if (g->hll[r])
@@ -148,6 +171,23 @@ static void drop_shards(spmv_mgpu *g) {
     g->rows_per_gpu = g->M = g->N = 0;
     g->ragged = g->longest = 0;
     g->start.assign((size_t)g->n + 1, 0);
+    g->xcsr.clear();
+    g->xhll.clear();
+    g->L = 1;
+}
+
+/* the logical shards asked for take effect now (a load / generate): needs the
+ * even partition with rows per device = L shards of whole hack blocks */
+static int adopt_logical_shards(spmv_mgpu *g) {
+    g->L = 1;
+    if (g->want_L <= 1)
+        return 0;
+    if (g->ragged || !g->even || g->rows_per_gpu % (g->want_L * HACK_SIZE))
+        return -EINVAL;
+    g->L = g->want_L;
+    g->xcsr.assign((size_t)g->n * (g->L - 1), NULL);
+    g->xhll.assign((size_t)g->n * (g->L - 1), NULL);
+    return 0;
 }
 
 extern "C" {
@@ -219,6 +259,8 @@ static int create(int ngpus, int loopback, spmv_mgpu **out) {
     g->chunks = 1;
     g->force_exchange = 0;
     g->even = 0;
+    g->L = g->want_L = 1;
+    g->reserve_cus = 0;
     g->loopback = loopback;
     for (int r = 0; r < ngpus; ++r)
         g->dev[r] = loopback ? r % have : r;
@@ -271,8 +313,8 @@ static int alloc_vectors(spmv_mgpu *g) {
                           (size_t)(g->N > 0 ? g->N : 1) * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&g->y[r], (ny ? ny : 1) * sizeof(double)));
         HIP_TRY(hipMemset(g->y[r], 0, (ny ? ny : 1) * sizeof(double)));
-        if (g->chunks > 1 && ny > 0 && !g->ragged) /* a reload keeps the
-                                                      exchange setting */
+        if ((g->chunks > 1 || g->L > 1) && ny > 0 && !g->ragged)
+            /* a reload keeps the exchange setting */
             HIP_TRY(hipMalloc((void **)&g->stage[r], ny * sizeof(double)));
     }
     rc = alloc_pad(g);
@@ -320,22 +362,28 @@ int spmv_mgpu_load_csr_part(spmv_mgpu *g, const sparse_csr *A, int as_hll,
     g->N = A->N;
     g->is_hll = as_hll != 0;
     set_ranges(g, starts, A->M, partition == SPMV_MGPU_PART_NNZ);
+    rc = adopt_logical_shards(g);
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         if (starts[r + 1] == starts[r] && g->n > 1)
             continue; /* more devices than hack blocks: nothing to run here */
-        sparse_csr *S = csr_row_slice(A, starts[r], starts[r + 1]);
-        if (IS_ERR(S)) {
-            rc = PTR_ERR(S);
-            break;
+        const int per = (starts[r + 1] - starts[r]) / g->L;
+        for (int c = 0; c < g->L && !rc; ++c) {
+            const int a = starts[r] + c * per;
+            sparse_csr *S =
+                csr_row_slice(A, a, c == g->L - 1 ? starts[r + 1] : a + per);
+            if (IS_ERR(S)) {
+                rc = PTR_ERR(S);
+                break;
+            }
+            rc = spmv_csr_upload(S, &csr_at(g, r, c));
+            if (!rc && as_hll) {
+                rc = spmv_hll_from_csr(csr_at(g, r, c), 1, &hll_at(g, r, c));
+                spmv_csr_release(csr_at(g, r, c));
+                csr_at(g, r, c) = NULL;
+            }
+            csr_free(S);
         }
-        rc = spmv_csr_upload(S, &g->csr[r]);
-        if (!rc && as_hll) {
-            rc = spmv_hll_from_csr(g->csr[r], 1, &g->hll[r]);
-            spmv_csr_release(g->csr[r]);
-            g->csr[r] = NULL;
-        }
-        csr_free(S);
     }
     if (!rc)
         rc = alloc_vectors(g);
@@ -372,16 +420,21 @@ int spmv_mgpu_generate_part(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
     g->M = g->N = M;
     g->is_hll = as_hll != 0;
     set_ranges(g, starts, M, partition == SPMV_MGPU_PART_NNZ);
+    rc = adopt_logical_shards(g);
     for (int r = 0; r < g->n && !rc; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         if (starts[r + 1] == starts[r] && g->n > 1)
             continue;
-        rc = spmv_csr_generate(kind, starts[r + 1] - starts[r], g->N, K, W,
-                               (int64_t)starts[r], seed, &g->csr[r]);
-        if (!rc && as_hll) {
-            rc = spmv_hll_from_csr(g->csr[r], 1, &g->hll[r]);
-            spmv_csr_release(g->csr[r]);
-            g->csr[r] = NULL;
+        const int per = (starts[r + 1] - starts[r]) / g->L;
+        for (int c = 0; c < g->L && !rc; ++c) {
+            rc = spmv_csr_generate(kind, per, g->N, K, W,
+                                   (int64_t)starts[r] + (int64_t)c * per, seed,
+                                   &csr_at(g, r, c));
+            if (!rc && as_hll) {
+                rc = spmv_hll_from_csr(csr_at(g, r, c), 1, &hll_at(g, r, c));
+                spmv_csr_release(csr_at(g, r, c));
+                csr_at(g, r, c) = NULL;
+            }
         }
     }
     if (!rc)
@@ -473,24 +526,44 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
     }
     /* device 0's blocked copy is the model: every other shard is rebuilt
      * with its schedule, tile height and build options unless it already
-     * holds the same (shards of one matrix run one arrangement) */
-    for (int r = 1; r < g->n && !rc && pick == blocked; ++r) {
-        if (!g->hll[r] && !g->csr[r])
-            continue;
+     * holds the same (shards of one matrix run one arrangement).  With logical
+     * shards a sweep copy is first rebuilt on a grid that leaves reserve_cus
+     * compute units to RCCL (the all-gather of shard c runs beside the
+     * persistent launch of shard c + 1). */
+    if (!rc && pick == blocked && g->L > 1 && g->reserve_cus > 0) {
+        spmv_panel_opts o;
+        int waves = 0;
+        spmv_panel_opts_default(&o); /* struct_size: the layout call checks it */
+        HIP_TRY(hipSetDevice(g->dev[0]));
+        rc = g->is_hll ? spmv_hll_panels_layout(g->hll[0], &o, &waves)
+                       : spmv_csr_panels_layout(g->csr[0], &o, &waves);
+        if (!rc && o.sched == 1) {
+            o.reserve_cus = g->reserve_cus;
+            rc = g->is_hll ? spmv_hll_build_panels_opts(g->hll[0], &o)
+                           : spmv_csr_build_panels_opts(g->csr[0], &o);
+        }
+    }
+    for (int r = 0; r < g->n && !rc && pick == blocked; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
-        const bool same =
-            g->is_hll
-                ? (spmv_hll_panels_schedule(g->hll[r]) ==
-                       spmv_hll_panels_schedule(g->hll[0]) &&
-                   spmv_hll_panels_tile_rows(g->hll[r]) ==
-                       spmv_hll_panels_tile_rows(g->hll[0]))
-                : (spmv_csr_panels_schedule(g->csr[r]) ==
-                       spmv_csr_panels_schedule(g->csr[0]) &&
-                   spmv_csr_panels_tile_rows(g->csr[r]) ==
-                       spmv_csr_panels_tile_rows(g->csr[0]));
-        if (!same)
-            rc = g->is_hll ? spmv_hll_build_panels_like(g->hll[r], g->hll[0])
-                           : spmv_csr_build_panels_like(g->csr[r], g->csr[0]);
+        for (int c = 0; c < g->L && !rc; ++c) {
+            if ((r == 0 && c == 0) || (!hll_at(g, r, c) && !csr_at(g, r, c)))
+                continue;
+            bool same = false;
+            if (c == 0 && g->L == 1)
+                same = g->is_hll
+                           ? (spmv_hll_panels_schedule(g->hll[r]) ==
+                                  spmv_hll_panels_schedule(g->hll[0]) &&
+                              spmv_hll_panels_tile_rows(g->hll[r]) ==
+                                  spmv_hll_panels_tile_rows(g->hll[0]))
+                           : (spmv_csr_panels_schedule(g->csr[r]) ==
+                                  spmv_csr_panels_schedule(g->csr[0]) &&
+                              spmv_csr_panels_tile_rows(g->csr[r]) ==
+                                  spmv_csr_panels_tile_rows(g->csr[0]));
+            if (!same)
+                rc = g->is_hll
+                         ? spmv_hll_build_panels_like(hll_at(g, r, c), g->hll[0])
+                         : spmv_csr_build_panels_like(csr_at(g, r, c), g->csr[0]);
+        }
     }
     if (!rc)
         *kernel = pick;
@@ -506,11 +579,13 @@ int spmv_mgpu_build_panels(spmv_mgpu *g, const spmv_panel_opts *opts) {
     int rc = 0;
     device_guard keep;
     for (int r = 0; r < g->n && !rc; ++r) {
-        if (!g->hll[r] && !g->csr[r])
-            continue;
         HIP_TRY(hipSetDevice(g->dev[r]));
-        rc = g->is_hll ? spmv_hll_build_panels_opts(g->hll[r], opts)
-                       : spmv_csr_build_panels_opts(g->csr[r], opts);
+        for (int c = 0; c < g->L && !rc; ++c) {
+            if (!hll_at(g, r, c) && !csr_at(g, r, c))
+                continue;
+            rc = g->is_hll ? spmv_hll_build_panels_opts(hll_at(g, r, c), opts)
+                           : spmv_csr_build_panels_opts(csr_at(g, r, c), opts);
+        }
     }
 fail:
     return rc;
@@ -588,6 +663,10 @@ __global__ void k_unstage(int world, int k, int ch, const double *stage,
  * path runs whole shards), rows divisible into chunks of whole hack blocks */
 static bool staged(const spmv_mgpu *g, int kernel) {
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
+    /* logical shards: the shard is the chunk, whatever the kernel */
+    if (g->L > 1)
+        return g->even && !g->ragged && !g->loopback &&
+               (g->n > 1 || g->force_exchange) && g->stage[0] != NULL;
     /* the CSR stream kernel (4) owns a row-block table of the whole shard: a
      * row sub-range would fall back to the sub-wave kernel (spmv_engine.h),
      * which a long row makes 100x slower -- whole-shard launches instead */
@@ -607,7 +686,7 @@ static bool staged(const spmv_mgpu *g, int kernel) {
  * i.e. before the wait for the gathers: the kernel time of a device */
 static int step_staged(spmv_mgpu *g, int kernel, hipEvent_t *kernels_done) {
     int rc = 0;
-    const int k = g->chunks, ch = g->rows_per_gpu / k;
+    const int k = g->L > 1 ? g->L : g->chunks, ch = g->rows_per_gpu / k;
     for (int c = 0; c < k && !rc; ++c) {
         for (int r = 0; r < g->n && !rc; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
@@ -615,6 +694,13 @@ static int step_staged(spmv_mgpu *g, int kernel, hipEvent_t *kernels_done) {
              * indexes y from local row 0, so hand it (slot - first row) */
             double *slot = g->stage[r] + ((size_t)c * g->n + r) * ch;
             double *ybase = slot - (size_t)c * ch;
+            if (g->L > 1) /* a logical shard is a whole matrix: its row 0 */
+                rc = g->is_hll
+                         ? spmv_hll_launch(hll_at(g, r, c), kernel, NULL,
+                                           g->x[r], slot, g->stream[r])
+                         : spmv_csr_launch(csr_at(g, r, c), kernel, NULL,
+                                           g->x[r], slot, g->stream[r]);
+            else
             rc = g->is_hll
                      ? spmv_hll_launch_blocks(g->hll[r], kernel, NULL, g->x[r],
                                               ybase, c * ch / HACK_SIZE,
@@ -666,6 +752,21 @@ static int launch_shard(spmv_mgpu *g, int r, int kernel) {
     double *yfrag = g->y[r] + (size_t)g->start[r];
     if (!g->hll[r] && !g->csr[r])
         return 0; /* an empty range */
+    if (g->L > 1) { /* logical shards, one after the other, in row order */
+        const size_t per = (size_t)g->rows_per_gpu / g->L;
+        for (int c = 0; c < g->L; ++c) {
+            const int rc =
+                g->is_hll ? spmv_hll_launch(hll_at(g, r, c), kernel, NULL,
+                                            g->x[r], yfrag + c * per,
+                                            g->stream[r])
+                          : spmv_csr_launch(csr_at(g, r, c), kernel, NULL,
+                                            g->x[r], yfrag + c * per,
+                                            g->stream[r]);
+            if (rc)
+                return rc;
+        }
+        return 0;
+    }
     return g->is_hll ? spmv_hll_launch(g->hll[r], kernel, NULL, g->x[r], yfrag,
                                        g->stream[r])
                      : spmv_csr_launch(g->csr[r], kernel, NULL, g->x[r], yfrag,
@@ -837,11 +938,25 @@ int spmv_mgpu_set_exchange(spmv_mgpu *g, int chunks, int force) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         (void)hipFree(g->stage[r]);
         g->stage[r] = NULL;
-        if (chunks > 1 && ny > 0)
+        if ((chunks > 1 || g->L > 1) && ny > 0)
             HIP_TRY(hipMalloc((void **)&g->stage[r], ny * sizeof(double)));
     }
 fail:
     return rc;
+}
+
+/* L logical shards per device from the NEXT load / generate on (1 = off);
+ * reserve_cus: compute units a sweep copy leaves to RCCL when L > 1 (applied
+ * by spmv_mgpu_autotune).  The load answers -EINVAL when the rows of a device
+ * do not split into L shards of whole hack blocks (or the partition is not the
+ * even one). */
+int spmv_mgpu_set_logical_shards(spmv_mgpu *g, int shards, int reserve_cus) {
+    MG_OK(g);
+    if (shards < 1 || shards > MG_MAX_CHUNKS || reserve_cus < 0)
+        return -EINVAL;
+    g->want_L = shards;
+    g->reserve_cus = reserve_cus;
+    return 0;
 }
 
 /* how RAGGED fragments travel (see gather_y_ragged); the setting persists
@@ -866,9 +981,14 @@ int spmv_mgpu_partition(const spmv_mgpu *g, int *starts, int64_t *entries) {
     MG_OK(g);
     for (int r = 0; r <= g->n && starts; ++r)
         starts[r] = g->start[r];
-    for (int r = 0; r < g->n && entries; ++r)
-        entries[r] = g->hll[r] ? g->hll[r]->NZ
-                               : (g->csr[r] ? g->csr[r]->NZ : 0);
+    for (int r = 0; r < g->n && entries; ++r) {
+        int64_t nz = 0;
+        spmv_mgpu *m = const_cast<spmv_mgpu *>(g);
+        for (int c = 0; c < g->L; ++c)
+            nz += hll_at(m, r, c) ? hll_at(m, r, c)->NZ
+                                  : (csr_at(m, r, c) ? csr_at(m, r, c)->NZ : 0);
+        entries[r] = nz;
+    }
     return g->ragged;
 }
 
@@ -994,11 +1114,24 @@ int spmv_mgpu_shard_info(const spmv_mgpu *g, int rank, int64_t *stored,
     MG_OK(g);
     if (!g || rank < 0 || rank >= g->n || (!g->hll[rank] && !g->csr[rank]))
         return -EINVAL;
-    if (stored)
-        *stored = g->hll[rank] ? g->hll[rank]->slots : g->csr[rank]->NZ;
-    if (alg_bytes)
-        *alg_bytes = g->hll[rank] ? spmv_hll_algorithmic_bytes(g->hll[rank])
-                                  : spmv_csr_algorithmic_bytes(g->csr[rank]);
+    {
+        /* summed over the device's logical shards */
+        spmv_mgpu *m = const_cast<spmv_mgpu *>(g);
+        int64_t st = 0, by = 0;
+        for (int c = 0; c < g->L; ++c) {
+            if (hll_at(m, rank, c)) {
+                st += hll_at(m, rank, c)->slots;
+                by += spmv_hll_algorithmic_bytes(hll_at(m, rank, c));
+            } else if (csr_at(m, rank, c)) {
+                st += csr_at(m, rank, c)->NZ;
+                by += spmv_csr_algorithmic_bytes(csr_at(m, rank, c));
+            }
+        }
+        if (stored)
+            *stored = st;
+        if (alg_bytes)
+            *alg_bytes = by;
+    }
     if (layout && len) {
         layout[0] = 0;
         const int rc = g->hll[rank]
@@ -1028,16 +1161,19 @@ int spmv_mgpu_info(const spmv_mgpu *g, int *ngpus, int *rows_per_gpu,
     if (!g)
         return -EINVAL;
     int64_t nz = 0, by = 0;
+    spmv_mgpu *m = const_cast<spmv_mgpu *>(g);
     for (int r = 0; r < g->n; ++r) {
         int64_t b = 0;
-        if (g->hll[r]) {
-            nz += g->hll[r]->NZ;
-            b = spmv_hll_algorithmic_bytes(g->hll[r]);
-        } else if (g->csr[r]) {
-            nz += g->csr[r]->NZ;
-            b = spmv_csr_algorithmic_bytes(g->csr[r]);
+        for (int c = 0; c < g->L; ++c) {
+            if (hll_at(m, r, c)) {
+                nz += hll_at(m, r, c)->NZ;
+                b += spmv_hll_algorithmic_bytes(hll_at(m, r, c));
+            } else if (csr_at(m, r, c)) {
+                nz += csr_at(m, r, c)->NZ;
+                b += spmv_csr_algorithmic_bytes(csr_at(m, r, c));
+            }
         }
-        if (b > by) /* the heaviest shard bounds the step */
+        if (b > by) /* the heaviest device bounds the step */
             by = b;
     }
     if (ngpus)

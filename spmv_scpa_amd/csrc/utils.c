@@ -58,6 +58,9 @@ void log_prog_usage(const char *prog) {
             "                          balanced; ragged y fragments)\n"
             "      --ragged-exchange <x>  p2p (default) | bcast | padded\n"
             "      --exchange-chunks <k>  opt-in staged all-gather, k row chunks\n"
+            "      --logical-shards <L>   opt-in: L matrices per GPU, the all-gather\n"
+            "                          of shard c under the kernel of c+1 (also for\n"
+            "                          the blocked path)\n"
             "  -i, --iters <n>         timed GPU launches per kernel (default 20)\n"
             "      --no-cpu            skip the serial / OpenMP benchmarks\n"
             "      --only-multi-gpu    run only the -g <n> step (GPU-count sweeps)\n"

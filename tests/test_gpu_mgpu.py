@@ -413,3 +413,114 @@ def test_driver_partition_flag(tmp_path):
                         "-g", "1", "--partition", "rows"],
                        capture_output=True, text=True, env=env, timeout=60)
     assert r.returncode != 0 and "even or nnz" in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("as_hll", [True, False])
+@pytest.mark.parametrize("shards,sched", [(2, "sweep"), (4, "chain"),
+                                          (4, None)])
+def test_logical_shards_overlap_the_blocked_path(as_hll, shards, sched):
+    """spmv_mgpu_set_logical_shards: a device's rows as L matrices; the
+    staged pipeline then runs with chunk = logical shard -- shard c of every
+    device all-gathered on the second stream (here: 1-rank collectives) while
+    shard c+1 computes -- for the BLOCKED kernel too, which only runs whole
+    matrices (sched None: a direct kernel through the same pipeline).  Whole
+    y against the oracle's rows, several steps, the bench shape, shard_info /
+    partition summed over the logical shards."""
+    n = min(S.device_count(), 8)
+    rows = 128_000
+    g = S.MultiGpu(n)
+    g.set_logical_shards(shards, reserve_cus=8 if sched == "sweep" else 0)
+    g.generate(S.SYNTH_RANDOM, rows, 16, 1 << 30, 42, as_hll=as_hll)
+    g.fill_x(7)
+    g.set_exchange(1, force=True)
+    if sched is None:
+        kernel = 1 if as_hll else 2
+    else:
+        kernel = S.HLL_KERNEL_PANELS if as_hll else S.CSR_KERNEL_PANELS
+        g.build_panels(sched)
+    ms = g.spmv(kernel=kernel, warmup=1, iters=3)
+    assert len(ms) == 3 and np.all(ms > 0)
+    M = rows * n
+    y = g.get_y(n - 1)
+    per = rows // shards
+    probe = sorted({0, per - 1, per, 2 * per - 1, rows - 1, M - 1} | set(
+        np.random.default_rng(5).integers(0, M, 200).tolist()))
+    for grow in probe:
+        want, sc = O.synth_row_dot(S.SYNTH_RANDOM, M, M, 16, 1 << 30, 0, 42, 7,
+                                   grow)
+        assert abs(y[grow] - want) <= 1e-12 * sc, (grow, y[grow], want)
+    wall, kms = g.run(kernel, 1, 3)
+    assert wall > 0 and np.all(kms > 0)
+    stored, alg, layout = g.shard_info(0)
+    assert stored == rows * 16 and alg > 12 * stored
+    st, ent, ragged = g.partition()
+    assert not ragged and ent == [rows * 16] * n
+    # the selector's pick is propagated to every logical shard (and a sweep
+    # pick is rebuilt on a grid that leaves CUs to RCCL)
+    k = g.autotune()
+    g.spmv(kernel=k, warmup=0, iters=2)
+    y2 = g.get_y(0)
+    for grow in probe[:40]:
+        want, sc = O.synth_row_dot(S.SYNTH_RANDOM, M, M, 16, 1 << 30, 0, 42, 7,
+                                   grow)
+        assert abs(y2[grow] - want) <= 1e-12 * sc, grow
+    g.destroy()
+
+
+def test_logical_shards_on_logical_devices_and_what_is_refused():
+    """rehearsal handle (copies instead of collectives): 3 logical devices x
+    2 logical shards through the row-order path; rows that do not split into
+    whole hack blocks per shard, or the nnz partition, are refused"""
+    g = S.MultiGpu(3, rehearsal=True)
+    g.set_logical_shards(2)
+    rows = 64_000
+    g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, as_hll=True)
+    g.fill_x(7)
+    k = g.autotune()
+    g.spmv(kernel=k, warmup=0, iters=2)
+    M = rows * 3
+    for r in range(3):
+        y = g.get_y(r)
+        for grow in (0, rows // 2 - 1, rows // 2, rows, M - 1, 99_999):
+            want, sc = O.synth_row_dot(S.SYNTH_RAGGED, M, M, 24, 4096, 0, 42,
+                                       7, grow)
+            assert abs(y[grow] - want) <= 1e-12 * sc, (r, grow)
+    with pytest.raises(OSError):  # 64 032 rows: not 2 shards of whole blocks
+        g.generate(S.SYNTH_RANDOM, 64_032, 16, 4096, 42)
+    with pytest.raises(OSError):
+        g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, partition="nnz")
+    g.set_logical_shards(1)
+    g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, partition="nnz")  # fine again
+    with pytest.raises(OSError):
+        g.set_logical_shards(17)
+    g.destroy()
+
+
+def test_native_bench_chooses_its_exchange_arrangement_by_measurement():
+    """bench.py --native-mgpu with an exchange (here forced, one device):
+    the plain arrangement and the logical-shard one are both built and timed,
+    the line says which ran"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    for extra in (["--window", "0"], ["--window", "65536"]):
+        r = subprocess.run(
+            [sys.executable, os.path.join(S.ROOT, "bench.py"), "--native-mgpu",
+             "--gpus", "1", "--force-exchange", "--rows-per-gpu", "640000",
+             "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+             "--no-extras"] + extra,
+            capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        j = json.loads([l for l in r.stdout.splitlines()
+                        if l.startswith("{")][-1])
+        c = j["config"]
+        arr = c["exchange_arrangement"]
+        assert "exchange after the kernels" in arr and "logical shards" in arr
+        assert arr.endswith("-> logical shards") or arr.endswith(
+            "-> exchange after the kernels"), arr
+        assert c["logical_shards_per_gpu"] in (1, 2, 4)
+        if c["logical_shards_per_gpu"] > 1:
+            assert c["exchange"].startswith("staged: %d logical shards"
+                                            % c["logical_shards_per_gpu"])
+        assert j["rows_checked"] >= 258 and j["value"] > 0
