@@ -524,3 +524,24 @@ def test_native_bench_chooses_its_exchange_arrangement_by_measurement():
             assert c["exchange"].startswith("staged: %d logical shards"
                                             % c["logical_shards_per_gpu"])
         assert j["rows_checked"] >= 258 and j["value"] > 0
+
+
+def test_driver_logical_shards_flag(tmp_path):
+    """spmv_scpa_amd -g 1 --logical-shards 2 -d: two matrices per GPU, y
+    validated against the serial CSR result; rows that do not split fall
+    back to one shard with a warning"""
+    drv = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
+    env = dict(os.environ, OMP_NUM_THREADS="4", SPMV_FORCE_MGPU="1")
+    r = subprocess.run([drv, "-s", "random", "--rows", "64000", "--nnz-row",
+                        "16", "--window", "4096", "-o", str(tmp_path), "-d",
+                        "--iters", "3", "--no-cpu", "-g", "1",
+                        "--logical-shards", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "do not split" not in r.stdout + r.stderr
+    r = subprocess.run([drv, "-m", G.mtx_path("sym70"), "-o", str(tmp_path),
+                        "-d", "--iters", "2", "--no-cpu", "-g", "1",
+                        "--logical-shards", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "do not split into 2 logical shards" in r.stdout + r.stderr
