@@ -359,6 +359,7 @@ def roofline_dict(alg_bytes, kern_ms, kname, nnz, traffic, why=None):
         # the blocked layout the counters were taken on (the selector runs
         # again in every pass: compare with config.blocked_layout)
         "traffic_layout": traffic.get("blocked_layout") if traffic else None,
+        # (bench lines print "same" here when it equals config.blocked_layout)
         "kernel": kname, "algorithmic_bytes_per_launch": alg_bytes,
         "kernel_ms_avg": round(kavg, 5),
         "kernel_ms_min": round(float(np.min(kern_ms)), 5),

@@ -77,11 +77,11 @@ def cpu_baseline(S, kind, M, N, K, W, csv_dir, name, reps=3):
     ladder = thread_ladder(nproc, quota)
     qtxt = ("cgroup quota %g CPUs of %d visible hardware threads" %
             (quota, nproc)) if quota else "%d hardware threads" % nproc
-    sample = ("full size: %s %dx%d, %d nnz/row, W=%s, same generator and "
-              "seeds as the GPU run; CSR serial + omp_guided + omp_nnz at "
-              "threads %s, then HLL serial + omp_guided at the same thread "
-              "counts (15 s box); every leg: median of %d samples, each the "
-              "single-shot bench repeated over >= %d ms; %s"
+    sample = ("full size: %s %dx%d, %d nnz/row, W=%s, the GPU run's generator "
+              "and seeds; CSR serial + omp_guided + omp_nnz at threads %s, "
+              "then HLL serial + omp_guided at the same counts (15 s box); "
+              "every leg: median of %d samples, each the single-shot bench "
+              "repeated over >= %d ms; %s"
               % (name, M, N, K, "N" if W >= 2 * N else str(W),
                  "/".join(str(t) for t in ladder), reps, CPU_WINDOW_MS, qtxt))
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_fast")
@@ -123,8 +123,10 @@ def cpu_baseline(S, kind, M, N, K, W, csv_dir, name, reps=3):
                     if hll else None,
                     "host_threads": nproc, "cpu_quota": quota,
                     "reps": reps, "window_ms": CPU_WINDOW_MS,
-                    "ladder": [[r["format"], r["bench"], r["threads"],
-                                round(r["gflops"], 3)] for r in runs],
+                    # [format, bench (serial / guided / nnz), threads, GFLOP/s]
+                    "ladder": [[r["format"], r["bench"].replace("omp_", ""),
+                                r["threads"], round(r["gflops"], 2)]
+                               for r in runs],
                     "hll_convert_s": round(res.get("hll_prep_ms", 0) / 1e3, 1),
                     "hll_skipped_threads": res.get("hll_skipped_threads", []),
                     "csv_dir": logged, "wall_s": round(time.time() - t0, 1)}

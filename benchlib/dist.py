@@ -609,6 +609,9 @@ def run_rank(args, argv, omp_team):
     traffic, why = (measured_traffic(workload, kname, sched_now) if world == 1
                     else (None, "single-GPU profiles only"))
     roof = roofline_dict(alg_bytes, kern_ms, kname, job.nnz_local, traffic, why)
+    if roof["traffic_layout"] and \
+            roof["traffic_layout"] == blocked_desc["blocked_layout"]:
+        roof["traffic_layout"] = "same as config.blocked_layout"
     if per_rank:  # rank 0's events above; every rank's mean here
         roof["kernel_ms_per_rank"] = [round(v, 5) for v in per_rank]
         roof["kernel_ms_min_rank"] = round(min(per_rank), 5)

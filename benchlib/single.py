@@ -48,9 +48,10 @@ def window_variants(S, torch, x, y, Mloc, Nglob, K, fmt_family):
                 "gflops": round(2.0 * dH.NZ / (float(np.mean(ms)) * 1e6), 1),
                 "achieved": round(b / (float(np.mean(ms)) * 1e6), 1),
                 "frac": round(b / (float(np.mean(ms)) * 1e6) / HBM_PEAK_GBPS, 4),
-                "traffic": round(tr["bytes_per_launch"]) if tr else None,
-                "profile": ("profiles/" + tr["source"]) if tr else None,
             }
+            if tr:  # committed rocprofv3 passes of this variant
+                out[tag]["traffic"] = round(tr["bytes_per_launch"])
+                out[tag]["profile"] = "profiles/" + tr["source"]
             if fam == "ragged":  # what the format pads, and what was priced
                 out[tag]["stored_slots_over_nnz"] = round(dH.slots / dH.NZ, 4)
                 out[tag]["priced_on"] = (

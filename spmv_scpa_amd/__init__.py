@@ -174,11 +174,13 @@ def rocm_runtime_report():
     built = _lib.spmv_hip_build_version()
     run = _lib.spmv_hip_runtime_version()
     maps = mapped_rocm_runtimes()
+    lib = (maps.get("libamdhip64.so") or [None])[0]
     return {"hip_built": _fmt_hip(built),
             "hip_runtime": _fmt_hip(run) if run > 0 else None,
             "shared_with_torch": bool(ROCM_RUNTIME_SHARED_WITH_TORCH),
-            "runtimes_mapped": {k: len(v) for k, v in maps.items()},
-            "hip_library": (maps.get("libamdhip64.so") or [None])[0]}
+            # copies of the HIP / RCCL / HSA runtime mapped: 1 each when healthy
+            "runtimes_mapped": max([len(v) for v in maps.values()] or [0]),
+            "hip_from": "torch/lib" if lib and "/torch/lib/" in lib else lib}
 
 
 def _check_the_bound_runtime():
