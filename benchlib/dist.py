@@ -80,10 +80,16 @@ class RankJob:
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # a collective that never completes (a rank died in a leg) ends this
+        # rank after 5 minutes instead of holding the GPUs until the caller's
+        # own limit
+        import datetime
+        limit = datetime.timedelta(seconds=300)
         if self.args.backend == "gloo":
-            self.dist.init_process_group("gloo")
+            self.dist.init_process_group("gloo", timeout=limit)
         else:
-            self.dist.init_process_group("nccl", device_id=self.dev)
+            self.dist.init_process_group("nccl", device_id=self.dev,
+                                         timeout=limit)
 
     def sync(self):
         self.torch.cuda.synchronize()
