@@ -500,23 +500,27 @@ int spmv_mgpu_autotune(spmv_mgpu *g, int *kernel) {
          * ngpus x the 0.5..3 s of a selector run */
         std::vector<int> rcs((size_t)g->n, 0), picks((size_t)g->n, -1);
         std::vector<std::thread> th;
+        auto tune = [g, &rcs, &picks](int r) {
+            if (hipSetDevice(g->dev[r]) != hipSuccess) {
+                rcs[(size_t)r] = -ENODEV;
+                return;
+            }
+            double *yfrag = g->y[r] + (size_t)g->start[r];
+            int k = -1;
+            rcs[(size_t)r] =
+                g->is_hll
+                    ? spmv_hll_autotune(g->hll[r], g->x[r], yfrag, 1, &k, NULL)
+                    : spmv_csr_autotune(g->csr[r], g->x[r], yfrag, 1, &k, NULL);
+            picks[(size_t)r] = k;
+        };
         for (int r = 0; r < g->n; ++r) {
             if (!g->hll[r] && !g->csr[r])
                 continue; /* an empty range */
-            th.emplace_back([g, r, &rcs, &picks]() {
-                if (hipSetDevice(g->dev[r]) != hipSuccess) {
-                    rcs[(size_t)r] = -ENODEV;
-                    return;
-                }
-                double *yfrag = g->y[r] + (size_t)g->start[r];
-                int k = -1;
-                rcs[(size_t)r] =
-                    g->is_hll ? spmv_hll_autotune(g->hll[r], g->x[r], yfrag, 1,
-                                                  &k, NULL)
-                              : spmv_csr_autotune(g->csr[r], g->x[r], yfrag, 1,
-                                                  &k, NULL);
-                picks[(size_t)r] = k;
-            });
+            try {
+                th.emplace_back(tune, r);
+            } catch (...) { /* no thread to be had: tune it from here */
+                tune(r);
+            }
         }
         for (std::thread &t : th)
             t.join();
