@@ -20,11 +20,17 @@
  *
  * STATUS: UNMEASURED with more than one device -- the boxes this was built
  * on have one GPU.  What HAS run there: everything with n = 1 (`-g 1`,
- * bench.py --native-mgpu --gpus 1), and with spmv_mgpu_set_exchange(chunks,
- * force = 1) the whole overlapped pipeline -- chunk kernels into the staging
- * buffer, the grouped ncclAllGather per chunk on the second stream (a 1-rank
- * collective), the copy back -- against the oracle (tests/test_gpu_mgpu.py).
- * The n > 1 timings and RCCL's behaviour across devices have not run yet.
+ * bench.py --native-mgpu --gpus 1); with spmv_mgpu_set_exchange(chunks,
+ * force = 1) the RCCL side as 1-rank collectives -- the in-place all-gather,
+ * the staged pipeline (chunk kernels or logical shards into the staging
+ * buffer, grouped ncclAllGather per chunk on the second stream, the copy
+ * back), ncclBroadcast / padded all-gather of a ragged partition -- against
+ * the oracle; and on REHEARSAL handles (spmv_mgpu_create_rehearsal: n logical
+ * devices on the one card, copies instead of collectives) everything that
+ * depends on n > 1 but not on RCCL: even / nnz partitions, ragged offsets,
+ * empty ranges, the concurrent per-device selector, pick propagation, logical
+ * shards (tests/test_gpu_mgpu.py).  The n > 1 timings and RCCL's behaviour
+ * across devices have not run yet.
  */
 #ifndef SPMV_MGPU_H
 #define SPMV_MGPU_H
