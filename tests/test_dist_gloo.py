@@ -171,3 +171,51 @@ def test_partition_helpers():
     assert D.chunk_bounds(40, 8) == [0, 40]
     assert D.chunk_bounds(96, 8) == [0, 32, 64, 96]
     assert D.chunk_bounds(10, 4) == [0, 10]
+
+
+def test_nnz_partition_property_fuzz():
+    """random row-length profiles, alignments and part counts: the library's
+    cut == the Python mirror, boundaries aligned and ascending, no empty
+    range while blocks suffice, and no cut of the same shape has a smaller
+    largest range by more than one block's weight (prefix-nearest cuts are
+    within one block of the ideal share)"""
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    import spmv_scpa_amd as S
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 3000), st.integers(1, 9), st.sampled_from([1, 8, 32]),
+           st.integers(0, 2 ** 31 - 1), st.sampled_from(["flat", "exp", "hub"]))
+    def prop(M, world, align, seed, shape):
+        rng = np.random.default_rng(seed)
+        if shape == "flat":
+            ln = rng.integers(0, 50, M)
+        elif shape == "exp":
+            ln = np.minimum(rng.exponential(20.0, M).astype(np.int64), 5000)
+        else:
+            ln = rng.integers(0, 8, M)
+            ln[rng.integers(0, M)] = 100_000
+        irp = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+        got = D.nnz_row_partition(irp, world, align)
+        lib = S._lib.partition_rows_nnz_aligned
+        arr = np.ascontiguousarray(irp, dtype=np.int32)
+        import ctypes as C
+        p = lib(arr.ctypes.data_as(C.POINTER(C.c_int)), M, world, align)
+        out = [p[k] for k in range(world + 1)]
+        S._libc_free(p)
+        assert got == out
+        assert got[0] == 0 and got[-1] == M
+        assert all(b >= a for a, b in zip(got, got[1:]))
+        assert all(v % align == 0 or v == M for v in got)
+        nb = -(-M // align)
+        if nb >= world:
+            assert all(b > a for a, b in zip(got, got[1:]))
+        # within one block of the ideal share (unless forced by "no empty")
+        per = [int(irp[got[k + 1]] - irp[got[k]]) for k in range(world)]
+        heaviest_block = max(
+            int(irp[min(b * align + align, M)] - irp[b * align])
+            for b in range(nb))
+        if nb >= 4 * world:
+            assert max(per) <= irp[-1] / world + 2 * heaviest_block + 1
+
+    prop()
