@@ -189,7 +189,12 @@ def test_bench_wrappers_and_reference_abi_names():
     (S.SYNTH_RAGGED, 50_021, 60_000, 32, 2048),
     (S.SYNTH_POWERLAW, 150_001, 150_001, 3, 1 << 30),
     (S.SYNTH_HUB, 50_021, 60_000, 6, 2048),
-], ids=["ragged", "powerlaw", "hub"])
+    # rows of 225..375 entries: a 128-row range exceeds the LDS budget of the
+    # generator and of the CSR->HLL fill -- their direct-access fallbacks
+    (S.SYNTH_RAGGED, 30_011, 60_000, 300, 8192),
+    # every 64th row 8x longer than the others
+    (S.SYNTH_KKT, 50_021, 60_000, 16, 2048),
+], ids=["ragged", "powerlaw", "hub", "wide_rows", "kkt"])
 def test_persistent_handles_and_device_generation(kind, M, N, K, W):
     """upload once / launch many; device-side generation and device-side
     CSR->HLL agree bit-for-bit with the host path."""
