@@ -59,50 +59,63 @@ def native_mgpu_bench(args, argv, omp_team):
         kernel = g.autotune()
         t_tune = time.time() - t_tune
     # ---- the exchange arrangement, chosen by measurement like the torch
-    # path's: (a) every device's kernel, then the exchange; (b) the rows of a
-    # device as LOGICAL SHARDS (4; a sweep pick: 2, on a grid that leaves
-    # --reserve-cus CUs to RCCL), shard c all-gathered on a second stream
-    # while shard c+1 computes (spmv_mgpu_set_logical_shards).  Both are
-    # built and timed (5 steps), the faster one runs the K timed steps.
+    # path's.  (a) every device's kernel, then ONE RCCL all-gather (what
+    # BASELINE names; always the first candidate).  (b) the rows of a device
+    # as LOGICAL SHARDS (4; a sweep pick: 2, on a grid that leaves
+    # --reserve-cus CUs to RCCL's kernels), shard c all-gathered on a second
+    # stream while shard c+1 computes.  (c) the same shards with the COPY
+    # ENGINE: every device pushes shard c into its peers' y with peer copies
+    # (SDMA over xGMI) -- no kernel competes with the SpMV for CUs, so no CUs
+    # are reserved.  Each is built and timed (5 steps); the fastest runs the K
+    # timed steps.
     arrangement = None
-    L_used = 1
+    L_used, engine_used = 1, "copy" if args.native_rehearsal else "rccl"
     if ((n > 1 or args.force_exchange) and not ragged and chunks == 1
             and Mloc % (4 * 32) == 0 and not args.no_arrangement_choice):
         try:
             _, _, lay = g.shard_info(0)
             sweep = lay.startswith("sweep")
-            L2, res = (2, args.reserve_cus) if sweep else (4, 0)
+            L2 = 2 if sweep else 4
             g.spmv(kernel, 1, 1)
-            t_a = g.run(kernel, 1, 5)[0] / 5
-            g2 = S.MultiGpu(n, rehearsal=args.native_rehearsal)
-            g2.set_logical_shards(L2, res)
-            g2.generate(kind, Mloc, K, W, MATRIX_SEED,
-                        as_hll=args.format == "hll")
-            g2.fill_x(X_SEED)
-            g2.set_exchange(1, args.force_exchange)
-            if args.kernel >= 0:
-                k2 = args.kernel
-                if labels[k2] == "tile_panels":
-                    g2.build_panels()
-            else:
-                k2 = g2.autotune()
-            g2.spmv(k2, 1, 1)
-            t_b = g2.run(k2, 1, 5)[0] / 5
-            arrangement = (
-                "exchange after the kernels %.3f ms/step vs %d logical shards "
-                "per device%s with the all-gather of shard c under the kernel "
-                "of c+1 %.3f ms/step" % (
-                    t_a, L2, " on %d fewer CUs" % res if res else "", t_b))
-            if t_b < t_a:
-                g.destroy()
-                g, kernel, L_used = g2, k2, L2
-                starts, nnz_per_rank, ragged = g.partition()
-                arrangement += " -> logical shards"
-            else:
-                g2.destroy()
-                arrangement += " -> exchange after the kernels"
+            best_t = g.run(kernel, 1, 5)[0] / 5
+            notes = ["exchange after the kernels %.3f ms/step" % best_t]
+            cands = [] if args.native_rehearsal else [
+                ("%d logical shards%s, RCCL all-gather of shard c under the "
+                 "kernel of c+1" % (L2, " on %d fewer CUs" % args.reserve_cus
+                                    if sweep else ""),
+                 L2, args.reserve_cus if sweep else 0, "rccl")]
+            cands.append(("%d logical shards, shard c pushed by the copy "
+                          "engines under the kernel of c+1" % L2, L2, 0,
+                          "copy"))
+            chosen = "exchange after the kernels"
+            for label, L2_, res, eng in cands:
+                g2 = S.MultiGpu(n, rehearsal=args.native_rehearsal)
+                g2.set_logical_shards(L2_, res)
+                if not args.native_rehearsal:
+                    g2.set_exchange_engine(eng)
+                g2.generate(kind, Mloc, K, W, MATRIX_SEED,
+                            as_hll=args.format == "hll")
+                g2.fill_x(X_SEED)
+                g2.set_exchange(1, args.force_exchange)
+                if args.kernel >= 0:
+                    k2 = args.kernel
+                    if labels[k2] == "tile_panels":
+                        g2.build_panels()
+                else:
+                    k2 = g2.autotune()
+                g2.spmv(k2, 1, 1)
+                t2 = g2.run(k2, 1, 5)[0] / 5
+                notes.append("%s %.3f ms/step" % (label, t2))
+                if t2 < best_t:
+                    g.destroy()
+                    g, kernel, best_t = g2, k2, t2
+                    L_used, engine_used, chosen = L2_, eng, label
+                    starts, nnz_per_rank, ragged = g.partition()
+                else:
+                    g2.destroy()
+            arrangement = " vs ".join(notes) + " -> " + chosen
         except OSError as e:
-            arrangement = "logical-shard arrangement not built (%s)" % e
+            arrangement = "alternative arrangements not built (%s)" % e
     kname = prefix + labels[kernel]
     t_setup = time.time() - t_setup
 
@@ -123,13 +136,22 @@ def native_mgpu_bench(args, argv, omp_team):
     wall_ms, kms = g.run(kernel, args.warmup, args.steps)
     exch = g.exchange_only(10) if n > 1 or args.force_exchange else None
     exch_alt = None
-    if ragged and (n > 1 or args.force_exchange):
-        # the same ragged fragments by the other two ways (spmv_mgpu.h)
+    if (n > 1 or args.force_exchange) and not args.native_rehearsal:
+        # the same fragments by the other ways the library can move them
+        # (spmv_mgpu.h): the copy engines, and -- ragged fragments -- the
+        # three RCCL forms
         exch_alt = {}
-        for kind_x in ("p2p", "bcast", "padded"):
+        g.set_exchange_engine("copy")
+        exch_alt["copy"] = round(g.exchange_only(5), 5)
+        g.set_exchange_engine("rccl")
+        for kind_x in ("p2p", "bcast", "padded") if ragged else ():
             g.set_ragged_exchange(kind_x)
             exch_alt[kind_x] = round(g.exchange_only(5), 5)
-        g.set_ragged_exchange(args.ragged_exchange)
+        if ragged:
+            g.set_ragged_exchange(args.ragged_exchange)
+        else:
+            exch_alt["allgather"] = round(g.exchange_only(5), 5)
+        g.set_exchange_engine(engine_used)
     ngp, _, nnz_global, _ = g.info()
     stored, alg_bytes, layout = g.shard_info(0)
     if args.format == "hll" and kernel == S.HLL_KERNEL_PANELS:
@@ -181,8 +203,11 @@ def native_mgpu_bench(args, argv, omp_team):
             "row_starts": starts if ragged else None,
             "nnz_per_rank": nnz_per_rank if n > 1 else None,
             "chunks": chunks,
-            "exchange": ("staged: %d logical shards per device, all-gather "
-                         "of shard c under the kernel of c+1" % L_used)
+            "exchange": ("%d logical shards per device, shard c %s under the "
+                         "kernel of c+1" % (
+                             L_used, "pushed by the copy engines"
+                             if engine_used == "copy" else
+                             "all-gathered (staged)"))
             if L_used > 1 else
             ("staged: %d chunks, all-gather of chunk c under the "
              "kernel of c+1" % chunks)

@@ -85,6 +85,18 @@ int spmv_mgpu_generate_part(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
                             int64_t W, uint64_t seed, int as_hll,
                             int partition);
 
+/* Which ENGINE moves the fragments of y.  _RCCL (default): collectives --
+ * kernels that run on compute units.  _COPY: every device pushes its fragment
+ * into its peers' y with hipMemcpyAsync (the copy engines over xGMI; peer
+ * access is enabled at create): nothing competes with the SpMV kernels for
+ * CUs -- what the persistent sweep launch of the blocked path wants -- any
+ * partition (even or ragged) needs no staging, and with logical shards the
+ * pushes of shard c run under the kernel of shard c + 1.  Not the all-gather
+ * BASELINE names: an alternative bench.py --native-mgpu times beside it
+ * (exchange_alternatives_ms "copy").  Rehearsal handles always use it. */
+enum spmv_mgpu_engine { SPMV_MGPU_ENGINE_RCCL = 0, SPMV_MGPU_ENGINE_COPY = 1 };
+int spmv_mgpu_set_exchange_engine(spmv_mgpu *g, int engine);
+
 /* LOGICAL SHARDS: from the next load / generate on, every device holds its
  * rows as `shards` matrices of rows / shards rows each (1 = off, up to 16;
  * even partition, rows per device divisible by shards * 32, else the load

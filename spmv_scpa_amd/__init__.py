@@ -1374,6 +1374,7 @@ _sig("spmv_mgpu_generate_part", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
      C.c_int64, C.c_uint64, C.c_int, C.c_int)
 _sig("spmv_mgpu_set_ragged_exchange", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_mgpu_set_logical_shards", C.c_int, C.c_void_p, C.c_int, C.c_int)
+_sig("spmv_mgpu_set_exchange_engine", C.c_int, C.c_void_p, C.c_int)
 _sig("spmv_mgpu_partition", C.c_int, C.c_void_p, _ip, C.POINTER(C.c_int64))
 _sig("spmv_mgpu_build_panels", C.c_int, C.c_void_p, C.POINTER(PanelOpts))
 _sig("spmv_mgpu_set_x", C.c_int, C.c_void_p, _dp)
@@ -1437,6 +1438,14 @@ class MultiGpu:
             self.h, kind, rows_per_gpu, K, W, seed, int(as_hll),
             self.PARTITIONS[partition]), "spmv_mgpu_generate_part")
         self.M = rows_per_gpu * self.n
+
+    ENGINES = {"rccl": 0, "copy": 1}
+
+    def set_exchange_engine(self, engine="rccl"):
+        """"rccl": collectives (default); "copy": peer copies on the copy
+        engines (no kernel competes with the SpMV for CUs)"""
+        _check(_lib.spmv_mgpu_set_exchange_engine(self.h, self.ENGINES[engine]),
+               "spmv_mgpu_set_exchange_engine")
 
     def set_logical_shards(self, shards=1, reserve_cus=0):
         """from the next load / generate on: every device's rows as `shards`

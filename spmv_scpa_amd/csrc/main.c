@@ -40,8 +40,9 @@ static struct {
     int chunks;    /* > 1: opt-in staged exchange (even partition only) */
     int shards;    /* > 1: opt-in logical shards per GPU (overlap for the
                       blocked path too; even partition only) */
+    int engine;    /* SPMV_MGPU_ENGINE_RCCL (default) / _COPY */
 } opt = {NULL, NULL, NULL, 1000000, 16, 20, 1, 1, 0, 0, false,
-         SPMV_MGPU_PART_EVEN, SPMV_MGPU_XCHG_P2P, 1, 1};
+         SPMV_MGPU_PART_EVEN, SPMV_MGPU_XCHG_P2P, 1, 1, SPMV_MGPU_ENGINE_RCCL};
 
 static sparse_csr *A;
 static sparse_hll *H_row, *H_col;
@@ -307,8 +308,12 @@ static void run_multi_gpu(void) {
                 break;
         }
         rc = spmv_mgpu_set_ragged_exchange(g, opt.xchg);
-        if (!rc) /* a sweep pick leaves 8 CUs to RCCL (spmv_mgpu.h) */
-            rc = spmv_mgpu_set_logical_shards(g, opt.shards, 8);
+        if (!rc)
+            rc = spmv_mgpu_set_exchange_engine(g, opt.engine);
+        if (!rc) /* a sweep pick leaves 8 CUs to RCCL's kernels; the copy
+                    engines need none (spmv_mgpu.h) */
+            rc = spmv_mgpu_set_logical_shards(
+                g, opt.shards, opt.engine == SPMV_MGPU_ENGINE_RCCL ? 8 : 0);
         if (!rc) {
             rc = spmv_mgpu_load_csr_part(g, A, fmt, opt.partition);
             if (rc == -EINVAL && opt.shards > 1) {
@@ -404,6 +409,7 @@ int main(int argc, char **argv) {
         {"ragged-exchange", required_argument, NULL, 1005},
         {"exchange-chunks", required_argument, NULL, 1006},
         {"logical-shards", required_argument, NULL, 1007},
+        {"exchange-engine", required_argument, NULL, 1008},
         {"no-cpu", no_argument, NULL, 'C'},
         {"debug", no_argument, NULL, 'd'},
         {"help", no_argument, NULL, 'h'},
@@ -454,6 +460,16 @@ int main(int argc, char **argv) {
             opt.shards = atoi(optarg);
             if (opt.shards < 1 || opt.shards > 16) {
                 LOG_ERR("--logical-shards takes 1..16");
+                return EXIT_FAILURE;
+            }
+            break;
+        case 1008:
+            if (!strcmp(optarg, "copy"))
+                opt.engine = SPMV_MGPU_ENGINE_COPY;
+            else if (!strcmp(optarg, "rccl"))
+                opt.engine = SPMV_MGPU_ENGINE_RCCL;
+            else {
+                LOG_ERR("--exchange-engine takes rccl or copy, not %s", optarg);
                 return EXIT_FAILURE;
             }
             break;

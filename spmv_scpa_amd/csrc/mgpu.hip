@@ -40,6 +40,14 @@ struct spmv_mgpu {
      * stream while shard c+1 computes (the staged pipeline, chunk = shard).
      * Shards 1 .. L-1 of device r live at [r * (L - 1) + c - 1]. */
     int L, want_L, reserve_cus;
+    /* exchange ENGINE: 0 = RCCL collectives (kernels on the CUs), 1 = the
+     * copy engines -- every device PUSHES its fragment into its peers' y with
+     * hipMemcpyAsync over xGMI (SDMA, peer access enabled at create): no
+     * kernel competes with the SpMV for compute units, which is what the
+     * persistent sweep launch wants, and with logical shards the pushes of
+     * shard c run under the kernel of c + 1 without any staging buffer.
+     * Rehearsal handles always run this engine (same-device copies). */
+    int engine;
     std::vector<spmv_csr_dev *> xcsr;
     std::vector<spmv_hll_dev *> xhll;
     std::vector<double *> x, y;
@@ -261,11 +269,26 @@ static int create(int ngpus, int loopback, spmv_mgpu **out) {
     g->even = 0;
     g->L = g->want_L = 1;
     g->reserve_cus = 0;
+    g->engine = loopback ? 1 : 0;
     g->loopback = loopback;
     for (int r = 0; r < ngpus; ++r)
         g->dev[r] = loopback ? r % have : r;
     if (!loopback)
         NCCL_TRY(ncclCommInitAll(g->comm.data(), ngpus, g->dev.data()));
+    for (int r = 0; r < ngpus && !loopback; ++r) {
+        /* peer access for the copy engine (and for RCCL's own P2P paths);
+         * "already enabled" is not an error, "not supported" leaves the
+         * copies to the runtime's staging */
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        for (int p = 0; p < ngpus; ++p) {
+            int can = 0;
+            if (p != r &&
+                hipDeviceCanAccessPeer(&can, g->dev[r], g->dev[p]) == hipSuccess &&
+                can)
+                (void)hipDeviceEnablePeerAccess(g->dev[p], 0);
+        }
+        (void)hipGetLastError();
+    }
     for (int r = 0; r < ngpus; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
         HIP_TRY(hipStreamCreate(&g->stream[r]));
@@ -597,7 +620,8 @@ fail:
 
 static int launch_shard(spmv_mgpu *g, int r, int kernel);
 static int sync_all(spmv_mgpu *g);
-static int gather_y(spmv_mgpu *g);
+static int push_rows(spmv_mgpu *g, int r, int a, int b, int slot);
+static int gather_y(spmv_mgpu *g, bool after_kernels = true);
 static bool staged(const spmv_mgpu *g, int kernel);
 static int step_staged(spmv_mgpu *g, int kernel, hipEvent_t *kernels_done);
 
@@ -667,6 +691,8 @@ __global__ void k_unstage(int world, int k, int ch, const double *stage,
  * path runs whole shards), rows divisible into chunks of whole hack blocks */
 static bool staged(const spmv_mgpu *g, int kernel) {
     const int blocked = g->is_hll ? SPMV_HLL_KERNEL_PANELS : SPMV_CSR_KERNEL_PANELS;
+    if (g->engine == 1) /* the copy engine needs no staging: rows in place */
+        return false;
     /* logical shards: the shard is the chunk, whatever the kernel */
     if (g->L > 1)
         return g->even && !g->ragged && !g->loopback &&
@@ -758,14 +784,19 @@ static int launch_shard(spmv_mgpu *g, int r, int kernel) {
         return 0; /* an empty range */
     if (g->L > 1) { /* logical shards, one after the other, in row order */
         const size_t per = (size_t)g->rows_per_gpu / g->L;
+        const bool push = g->engine == 1 && (g->n > 1 || g->force_exchange);
         for (int c = 0; c < g->L; ++c) {
-            const int rc =
+            int rc =
                 g->is_hll ? spmv_hll_launch(hll_at(g, r, c), kernel, NULL,
                                             g->x[r], yfrag + c * per,
                                             g->stream[r])
                           : spmv_csr_launch(csr_at(g, r, c), kernel, NULL,
                                             g->x[r], yfrag + c * per,
                                             g->stream[r]);
+            /* copy engine: shard c travels while shard c + 1 computes */
+            if (!rc && push)
+                rc = push_rows(g, r, g->start[r] + (int)(c * per),
+                               g->start[r] + (int)((c + 1) * per), c);
             if (rc)
                 return rc;
         }
@@ -862,35 +893,61 @@ fail:
     return rc;
 }
 
-/* rehearsal handles: every logical device copies every other one's fragment
- * out of that device's y (all streams drained first: no cross-stream order
- * is needed, and no timing is claimed) */
-static int gather_y_loopback(spmv_mgpu *g) {
-    int rc = sync_all(g);
-    for (int r = 0; r < g->n && !rc; ++r) {
-        HIP_TRY(hipSetDevice(g->dev[r]));
-        for (int p = 0; p < g->n; ++p) {
-            const size_t cnt = (size_t)(g->start[p + 1] - g->start[p]);
-            if (p != r && cnt)
-                HIP_TRY(hipMemcpyAsync(g->y[r] + g->start[p],
-                                       g->y[p] + g->start[p],
-                                       cnt * sizeof(double), hipMemcpyDefault,
-                                       g->stream[r]));
-        }
-    }
-    if (!rc)
-        rc = sync_all(g);
+/* COPY ENGINE.  push_rows: after what device r has enqueued on its compute
+ * stream so far (the kernel that produced rows [a, b), global numbering), its
+ * second stream copies those rows into every peer's y.  `slot` picks the event
+ * (one per logical shard of a step). */
+static int push_rows(spmv_mgpu *g, int r, int a, int b, int slot) {
+    int rc = 0;
+    if (b <= a)
+        return 0;
+    hipEvent_t e = g->ev_k[(size_t)r * MG_MAX_CHUNKS + slot];
+    HIP_TRY(hipSetDevice(g->dev[r]));
+    HIP_TRY(hipEventRecord(e, g->stream[r]));
+    HIP_TRY(hipStreamWaitEvent(g->xstream[r], e, 0));
+    for (int p = 0; p < g->n; ++p)
+        if (p != r)
+            HIP_TRY(hipMemcpyAsync(g->y[p] + a, g->y[r] + a,
+                                   (size_t)(b - a) * sizeof(double),
+                                   hipMemcpyDefault, g->xstream[r]));
 fail:
     return rc;
 }
 
+/* ... and the close of a step: every device's compute stream waits for its own
+ * pushes (the next step's kernel overwrites the rows they read; synchronising
+ * the compute streams of ALL devices then covers every copy of the step) */
+static int close_pushes(spmv_mgpu *g) {
+    int rc = 0;
+    for (int r = 0; r < g->n; ++r) {
+        hipEvent_t e = g->ev_x[(size_t)r * MG_MAX_CHUNKS];
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipEventRecord(e, g->xstream[r]));
+        HIP_TRY(hipStreamWaitEvent(g->stream[r], e, 0));
+    }
+fail:
+    return rc;
+}
+
+static int gather_y_copy(spmv_mgpu *g, bool after_kernels) {
+    int rc = 0;
+    /* with logical shards the pushes were issued shard by shard behind the
+     * kernels (launch_shard); otherwise -- and when the exchange runs by
+     * itself -- the whole fragment goes now */
+    for (int r = 0; r < g->n && !rc && (g->L == 1 || !after_kernels); ++r)
+        rc = push_rows(g, r, g->start[r], g->start[r + 1], 0);
+    if (!rc)
+        rc = close_pushes(g);
+    return rc;
+}
+
 /* one grouped in-place all-gather of y over all devices (n > 1) */
-static int gather_y(spmv_mgpu *g) {
+static int gather_y(spmv_mgpu *g, bool after_kernels) {
     int rc = 0;
     if (g->n < 2 && !g->force_exchange)
         return 0;
-    if (g->loopback)
-        return gather_y_loopback(g);
+    if (g->engine == 1)
+        return gather_y_copy(g, after_kernels);
     if (g->ragged)
         return gather_y_ragged(g);
     /* every call inside the group is checked, and the group is ALWAYS closed
@@ -946,6 +1003,21 @@ int spmv_mgpu_set_exchange(spmv_mgpu *g, int chunks, int force) {
             HIP_TRY(hipMalloc((void **)&g->stage[r], ny * sizeof(double)));
     }
 fail:
+    return rc;
+}
+
+/* which engine moves the fragments: SPMV_MGPU_ENGINE_RCCL (collectives) or
+ * _COPY (peer copies on the copy engines; see struct spmv_mgpu) */
+int spmv_mgpu_set_exchange_engine(spmv_mgpu *g, int engine) {
+    MG_OK(g);
+    if (engine != SPMV_MGPU_ENGINE_RCCL && engine != SPMV_MGPU_ENGINE_COPY)
+        return -EINVAL;
+    if (g->loopback && engine != SPMV_MGPU_ENGINE_COPY)
+        return -ENOTSUP; /* a rehearsal handle has no communicator */
+    device_guard keep;
+    const int rc = sync_all(g);
+    if (!rc)
+        g->engine = engine;
     return rc;
 }
 
@@ -1077,12 +1149,12 @@ int spmv_mgpu_exchange_only(spmv_mgpu *g, int iters, double *ms_avg) {
     *ms_avg = 0.0;
     if (g->n < 2 && !g->force_exchange)
         return 0;
-    int rc = gather_y(g); /* warm */
+    int rc = gather_y(g, false); /* warm */
     if (!rc)
         rc = sync_all(g);
     const double t0 = wall_ms_now();
     for (int it = 0; it < iters && !rc; ++it)
-        rc = gather_y(g);
+        rc = gather_y(g, false);
     if (!rc)
         rc = sync_all(g);
     if (!rc)

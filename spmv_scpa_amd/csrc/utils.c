@@ -58,6 +58,8 @@ void log_prog_usage(const char *prog) {
             "                          balanced; ragged y fragments)\n"
             "      --ragged-exchange <x>  p2p (default) | bcast | padded\n"
             "      --exchange-chunks <k>  opt-in staged all-gather, k row chunks\n"
+            "      --exchange-engine <e>  rccl (collectives, default) | copy (peer\n"
+            "                          copies on the copy engines)\n"
             "      --logical-shards <L>   opt-in: L matrices per GPU, the all-gather\n"
             "                          of shard c under the kernel of c+1 (also for\n"
             "                          the blocked path)\n"

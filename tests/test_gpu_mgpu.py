@@ -517,12 +517,14 @@ def test_native_bench_chooses_its_exchange_arrangement_by_measurement():
         c = j["config"]
         arr = c["exchange_arrangement"]
         assert "exchange after the kernels" in arr and "logical shards" in arr
-        assert arr.endswith("-> logical shards") or arr.endswith(
-            "-> exchange after the kernels"), arr
+        assert "RCCL all-gather of shard c" in arr and "copy engines" in arr
+        assert " -> " in arr
         assert c["logical_shards_per_gpu"] in (1, 2, 4)
         if c["logical_shards_per_gpu"] > 1:
-            assert c["exchange"].startswith("staged: %d logical shards"
+            assert c["exchange"].startswith("%d logical shards"
                                             % c["logical_shards_per_gpu"])
+        alt = c["exchange_alternatives_ms"]
+        assert set(alt) == {"copy", "allgather"} and min(alt.values()) >= 0
         assert j["rows_checked"] >= 258 and j["value"] > 0
 
 
@@ -532,16 +534,57 @@ def test_driver_logical_shards_flag(tmp_path):
     back to one shard with a warning"""
     drv = os.path.join(S.ROOT, "spmv_scpa_amd", "bin", "spmv_scpa_amd")
     env = dict(os.environ, OMP_NUM_THREADS="4", SPMV_FORCE_MGPU="1")
-    r = subprocess.run([drv, "-s", "random", "--rows", "64000", "--nnz-row",
-                        "16", "--window", "4096", "-o", str(tmp_path), "-d",
-                        "--iters", "3", "--no-cpu", "-g", "1",
-                        "--logical-shards", "2"],
-                       capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode == 0, r.stderr + r.stdout
-    assert "do not split" not in r.stdout + r.stderr
+    for eng in ("rccl", "copy"):
+        r = subprocess.run([drv, "-s", "random", "--rows", "64000", "--nnz-row",
+                            "16", "--window", "4096", "-o", str(tmp_path), "-d",
+                            "--iters", "3", "--no-cpu", "-g", "1",
+                            "--logical-shards", "2", "--exchange-engine", eng],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "do not split" not in r.stdout + r.stderr
     r = subprocess.run([drv, "-m", G.mtx_path("sym70"), "-o", str(tmp_path),
                         "-d", "--iters", "2", "--no-cpu", "-g", "1",
                         "--logical-shards", "2"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "do not split into 2 logical shards" in r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("shards", [1, 4])
+@pytest.mark.parametrize("partition", ["even", "nnz"])
+def test_copy_engine_exchange(shards, partition):
+    """spmv_mgpu_set_exchange_engine("copy"): every device pushes its
+    fragment -- or, with logical shards, shard after shard behind the kernels
+    -- into its peers' y with peer copies instead of RCCL collectives.  On a
+    rehearsal handle (4 logical devices on the card; its only engine) and on a
+    real one-device handle with the exchange forced; whole y on every device
+    against the oracle, back-to-back steps (the close of a step orders the
+    next kernel behind this step's pushes)."""
+    if shards > 1 and partition == "nnz":
+        pytest.skip("logical shards need the even partition")
+    rows = 64_000
+    for g, n in ((S.MultiGpu(4, rehearsal=True), 4), (S.MultiGpu(1), 1)):
+        g.set_logical_shards(shards)
+        if n == 1:
+            g.set_exchange_engine("copy")
+            g.set_exchange(1, force=True)
+        g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, as_hll=True,
+                   partition=partition)
+        g.fill_x(7)
+        wall, kms = g.run(1, 1, 6)  # six steps without a sync in between
+        assert wall > 0
+        M = rows * n
+        for r in range(n):
+            y = g.get_y(r)
+            for grow in (0, rows // 4, rows - 1, M // 2, M - 1):
+                want, sc = O.synth_row_dot(S.SYNTH_RAGGED, M, M, 24, 4096, 0,
+                                           42, 7, grow)
+                assert abs(y[grow] - want) <= 1e-12 * sc, (n, r, grow)
+        assert g.exchange_only(3) >= 0.0
+        g.destroy()
+    with pytest.raises(OSError):  # a rehearsal handle has no communicator
+        h = S.MultiGpu(2, rehearsal=True)
+        try:
+            h.set_exchange_engine("rccl")
+        finally:
+            h.destroy()
