@@ -59,6 +59,17 @@ def log_cpu_rows(S, out_dir, name, M, N, nnz, runs, hll_blocks=0):
 CPU_WINDOW_MS = 300  # >= 3 CFS periods of 100 ms per sample
 
 
+def cpu_model():
+    """the host CPU's model name ("report nproc, CPU model")"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()[:48]
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(S, kind, M, N, K, W, csv_dir, name, reps=3):
     """The reference's own serial + OpenMP path (oracle/_ref/ref_fast, built
     from /root/reference/src by oracle/build_ref.sh with the reference's
@@ -122,6 +133,7 @@ def cpu_baseline(S, kind, M, N, K, W, csv_dir, name, reps=3):
                     "best_hll_gflops": round(max(r["gflops"] for r in hll), 3)
                     if hll else None,
                     "host_threads": nproc, "cpu_quota": quota,
+                    "cpu_model": cpu_model(),
                     "reps": reps, "window_ms": CPU_WINDOW_MS,
                     # [format, bench (serial / guided / nnz), threads, GFLOP/s]
                     "ladder": [[r["format"], r["bench"].replace("omp_", ""),
