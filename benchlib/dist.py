@@ -704,6 +704,16 @@ def run_rank(args, argv, omp_team):
         "setup_s": round(t_setup, 2),
         "rows_checked": job.checked,
     }
+    if world > 1 and per_rank:
+        # y-throughput (global rows per second) kernel only, kernel
+        # + exchange one after the other, and as measured (the arrangement
+        # that ran overlaps what it can)
+        kmax = max(per_rank)
+        out["config"]["y_rows_per_s"] = {
+            "kernel_only": round(job.Mglob / (kmax * 1e-3), 1),
+            "kernel_then_exchange": round(
+                job.Mglob / ((kmax + exch_ms) * 1e-3), 1) if exch_ms else None,
+            "measured": round(job.Mglob / (ms_per_step * 1e-3), 1)}
     if world > 1:
         out["native"] = native
         out["legs_failed"] = job.legs.failed

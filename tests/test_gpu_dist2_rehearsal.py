@@ -69,6 +69,9 @@ def test_two_ranks_share_one_gpu(extra):
     # ONE command, ONE complete record: every optional
     # leg present or named as failed / skipped, never a lost line
     assert j["legs_failed"] == [] and j["legs_skipped"] == [], j
+    ythr = c["y_rows_per_s"]
+    assert ythr["kernel_only"] >= ythr["kernel_then_exchange"] > 0
+    assert ythr["measured"] > 0
     kkt = c["partition_kkt"]
     assert kkt["nnz_balanced"]["nnz_max_over_min"] < 1.15 < \
         kkt["even_rows"]["nnz_max_over_min"], kkt
