@@ -22,14 +22,18 @@ inputs resident in HBM.  value = 2 * nnz_global / step time, in GFLOP/s
     python bench.py --config 2     # 1M banded CSR, 16/row, flushed
     python bench.py --native-mgpu --gpus N   # the library's own multi-GPU path
 
-Prints ONE JSON line on rank 0.  At N > 1 that one line is the complete
-record of the run: the weak-scaling measurement, `config.strong` (the fixed
-80M x 80M problem), `config.exchange_ms_alone` + `exchange_alternatives_ms`,
-both exchange arrangements of the sweep schedule, `config.partition_kkt`
-(even vs nnz-balanced rows on the nlpkkt160-shaped matrix) and `native` (the
-library's own multi-GPU path, from a fresh child process once the ranks have
-released the devices); a leg that fails is named in `legs_failed` and costs
-nothing else of the line.
+Rank 0 prints the line TWICE: right after the main measurement (the PLAIN
+arrangement: each rank's kernel, then one exchange of y) -- complete, flagged
+`"provisional": true`, naming `legs_pending` -- and again at the end with what
+the optional legs added: `config.exchange_ms_alone` + `exchange_alternatives_ms`,
+`config.arrangements` (the overlapped arrangement timed beside the plain one;
+`value_best` when it wins), `config.strong` (the fixed 80M x 80M problem),
+`config.partition_kkt` (even vs nnz-balanced rows on the nlpkkt160-shaped
+matrix), `native` (the library's own multi-GPU path, from a fresh child once
+the ranks have released the devices); at N = 1 `roofline.variants`,
+`cpu_baseline`, `extras`.  The LAST line is the record.  A leg that fails is
+named in `legs_failed`; a leg that hangs is ended by a watchdog with the line
+printed (benchlib/legs.py); nothing after the main measurement can cost it.
 
 This file is the CLI and the process orchestration; the modes live in
 benchlib/: common (workload, result check, roofline records), single
@@ -66,27 +70,23 @@ def orchestrate(args, argv):
     if want_native:  # the ranks leave `native` to this parent
         os.environ["SPMV_BENCH_PARENT_RUNS_NATIVE"] = "1"
     buf = io.StringIO()
-    rc = launch_ranks(args, argv, out=buf)
+    rc = launch_ranks(args, argv, out=buf)  # rank 0's lines were passed on
     text = buf.getvalue()
     lines = [l for l in text.splitlines() if l.startswith("{")]
     if rc != 0 or not lines or not want_native:
-        sys.stdout.write(text)
-        sys.stdout.flush()
         return rc
     line = json.loads(lines[-1])
+    if line.get("provisional"):  # rank 0 never reached its final line
+        return rc
     t0 = time.time()
     try:
         from benchlib.native import native_leg
-        line["native"] = native_leg(args, args.gpus)
+        line["native"] = native_leg(args, args.gpus, timeout_s=180)
     except Exception as e:  # noqa: BLE001 - an optional leg
         line.setdefault("legs_failed", []).append("native_mgpu: %r" % (e,))
         line["native"] = None
     line.setdefault("legs_s", {})["native_mgpu"] = round(time.time() - t0, 1)
-    for l in text.splitlines():  # anything else rank 0 printed stays
-        if l is not lines[-1] and l.strip():
-            print(l)
-    print(json.dumps(line))
-    sys.stdout.flush()
+    print(json.dumps(line), flush=True)  # the last line is the complete one
     return 0
 
 

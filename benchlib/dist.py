@@ -4,13 +4,18 @@ rows partitioned by contiguous ranges, x replicated, the fragments of y
 exchanged every step.
 
 `run_rank` is what every rank executes; it is a sequence of small steps on a
-`RankJob` (build the shard, agree on the kernel, arrange the exchange, check
-rows against the host generator, time K steps, optional legs, report).  The
-optional legs of an N > 1 line -- the fixed-problem reading (`config.strong`),
-the exchange alone and its alternatives, the nnz-balanced partition of the
-nlpkkt160-shaped matrix, the library's own multi-GPU path -- each run inside
-`optional_leg`: a leg that fails is named in `legs_failed` and costs nothing
-else of the line."""
+`RankJob`: build the shard, agree on the kernel, check rows against the host
+generator, time K steps of the PLAIN arrangement (each rank's kernel, then
+ONE in-place all-gather / grouped send-recv of y), print the line.  That line
+goes out at once -- complete, flagged `provisional`, naming `legs_pending` --
+and only then the optional legs run: the exchange alone and its
+alternatives, the overlapped arrangements (`value_best` beside `value` when
+one wins), the fixed-problem reading (`config.strong`), the nnz-balanced
+partition of the nlpkkt160-shaped matrix, the library's own multi-GPU path.
+Each leg runs inside `benchlib.legs.LegRunner.run`: local work first, the
+ranks agree on failure before any collective of the leg, a leg that outlives
+its limit ends the run WITH the line (watchdog), and the final line repeats
+the main measurement plus whatever the legs added."""
 import json
 import os
 import sys
@@ -23,26 +28,13 @@ from .common import (FAMILIES, MATRIX_SEED, METRIC, ROOT, ROWS_PER_GPU, X_SEED,
                      secondary_roofline, stat_delta, strong_one_gpu,
                      strong_speedup_of, workload_name)
 from .cpu import cpu_baseline
+from .legs import LEG_BUDGET_S, LegRunner
 from .single import extra_measurements, single_matrix_bench, window_variants
 
-# wall budget of the optional legs of an N > 1 line (seconds): the driver
-# gives a bench run 600 s; the main measurement takes ~15 s, so the legs
-# together must stay well under half of that.  A leg is skipped (and named in
-# legs_skipped) when the time already spent exceeds its start-by mark.
-LEG_BUDGET_S = 240.0
-
-
-class Legs:
-    """bookkeeping of the optional legs: failures are recorded, never raised;
-    all ranks must take the same skip decision (collectives inside the legs),
-    so the clock that decides is rank 0's, broadcast by the caller"""
-
-    def __init__(self, t0):
-        self.t0 = t0
-        self.failed, self.skipped, self.seconds = [], [], {}
-
-    def spent(self):
-        return time.time() - self.t0
+# an alternative arrangement replaces nothing: it is reported as `value_best`
+# when it beats the plain one by this margin (5 + 5 timed steps decide; a
+# closer call is noise -- ADVICE r05)
+ARRANGEMENT_MARGIN = 0.97
 
 
 class RankJob:
@@ -70,26 +62,27 @@ class RankJob:
         S.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.use_dist = self.world > 1 or args.force_exchange
-        self.legs = Legs(self.t_start)
+        self.legs = None  # LegRunner, once the process group exists
 
     # ------------------------------------------------------------ plumbing
     def init_process_group(self):
-        if not self.use_dist:
-            return
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # a collective that never completes (a rank died in a leg) ends this
-        # rank after 5 minutes instead of holding the GPUs until the caller's
-        # own limit
-        import datetime
-        limit = datetime.timedelta(seconds=300)
-        if self.args.backend == "gloo":
-            self.dist.init_process_group("gloo", timeout=limit)
-        else:
-            self.dist.init_process_group("nccl", device_id=self.dev,
-                                         timeout=limit)
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            # last resort only: the legs' own watchdog (benchlib.legs) ends a
+            # run whose collective never completes long before this does
+            import datetime
+            limit = datetime.timedelta(seconds=300)
+            if self.args.backend == "gloo":
+                self.dist.init_process_group("gloo", timeout=limit)
+            else:
+                self.dist.init_process_group("nccl", device_id=self.dev,
+                                             timeout=limit)
+        self.legs = LegRunner(
+            self.rank, self.world, self.t_start, self.dist,
+            self.dev if self.args.backend == "nccl" else None, self.use_dist)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -118,27 +111,6 @@ class RankJob:
             sh.step()
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0) * 1e3 / n
-
-    def optional_leg(self, name, fn, start_by=LEG_BUDGET_S, collective=True):
-        """run fn() unless the legs' wall budget is spent; a failure is
-        recorded in legs_failed and None is returned.  The legs hold
-        collectives, so every rank must take the same skip decision: the
-        slowest rank's clock (an all-reduce) decides -- except for a leg only
-        one rank runs (collective=False)."""
-        late = self.max_over_ranks(self.legs.spent()) \
-            if self.use_dist and collective else self.legs.spent()
-        if late > start_by:
-            self.legs.skipped.append("%s (%.0f s spent, starts by %.0f s)"
-                                     % (name, late, start_by))
-            return None
-        t0 = time.time()
-        try:
-            return fn()
-        except Exception as e:  # noqa: BLE001 - an optional figure
-            self.legs.failed.append("%s: %r" % (name, e))
-            return None
-        finally:
-            self.legs.seconds[name] = round(time.time() - t0, 1)
 
     # --------------------------------------------------------- the workload
     def define_workload(self):
@@ -247,33 +219,13 @@ class RankJob:
             mat.build_panels(0)
         self.sweep = self.blocked and mat.panels_schedule() == "sweep"
 
-    def chain_logical_shards(self):
-        """the blocked path runs whole matrices only: hold the rank's rows as
-        `nsplit` logical shards (4, like the row chunks of the direct kernels)
-        so that the all-gather of one shard runs under the kernel of the next
-        -- at 8 GPUs the exchange (560 MB in per GPU) is longer than the
-        kernel of a matrix with locality"""
-        D = self.D
-        nsplit = 2 if self.args.force_exchange and self.world == 1 else 4
-        if not (self.blocked and not self.sweep and self.use_dist
-                and self.L == 1 and not self.ragged
-                and self.Mshard % (nsplit * D.HACK) == 0):
-            return
-        model = self.mats[0]
-        for m in self.mats[1:]:
-            m.release()
-        self.L, self.Mshard = nsplit, self.Mshard // nsplit
-        self.mats, self.nnz_local, self.slots = self.build_shards(
-            self.L, self.Mshard)
-        for m in self.mats:  # the tuned schedule and tile height
-            m.build_panels_like(model)
-        model.release()
-        self.arrangement = ("chain: %d logical shards, all-gather of shard c "
-                            "under the kernel of c+1" % self.L)
-
     def exchange_settings(self):
         a, D = self.args, self.D
-        chunks = a.chunks if a.chunks > 0 else (4 if self.world > 1 else 1)
+        # the PLAIN arrangement is the line's: the whole shard's kernel, then
+        # ONE exchange.  Row chunks (the overlapped "staged" pipeline) only on
+        # request (--chunks k); without it they are an optional leg whose
+        # result is reported beside `value` (alternative_arrangement)
+        chunks = a.chunks if a.chunks > 0 else 1
         if self.blocked or self.L > 1 or (a.format == "csr"
                                           and self.kernel == 4):
             chunks = 1  # the blocked path runs whole shards only; with logical
@@ -294,7 +246,7 @@ class RankJob:
             halo = -(-halo // D.HACK) * D.HACK
         self.chunks, self.halo = chunks, halo
 
-    def make_sharded(self, ms, rows_total=None, xx=None, yy=None):
+    def make_sharded(self, ms, rows_total=None, xx=None, yy=None, chunks=None):
         a = self.args
         rows_total = self.Mshard * self.L if rows_total is None else rows_total
         mode = "halo" if self.halo else (
@@ -303,50 +255,100 @@ class RankJob:
             ms if len(ms) > 1 else ms[0], self.kernel, self.rank, self.world,
             None if self.ragged else rows_total,
             self.x if xx is None else xx, self.y if yy is None else yy,
-            waves_per_block=a.waves, chunks=self.chunks,
+            waves_per_block=a.waves,
+            chunks=self.chunks if chunks is None else chunks,
             force_exchange=a.force_exchange, mode=mode, halo_rows=self.halo,
             starts=self.starts if self.ragged else None)
 
-    def choose_sweep_arrangement(self):
-        """The sweep launch is persistent and wants its whole grid resident
-        (phase counters), so by default the exchange FOLLOWS the kernel.
-        Alternative: two logical shards, each swept by a grid that leaves
-        --reserve-cus compute units free, the all-gather of the first half
-        running beside the sweep of the second.  Whether RCCL's kernels and
-        the persistent grid share the chip well is a property of the node:
-        both arrangements are timed here (5 steps each, max over ranks) and
-        the faster one is kept -- the same "choose by measurement" rule as the
-        kernel selector, and every rank sees the same reduced times."""
+    # ---------------------------------------- the overlapped arrangements
+    def alternative_kind(self):
+        """which overlapped arrangement this run could try beside the plain
+        one (None: none applies) -- decided from facts every rank shares"""
         a, D = self.args, self.D
-        if not (self.sweep and self.use_dist and self.L == 1 and not self.halo
-                and not self.ragged and self.Mshard % (2 * D.HACK) == 0):
-            return
-        try:
-            alt, nnz_alt, slots_alt = self.build_shards(2, self.Mshard // 2)
-            for m in alt:
-                m.build_panels(0, "sweep", reserve_cus=a.reserve_cus)
-            sh_alt = self.make_sharded(alt)
-            for s_ in (self.sharded, sh_alt):
-                s_.step()
-            t_serial = self.time_steps(self.sharded, 5)
-            t_split = self.time_steps(sh_alt, 5)
-            self.arrangement = (
-                "sweep: exchange after the kernel %.3f ms/step vs 2 logical "
-                "shards on %d fewer CUs with overlapped all-gather %.3f "
-                "ms/step" % (t_serial, a.reserve_cus, t_split))
-            if t_split < t_serial:
-                for m in self.mats:
-                    m.release()
-                self.mats, self.sharded = alt, sh_alt
-                self.L, self.Mshard = 2, self.Mshard // 2
-                self.nnz_local, self.slots = nnz_alt, slots_alt
-                self.arrangement += " -> overlapped"
-            else:
+        if not self.use_dist or self.L != 1 or self.halo or self.ragged:
+            return None
+        if self.sweep:
+            return "sweep_split" if self.Mshard % (2 * D.HACK) == 0 else None
+        nsplit = 2 if a.force_exchange and self.world == 1 else 4
+        if self.blocked:
+            return "logical_shards" if self.Mshard % (nsplit * D.HACK) == 0 \
+                else None
+        if a.chunks > 0 or (a.format == "csr" and self.kernel == 4):
+            return None  # chunks were asked for / the stream kernel runs whole
+        return "row_chunks" if self.Mshard % (4 * D.HACK) == 0 else None
+
+    def build_alternative(self):
+        """LOCAL half of the arrangement leg -> (kind, shards or None,
+        ShardedSpmv, nnz, slots, text):
+        sweep_split     two logical shards, each swept by a grid that leaves
+                        --reserve-cus compute units to RCCL, the all-gather of
+                        the first half beside the sweep of the second (the
+                        sweep launch is persistent and wants its whole grid
+                        resident, so by default the exchange FOLLOWS it)
+        logical_shards  blocked chain / steps: the rank's rows as 4 logical
+                        shards, the all-gather of shard c under the kernel of
+                        c+1 (at 8 GPUs the exchange, 560 MB in per GPU, is
+                        longer than the kernel of a matrix with locality)
+        row_chunks      direct kernels: 4 row chunks, chunk c all-gathered
+                        (chunk-major staging) under the kernel of c+1"""
+        a, kind = self.args, self.alternative_kind()
+        if kind == "sweep_split":
+            alt, nnz, slots = self.build_shards(2, self.Mshard // 2)
+            try:
+                for m in alt:
+                    m.build_panels(0, "sweep", reserve_cus=a.reserve_cus)
+                sh = self.make_sharded(alt)
+            except Exception:
                 for m in alt:
                     m.release()
-                self.arrangement += " -> exchange after the kernel"
-        except OSError as e:
-            self.arrangement = "sweep: overlapped arrangement not built (%s)" % e
+                raise
+            return (kind, alt, sh, nnz, slots,
+                    "2 logical shards on %d fewer CUs, the all-gather of the "
+                    "first beside the sweep of the second" % a.reserve_cus)
+        if kind == "logical_shards":
+            n = 2 if a.force_exchange and self.world == 1 else 4
+            alt, nnz, slots = self.build_shards(n, self.Mshard // n)
+            try:
+                for m in alt:  # the tuned schedule and tile height
+                    m.build_panels_like(self.mats[0])
+                sh = self.make_sharded(alt)
+            except Exception:
+                for m in alt:
+                    m.release()
+                raise
+            return (kind, alt, sh, nnz, slots,
+                    "%d logical shards, the all-gather of shard c under the "
+                    "kernel of c+1" % n)
+        sh = self.make_sharded(self.mats, chunks=4)
+        return (kind, None, sh, self.nnz_local, self.slots,
+                "4 row chunks, the all-gather of chunk c (staged) under the "
+                "kernel of c+1")
+
+    def time_alternative(self, kind, alt, sh_alt, nnz, slots, text):
+        """COLLECTIVE half: 5 + 5 steps, max over ranks (every rank sees the
+        same two numbers, hence takes the same branch); when the alternative
+        wins by the margin, exactly K steps of it are timed like the main
+        measurement -> `value_best`.  The plain arrangement stays `value`."""
+        for s_ in (self.sharded, sh_alt):
+            s_.step()
+        t_plain = self.time_steps(self.sharded, 5)
+        t_alt = self.time_steps(sh_alt, 5)
+        rec = {"plain_ms_per_step": round(t_plain, 5),
+               "alternative": text, "alternative_kind": kind,
+               "alternative_ms_per_step": round(t_alt, 5),
+               "margin": ARRANGEMENT_MARGIN, "winner": "plain"}
+        if t_alt < ARRANGEMENT_MARGIN * t_plain:
+            wall, kern, _ = self.timed_steps(sh_alt)
+            ms = self.max_over_ranks(wall) * 1e3 / self.args.steps
+            rec.update(winner=kind, best_ms_per_step=round(ms, 5),
+                       best_kernel_ms_avg=round(float(self.np.mean(kern)), 5),
+                       best_exchange=sh_alt.mode)
+        return rec
+
+    def release_alternative(self, built=None):
+        if built and built[1]:
+            for m in built[1]:
+                m.release()
 
     # ------------------------------------------------------ check and timing
     def check_result(self):
@@ -373,14 +375,25 @@ class RankJob:
                     extra.append(np.array([lo, (lo + hi) // 2, hi - 1]))
             rows = np.concatenate([rows] + extra)
         got = self.y[torch.as_tensor(rows, device=self.dev)].cpu().numpy()
-        self.checked = check_rows(self.S, self.kind, self.Nglob, self.K, self.W,
-                                  got, rows)
+        # a rank whose rows are wrong must not leave the others waiting in
+        # the next barrier: the ranks agree, then ALL of them stop
+        err = None
+        try:
+            self.checked = check_rows(self.S, self.kind, self.Nglob, self.K,
+                                      self.W, got, rows)
+        except SystemExit as e:
+            err = e
+        bad = self.legs.ranks_where(err is not None)
+        if bad:
+            raise SystemExit("parity check failed on rank(s) %s%s" % (
+                bad, ": %s" % (err,) if err is not None else ""))
 
-    def timed_steps(self):
+    def timed_steps(self, sh=None):
         """K steps between barrier + synchronize on both sides; per-step
         events on the launch stream and host timestamps after each enqueue.
         -> (wall seconds, kernel ms per step, host seconds between enqueues)"""
         torch, n = self.torch, self.args.steps
+        sh = self.sharded if sh is None else sh
         ev = [(torch.cuda.Event(enable_timing=True),
                torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         stamps = [0.0] * (n + 1)
@@ -388,7 +401,7 @@ class RankJob:
         t0 = time.perf_counter()
         stamps[0] = t0
         for k in range(n):
-            self.sharded.step(events=ev[k])
+            sh.step(events=ev[k])
             stamps[k + 1] = time.perf_counter()
         self.barrier()
         wall = time.perf_counter() - t0
@@ -440,24 +453,28 @@ class RankJob:
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t1) * 1e3 / iters
 
-    def exchange_alternatives(self):
-        """the same fragments by the other ways the library can move them
-        (dist.RaggedExchange on this run's row ranges): grouped send / recv,
-        one broadcast per rank, all-gather padded to the longest fragment +
-        compaction -- so that one scaling run prices every exchange"""
+    def build_exchange_alternatives(self):
+        """LOCAL: the same fragments by the other ways the library can move
+        them (dist.RaggedExchange on this run's row ranges): grouped send /
+        recv, one broadcast per rank, all-gather padded to the longest
+        fragment + compaction -- so that one scaling run prices every
+        exchange"""
         D = self.D
         if self.halo:
-            return None
-        out = {}
-        for mode in ("p2p", "bcast", "padded"):
-            sh = D.ShardedSpmv(self.mats[0], self.kernel, self.rank, self.world,
-                               None, self.x, self.y, chunks=1, mode=mode,
-                               force_exchange=self.args.force_exchange,
-                               starts=[int(v) for v in self.starts]
-                               if self.ragged else _never_even(self.starts),
-                               compute=lambda a, b, out=None: None)
-            out[mode] = round(self.exchange_alone(sh, 5), 5)
-        return out
+            return {}
+        return {mode: D.ShardedSpmv(
+            self.mats[0], self.kernel, self.rank, self.world, None, self.x,
+            self.y, chunks=1, mode=mode,
+            force_exchange=self.args.force_exchange,
+            starts=[int(v) for v in self.starts] if self.ragged
+            else _never_even(self.starts),
+            compute=lambda a, b, out=None: None)
+            for mode in ("p2p", "bcast", "padded")}
+
+    def time_exchange_alternatives(self, shs):
+        """COLLECTIVE: each alternative's exchange alone, ms"""
+        return {mode: round(self.exchange_alone(sh, 5), 5)
+                for mode, sh in shs.items()} or None
 
     def reduce_over_ranks(self):
         torch, dist = self.torch, self.dist
@@ -509,15 +526,14 @@ def run_rank(args, argv, omp_team):
     job = RankJob(args, omp_team)
     S, np, torch, dist = job.S, job.np, job.torch, job.dist
     job.init_process_group()
+    legs = job.legs
     job.define_workload()
 
     # ---- build the shard(s) in HBM (device-side generator + converter) ----
     t_setup = time.time()
     job.alloc_vectors()
     job.mats, job.nnz_local, job.slots = job.build_shards(job.L, job.Mshard)
-    job.arrangement = None
     job.pick_kernel()
-    job.chain_logical_shards()
     if job.blocked:
         for m in job.mats[1:]:  # the tuned shard's schedule and tile height
             if m.panels_info() is None:
@@ -527,7 +543,6 @@ def run_rank(args, argv, omp_team):
     job.sync()
     job.exchange_settings()
     job.sharded = job.make_sharded(job.mats)
-    job.choose_sweep_arrangement()
     mat = job.mats[0]
     pinfo = mat.panels_info() if job.blocked else None
     # kernel launches per step and GPU; the sweep schedule's phase counters
@@ -541,18 +556,11 @@ def run_rank(args, argv, omp_team):
     job.sync()
     t_setup = time.time() - t_setup
 
+    # ---- the main measurement: the PLAIN arrangement, exactly K steps ----
     job.check_result()
     stat1 = cgroup_cpu_stat()
     job.measure()
     kern_ms = job.kern_ms
-
-    # the exchange by itself (kernel only / serial / overlapped)
-    exch_ms = exch_alt = None
-    if job.use_dist:
-        exch_ms = job.optional_leg("exchange_alone", job.exchange_alone)
-        exch_alt = job.optional_leg("exchange_alternatives",
-                                    job.exchange_alternatives)
-
     # what joined, on which cards, and every rank's own kernel time
     rccl = per_rank = None
     if job.use_dist:
@@ -560,63 +568,18 @@ def run_rank(args, argv, omp_team):
                                       job.world, args.backend, kern_ms)
     job.reduce_over_ranks()
 
-    # ---- N > 1: the fixed-problem reading of config 5 (80M x 80M, 8 logical
-    # shards of 10M rows, 8/N per GPU), so that a scaling run can be read
-    # against the ">= 6x y-throughput at 8 GPUs" target: rows/s of the SAME
-    # problem at every N; the 1-GPU denominator is a committed measurement.
-    strong = None
-    if (job.world > 1 and not args.strong and not args.no_strong_leg
-            and 8 % job.world == 0 and args.family == "random"
-            and args.window <= 0 and not job.ragged):
-        strong = job.optional_leg("strong", lambda: strong_leg(job))
-    # ---- N > 1: the nlpkkt160-shaped matrix over the same ranks, even rows
-    # vs nnz-balanced rows (reference csr.c:218-276)
-    kkt = None
-    if job.world > 1 and not args.no_partition_leg:
-        kkt = job.optional_leg("partition_kkt",
-                               lambda: kkt_partition_leg(job, args.kkt_n))
-    # ---- N > 1: the library's OWN multi-GPU path (mgpu.hip), in a child
-    # process once every rank has freed its HBM -- unless a GPU-free parent
-    # of ours does that after the ranks have exited (bench.py orchestrate)
-    native = None
-    want_native = (job.world > 1 and not args.no_native_leg
-                   and not args.strong and args.shards_per_gpu == 1
-                   and not os.environ.get("SPMV_BENCH_PARENT_RUNS_NATIVE"))
-    # everything the line needs from the device is read before the release
-    blocked_desc = {
-        "blocked_schedule": mat.panels_schedule() if job.blocked else None,
-        "blocked_layout": mat.panels_describe() if job.blocked else None,
-        "blocked_pin": mat.panels_pin() if job.blocked else None,
-        "tune_log": (mat.tune_log() or "").splitlines()
-        if job.t_tune is not None and job.t_tune > 1.0 and job.L == 1
-        and job.arrangement is None else None}
-    exchange_mode = job.sharded.mode
-    if want_native:
-        # every rank frees its HBM (barrier inside), the process group goes
-        # away, ranks 1.. exit -- a rank left waiting in an RCCL barrier would
-        # spin a kernel on its GPU under the native child's measurement --
-        # and rank 0, alone, starts the child
-        job.release_everything()
-    if job.use_dist:
-        dist.destroy_process_group()
-    if job.rank != 0:
-        return
-    if want_native:
-        from .native import native_leg
-        native = job.optional_leg(
-            "native_mgpu", lambda: native_leg(args, job.world),
-            start_by=LEG_BUDGET_S + 60, collective=False)
-
     a, world, L, Mshard = args, job.world, job.L, job.Mshard
+    # everything the line needs from the device is read NOW: the line must be
+    # printable from the watchdog thread while the main thread sits in a leg
+    sched_now = mat.panels_schedule() if job.blocked else None
+    blocked_layout = mat.panels_describe() if job.blocked else None
     workload = workload_name(a.family, a.format, job.Mglob // world * 1,
                              job.Nglob, job.Mglob, job.K, a.window, job.W, L,
                              Mshard)
-    sched_now = blocked_desc["blocked_schedule"]
     traffic, why = (measured_traffic(workload, kname, sched_now) if world == 1
                     else (None, "single-GPU profiles only"))
     roof = roofline_dict(alg_bytes, kern_ms, kname, job.nnz_local, traffic, why)
-    if roof["traffic_layout"] and \
-            roof["traffic_layout"] == blocked_desc["blocked_layout"]:
+    if roof["traffic_layout"] and roof["traffic_layout"] == blocked_layout:
         roof["traffic_layout"] = "same as config.blocked_layout"
     if per_rank:  # rank 0's events above; every rank's mean here
         roof["kernel_ms_per_rank"] = [round(v, 5) for v in per_rank]
@@ -652,11 +615,18 @@ def run_rank(args, argv, omp_team):
             if job.tuned is not None else "fixed by --kernel",
             # host seconds the selector took; its phase log when that is > 1 s
             "tune_s": round(job.t_tune, 2) if job.t_tune is not None else None,
-            "tune_log": blocked_desc["tune_log"],
+            "tune_log": (mat.tune_log() or "").splitlines()
+            if job.t_tune is not None and job.t_tune > 1.0 and job.L == 1
+            else None,
             "blocked_schedule": sched_now,
-            "blocked_layout": blocked_desc["blocked_layout"],
+            "blocked_layout": blocked_layout,
             # what --blocked-pin takes to run this layout again
-            "blocked_pin": blocked_desc["blocked_pin"],
+            "blocked_pin": mat.panels_pin() if job.blocked else None,
+            # y bitwise reproducible from launch to launch?  (the direct
+            # kernels always; the blocked path when its copy was built
+            # deterministic -- the default on sweep layouts)
+            "deterministic": (not job.blocked) or
+            "deterministic" in (blocked_layout or ""),
             "kernel_source": kernel_source_ident(kname),
             "kernel_launches_per_step": launches,
             # sweep schedule: its phase counters are zeroed on the stream
@@ -676,15 +646,23 @@ def run_rank(args, argv, omp_team):
             else "single GPU",
             "row_starts": job.starts if world > 1 and job.ragged else None,
             "nnz_per_rank": job.nnz_per_rank if world > 1 else None,
-            "chunks": job.chunks, "exchange": exchange_mode,
-            "exchange_arrangement": job.arrangement,
-            "exchange_ms_alone": round(exch_ms, 5) if exch_ms else None,
-            "exchange_alternatives_ms": exch_alt,
+            "chunks": job.chunks, "exchange": job.sharded.mode,
+            # the arrangement `value` was measured with; the overlapped ones
+            # are an optional leg (config.arrangements, value_best)
+            "exchange_arrangement": (
+                "plain: every rank's kernel, then ONE exchange of y"
+                if job.use_dist and job.chunks == 1 and L == 1 else
+                "as asked for: %d row chunks / %d logical shards per GPU, the "
+                "exchange of one under the kernel of the next"
+                % (job.chunks, L) if job.use_dist else None),
+            "arrangements": None,
+            "exchange_ms_alone": None,
+            "exchange_alternatives_ms": None,
             "rccl": rccl,
             "halo_rows": job.halo or None,
             "rows_per_s": round(job.Mglob / (ms_per_step * 1e-3), 1),
-            "strong": strong,
-            "partition_kkt": kkt,
+            "strong": None,
+            "partition_kkt": None,
             "rocm": S.rocm_runtime_report(),
         },
         "roofline": roof,
@@ -704,41 +682,196 @@ def run_rank(args, argv, omp_team):
         "setup_s": round(t_setup, 2),
         "rows_checked": job.checked,
     }
-    if world > 1 and per_rank:
-        # y-throughput (global rows per second) kernel only, kernel
-        # + exchange one after the other, and as measured (the arrangement
-        # that ran overlaps what it can)
-        kmax = max(per_rank)
-        out["config"]["y_rows_per_s"] = {
-            "kernel_only": round(job.Mglob / (kmax * 1e-3), 1),
-            "kernel_then_exchange": round(
-                job.Mglob / ((kmax + exch_ms) * 1e-3), 1) if exch_ms else None,
-            "measured": round(job.Mglob / (ms_per_step * 1e-3), 1)}
-    if world > 1:
-        out["native"] = native
-        out["legs_failed"] = job.legs.failed
-        out["legs_skipped"] = job.legs.skipped
-        out["legs_s"] = job.legs.seconds
     if job.retried:
         out["host_stall_retry"] = True
-    # the >= 6x target is a FIXED-problem reading (80M x 80M on N GPUs vs 1):
-    # top level, so a scaling run can be read without digging
-    out["strong_speedup"] = strong_speedup_of(out, strong, world)
+    if out["config"]["rocm"].get("mismatch"):
+        out["rocm_mismatch"] = True
     single = world == 1 and L == 1 and not a.force_exchange
+
+    # ---- which optional legs this run will attempt, in order ----
+    plan = []
+    if job.use_dist:
+        plan += ["exchange_alone", "exchange_alternatives"]
+        if job.alternative_kind() and not a.no_arrangement_choice:
+            plan.append("arrangement")
+    want_strong = (world > 1 and not a.strong and not a.no_strong_leg
+                   and 8 % world == 0 and a.family == "random"
+                   and a.window <= 0 and not job.ragged)
+    if want_strong:
+        plan.append("strong")
+    if world > 1 and not a.no_partition_leg:
+        plan.append("partition_kkt")
+    # the library's OWN multi-GPU path (mgpu.hip), in a child process once
+    # every rank has freed its HBM -- unless a GPU-free parent of ours does
+    # that after the ranks have exited (bench.py orchestrate)
+    want_native = (world > 1 and not a.no_native_leg
+                   and not a.strong and a.shards_per_gpu == 1
+                   and not os.environ.get("SPMV_BENCH_PARENT_RUNS_NATIVE"))
+    if want_native:
+        plan.append("native_mgpu")
     if (single and not a.no_extras and a.family == "random"
             and a.window <= 0 and a.format == "hll"):
-        roof["variants"] = window_variants(S, torch, job.x, job.y, job.Mloc,
-                                           job.Nglob, job.K, a.family)
+        plan.append("variants")
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(
+        plan.append("cpu_baseline")
+    if single and not a.no_extras:
+        plan.append("extras")
+    legs.announce(plan)
+
+    def current_line(provisional=False):
+        """the line as it stands (callable from the watchdog thread)"""
+        with legs.lock:
+            line = json.loads(json.dumps(out))  # a snapshot
+            if world > 1 or legs.failed or legs.skipped:
+                line.setdefault("native", None)
+                line["legs_failed"] = list(legs.failed)
+                line["legs_skipped"] = list(legs.skipped)
+                line["legs_s"] = dict(legs.seconds)
+            if world > 1 and per_rank:
+                # SURVEY 8d: y-throughput (global rows per second) kernel
+                # only, kernel + exchange one after the other, as measured
+                # (the plain arrangement) and the best arrangement timed
+                kmax = max(per_rank)
+                exch = line["config"]["exchange_ms_alone"]
+                best = line.get("ms_per_step_best")
+                line["config"]["y_rows_per_s"] = {
+                    "kernel_only": round(job.Mglob / (kmax * 1e-3), 1),
+                    "kernel_then_exchange": round(
+                        job.Mglob / ((kmax + exch) * 1e-3), 1) if exch else None,
+                    "measured": round(job.Mglob / (ms_per_step * 1e-3), 1),
+                    "best_arrangement": round(job.Mglob / (best * 1e-3), 1)
+                    if best else None}
+            # the >= 6x target is a FIXED-problem reading (80M x 80M on N
+            # GPUs vs 1): top level, so a scaling run reads without digging
+            line["strong_speedup"] = strong_speedup_of(
+                line, line["config"]["strong"], world)
+            if line.get("ms_per_step_best") and line["strong_speedup"] and \
+                    not (line["config"]["strong"] or {}).get("speedup_vs_1gpu"):
+                line["strong_speedup_best"] = round(
+                    line["strong_speedup"] * line["ms_per_step"]
+                    / line["ms_per_step_best"], 3)
+            if provisional:
+                line["provisional"] = True
+                line["legs_pending"] = list(legs.pending)
+            return line
+
+    def emit(provisional=False):
+        print(json.dumps(current_line(provisional)), flush=True)
+
+    # ---- the line goes out NOW; whatever happens in a leg, it stands ----
+    legs.emit_final = emit
+    if job.rank == 0:
+        emit(provisional=True)
+    if job.use_dist:
+        legs.start_watchdog()
+
+    def note(key, value, where=None):
+        with legs.lock:
+            (out["config"] if where is None else where)[key] = value
+
+    # ---- legs with collectives -------------------------------------------
+    if job.use_dist:
+        # the exchange by itself (SURVEY 8d: kernel only / serial / overlapped)
+        v = legs.run("exchange_alone", job.exchange_alone)
+        note("exchange_ms_alone", round(v, 5) if v else None)
+        v = legs.run("exchange_alternatives", job.time_exchange_alternatives,
+                     prepare=[job.build_exchange_alternatives])
+        note("exchange_alternatives_ms", v)
+    if "arrangement" in plan:
+        built = []
+
+        def build():
+            built.append(job.build_alternative())
+            return built[0]
+        rec = legs.run("arrangement", lambda b: job.time_alternative(*b),
+                       prepare=[build],
+                       cleanup=lambda *_: job.release_alternative(
+                           built[0] if built else None))
+        note("arrangements", rec)
+        if rec:
+            with legs.lock:
+                best = rec.get("best_ms_per_step") or ms_per_step
+                out["ms_per_step_best"] = round(best, 5)
+                out["value_best"] = round(
+                    2.0 * job.nnz_global / (best * 1e6), 2)
+                out["best_arrangement"] = (
+                    rec["alternative"] if rec["winner"] != "plain" else
+                    "plain (the alternative -- %s -- did not win by %.0f %%)"
+                    % (rec["alternative"], 100 * (1 - ARRANGEMENT_MARGIN)))
+    # ---- N > 1: the fixed-problem reading of config 5 (80M x 80M, 8 logical
+    # shards of 10M rows, 8/N per GPU), so that a scaling run can be read
+    # against the ">= 6x y-throughput at 8 GPUs" target: rows/s of the SAME
+    # problem at every N; the 1-GPU denominator is a committed measurement.
+    if want_strong:
+        st = StrongLeg(job)
+        note("strong", legs.run("strong", st.run, prepare=[st.build],
+                                cleanup=lambda *_: st.release()))
+    # ---- N > 1: the nlpkkt160-shaped matrix over the same ranks, even rows
+    # vs nnz-balanced rows (SURVEY 8e; reference csr.c:218-276)
+    if "partition_kkt" in plan:
+        kk = KktLeg(job, a.kkt_n)
+        note("partition_kkt", legs.run(
+            "partition_kkt", kk.run, prepare=[kk.make_file, kk.load],
+            cleanup=lambda *_: kk.release(), limit_s=90.0))
+
+    # ---- the ranks part ----------------------------------------------------
+    if want_native and not legs.broken:
+        # every rank frees its HBM (barrier inside), the process group goes
+        # away, ranks 1.. exit -- a rank left waiting in an RCCL barrier would
+        # spin a kernel on its GPU under the native child's measurement --
+        # and rank 0, alone, starts the child
+        legs.run("release_for_native", job.release_everything, limit_s=30.0)
+    if job.use_dist and not legs.broken:
+        legs._current = ("destroy_process_group", time.time(), 30.0)
+        try:
+            dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001 - the line matters, not this
+            legs.failed.append("destroy_process_group: %r" % (e,))
+        legs._current = None
+    if job.rank != 0:
+        legs.finished = True
+        if legs.broken:
+            os._exit(0)  # a dead peer: leave without the runtime's teardown
+        return
+    if want_native:
+        from .native import native_leg
+        remaining = legs.deadline_s - legs.spent() - 15.0
+        nat = None
+        if remaining > 25.0:
+            nat = legs.run(
+                "native_mgpu",
+                lambda: native_leg(args, job.world,
+                                   timeout_s=max(20.0, min(180.0, remaining))),
+                start_by=LEG_BUDGET_S + 30, collective=False,
+                limit_s=max(30.0, min(190.0, remaining + 5.0)))
+        else:
+            legs.skipped.append("native_mgpu (%.0f s of the run's budget left)"
+                                % remaining)
+        note("native", nat, out)
+    elif world > 1:
+        note("native", None, out)
+
+    # ---- single GPU: what rides on the line (no collectives) ---------------
+    if "variants" in plan:
+        v = legs.run("variants", lambda: window_variants(
+            S, torch, job.x, job.y, job.Mloc, job.Nglob, job.K, a.family),
+            collective=False, start_by=1e9, limit_s=1e9)
+        note("variants", v, roof)
+    if "cpu_baseline" in plan:
+        v = legs.run("cpu_baseline", lambda: cpu_baseline(
             S, job.kind, job.Mloc, job.Nglob, job.K, job.W,
             a.cpu_csv_dir or os.path.join(ROOT, "gpurun_out", "cpu_baseline"),
-            "%s%dM" % (a.family, job.Mloc // 1_000_000))
-    if single and not a.no_extras:
-        out["extras"] = extra_measurements(S, torch, mat, job.x, job.y,
-                                           job.Mloc, job.Nglob, job.K)
-    print(json.dumps(out))
-    sys.stdout.flush()
+            "%s%dM" % (a.family, job.Mloc // 1_000_000)),
+            collective=False, start_by=1e9, limit_s=1e9)
+        note("cpu_baseline", v, out)
+    if "extras" in plan:
+        v = legs.run("extras", lambda: extra_measurements(
+            S, torch, mat, job.x, job.y, job.Mloc, job.Nglob, job.K),
+            collective=False, start_by=1e9, limit_s=1e9)
+        note("extras", v, out)
+    legs.finish()
+    if legs.broken:
+        os._exit(0)
 
 
 def describe_job(S, torch, dist, dev, local_rank, world, backend, kern_ms):
@@ -777,89 +910,123 @@ def describe_job(S, torch, dist, dev, local_rank, world, backend, kern_ms):
             [float(v) for v in allk.tolist()])
 
 
-def strong_leg(job):
+class StrongLeg:
     """The fixed 80M x 80M problem at this N: 8/N logical shards of 10M rows
     per GPU with global columns, built with rank 0's pick.  At N = 8 this IS
-    the weak-scaling workload (one shard per GPU), so nothing is rebuilt."""
-    args, S, torch = job.args, job.S, job.torch
-    rows, total = args.rows_per_gpu, 8 * args.rows_per_gpu
-    # the committed denominator is the FULL-size problem's
-    one_ms, one_src = (strong_one_gpu() if rows == ROWS_PER_GPU else
-                       (None, "not the 10M-rows-per-shard problem"))
-    if job.world == 8 and job.Mglob == total:
-        return {"problem": "80M x 80M, 8 shards of 10M rows: identical to "
-                           "this line's workload at N = 8",
-                "one_gpu_ms_per_step": one_ms,
-                "one_gpu_source": one_src,
-                "note": "speedup vs 1 GPU = one_gpu_ms_per_step / "
-                        "ms_per_step of this line"}
-    per = 8 // job.world
-    xs = torch.empty(total, dtype=torch.float64, device=job.dev)
-    ys = torch.zeros(total, dtype=torch.float64, device=job.dev)
-    S.dev_fill_synth(xs.data_ptr(), total, X_SEED, 0, job.stream())
-    ms_, _, _ = job.build_shards(per, rows, job.rank * per * rows, total,
-                                 2 * total)
-    try:
+    the weak-scaling workload (one shard per GPU), so nothing is rebuilt.
+    build() is local, run() holds the collectives (benchlib.legs)."""
+
+    def __init__(self, job):
+        self.job, self.ms_, self.xs, self.ys, self.sh = job, [], None, None, None
+        rows = job.args.rows_per_gpu
+        self.rows, self.total = rows, 8 * rows
+        # the committed denominator is the FULL-size problem's
+        self.one_ms, self.one_src = (
+            strong_one_gpu() if rows == ROWS_PER_GPU else
+            (None, "not the 10M-rows-per-shard problem"))
+        self.same = job.world == 8 and job.Mglob == self.total
+        self.per = 8 // job.world
+
+    def build(self):
+        if self.same:
+            return None
+        job, S, torch = self.job, self.job.S, self.job.torch
+        self.xs = torch.empty(self.total, dtype=torch.float64, device=job.dev)
+        self.ys = torch.zeros(self.total, dtype=torch.float64, device=job.dev)
+        S.dev_fill_synth(self.xs.data_ptr(), self.total, X_SEED, 0,
+                         job.stream())
+        self.ms_, _, _ = job.build_shards(
+            self.per, self.rows, job.rank * self.per * self.rows, self.total,
+            2 * self.total)
         if job.blocked:
-            for m in ms_:
+            for m in self.ms_:
                 m.build_panels_like(job.mats[0])
-        sh = job.make_sharded(ms_, per * rows, xs, ys)
-        sh.step()
-        ms = job.time_steps(sh, 5)
-    finally:
-        for m in ms_:
+        self.sh = job.make_sharded(self.ms_, self.per * self.rows, self.xs,
+                                   self.ys)
+        return None
+
+    def run(self, _=None):
+        if self.same:
+            return {"problem": "80M x 80M, 8 shards of 10M rows: identical to "
+                               "this line's workload at N = 8",
+                    "one_gpu_ms_per_step": self.one_ms,
+                    "one_gpu_source": self.one_src,
+                    "note": "speedup vs 1 GPU = one_gpu_ms_per_step / "
+                            "ms_per_step of this line"}
+        self.sh.step()
+        ms = self.job.time_steps(self.sh, 5)
+        return {"problem": "80M x 80M fixed, %d logical shards of 10M rows "
+                           "per GPU" % self.per,
+                "ms_per_step": round(ms, 4),
+                "rows_per_s": round(self.total / (ms * 1e-3), 1),
+                "one_gpu_ms_per_step": self.one_ms,
+                "one_gpu_source": self.one_src,
+                "speedup_vs_1gpu": round(self.one_ms / ms, 3)
+                if self.one_ms else None}
+
+    def release(self):
+        for m in self.ms_:
             m.release()
-        del xs, ys
-    return {"problem": "80M x 80M fixed, %d logical shards of 10M rows "
-                       "per GPU" % per,
-            "ms_per_step": round(ms, 4),
-            "rows_per_s": round(total / (ms * 1e-3), 1),
-            "one_gpu_ms_per_step": one_ms, "one_gpu_source": one_src,
-            "speedup_vs_1gpu": round(one_ms / ms, 3) if one_ms else None}
+        self.ms_, self.sh, self.xs, self.ys = [], None, None, None
 
 
 # ------------------------------------------------- a host matrix over N ranks
-def load_matrix_on_every_rank(job, mtx, kkt_n):
-    """BASELINE config 4's input on every rank: rank 0 makes sure the file
-    and its .bin sidecar exist (writes / parses once), the others then load
-    the sidecar.  -> (sparse_csr pointer, info)"""
-    S = job.S
-    info = {}
-    if job.rank == 0:
-        path, info = config4_file(mtx, kkt_n)
-        S.csr_free(S.io_load_csr_cached(path))  # writes the sidecar
-    job.barrier()
-    path, info2 = config4_file(mtx, kkt_n)
-    t0 = time.time()
-    A = S.io_load_csr_cached(path)
-    info = dict(info2, **info)
-    info["load_s"] = round(time.time() - t0, 2)
-    return A, info
-
-
-def partitioned_matrix_run(job, A, partition, xchg, steps, kernel=None):
+class PartitionedRun:
     """rows of host matrix A over the ranks (even / nnz), CSR shards, one
-    kernel for all (rank 0's measured pick unless given), `steps` timed steps
-    -> dict with per-rank rows / entries / kernel ms, ms_per_step, exchange"""
-    S, D, torch, np = job.S, job.D, job.torch, job.np
-    world, rank = job.world, job.rank
-    M, N = A.contents.M, A.contents.N
-    IRP, _, _ = S.csr_arrays(A)
-    starts = (D.nnz_row_partition(IRP, world) if partition == "nnz"
-              else D.even_row_partition(M, world))
-    per_nnz, balance = D.partition_balance(IRP, starts)
-    ragged = partition == "nnz"  # handled as ragged even if the cut is even
-    sl = S.csr_row_slice(A, starts[rank], starts[rank + 1])
-    dA = S.CsrDevice.upload(sl)
-    S.csr_free(sl)
-    x = torch.from_numpy(S.vec_random(N)).to(job.dev)  # the reference's x
-    # even partition: y padded to equal fragments for the in-place all-gather
-    y = torch.zeros(M if ragged else starts[1] * world, dtype=torch.float64,
-                    device=job.dev)
-    try:
+    kernel for all (rank 0's measured pick unless given).  prepare() is LOCAL
+    (slice, upload, x, y, the selector); run(steps) holds the collectives ->
+    dict with per-rank rows / entries / kernel ms, ms_per_step, exchange."""
+
+    def __init__(self, job, A, partition, xchg, kernel=None):
+        S, D = job.S, job.D
+        self.job, self.A, self.xchg, self.kernel = job, A, xchg, kernel
+        self.M, self.N = A.contents.M, A.contents.N
+        self.IRP, _, _ = S.csr_arrays(A)
+        self.starts = (D.nnz_row_partition(self.IRP, job.world)
+                       if partition == "nnz"
+                       else D.even_row_partition(self.M, job.world))
+        self.per_nnz, self.balance = D.partition_balance(self.IRP, self.starts)
+        # handled as ragged even if the cut happens to be even
+        self.ragged = partition == "nnz"
+        self.dA = self.x = self.y = None
+        self.tuned = None
+
+    def prepare(self):
+        job, S, torch = self.job, self.job.S, self.job.torch
+        st, rank = self.starts, job.rank
+        sl = S.csr_row_slice(self.A, st[rank], st[rank + 1])
+        try:
+            self.dA = S.CsrDevice.upload(sl)
+        finally:
+            S.csr_free(sl)
+        # the reference's x
+        self.x = torch.from_numpy(S.vec_random(self.N)).to(job.dev)
+        # even partition: y padded to equal fragments for the in-place gather
+        self.y = torch.zeros(self.M if self.ragged else st[1] * job.world,
+                             dtype=torch.float64, device=job.dev)
+        if self.kernel is None:
+            self.tuned, _ = self.dA.autotune(
+                self.x.data_ptr(), self.y.data_ptr() + 8 * st[rank])
+        return self
+
+    def run(self, steps):
+        job, S, D, torch, np = (self.job, self.job.S, self.job.D,
+                                self.job.torch, self.job.np)
+        world, rank, dA, st = job.world, job.rank, self.dA, self.starts
+        kernel = self.kernel
+
+        def build():  # LOCAL work inside the collective half: agreed on
+            if kernel == S.CSR_KERNEL_PANELS and dA.panels_info() is None:
+                dA.build_panels(0)
+            if self.ragged:
+                return D.ShardedSpmv(dA, kernel, rank, world, None, self.x,
+                                     self.y, chunks=1, mode=self.xchg,
+                                     starts=st)
+            return D.ShardedSpmv(dA, kernel, rank, world, st[1], self.x,
+                                 self.y, chunks=1)
+
         if kernel is None:
-            kernel, _ = dA.autotune(x.data_ptr(),
-                                    y.data_ptr() + 8 * starts[rank])
+            kernel = self.tuned
             if job.use_dist:
                 mine = D.Pick(kernel, dA.panels_schedule(),
                               dA.panels_tile_rows() or 0)
@@ -867,30 +1034,29 @@ def partitioned_matrix_run(job, A, partition, xchg, steps, kernel=None):
                 kernel = pick.kernel
                 if (kernel == S.CSR_KERNEL_PANELS
                         and not pick.same_build(mine)):
-                    dA.build_panels(0, pick.schedule, pick.tile_rows)
-        if kernel == S.CSR_KERNEL_PANELS and dA.panels_info() is None:
-            dA.build_panels(0)
-        if ragged:
-            sh = D.ShardedSpmv(dA, kernel, rank, world, None, x, y, chunks=1,
-                               mode=xchg, starts=starts)
-        else:
-            sh = D.ShardedSpmv(dA, kernel, rank, world, starts[1], x, y,
-                               chunks=1)
+                    together(job, lambda: dA.build_panels(
+                        0, pick.schedule, pick.tile_rows))
+        self.kernel = kernel
+        sh = together(job, build)
         yy = sh.y
         sh.step()
         job.sync()
-        # own rows and rows of every other rank against the HOST matrix
-        rng = np.random.default_rng(77 + rank)
-        rows = rng.integers(0, M, 64)
-        got = yy[torch.as_tensor(rows, device=job.dev)].cpu().numpy()
-        _, JA, AS = S.csr_arrays(A)
-        xh = x.cpu().numpy()
-        for g, r in zip(got, rows):
-            c, v = JA[IRP[r]:IRP[r + 1]], AS[IRP[r]:IRP[r + 1]]
-            t = v * xh[c]
-            if abs(g - t.sum()) > 1e-6 * max(abs(t.sum()),
-                                             1e-3 * np.abs(t).sum()):
-                raise RuntimeError("parity check failed on row %d" % r)
+
+        def check():  # own rows and rows of every other rank vs the HOST matrix
+            rng = np.random.default_rng(77 + rank)
+            rows = rng.integers(0, self.M, 64)
+            got = yy[torch.as_tensor(rows, device=job.dev)].cpu().numpy()
+            _, JA, AS = S.csr_arrays(self.A)
+            xh = self.x.cpu().numpy()
+            for g, r in zip(got, rows):
+                c = JA[self.IRP[r]:self.IRP[r + 1]]
+                v = AS[self.IRP[r]:self.IRP[r + 1]]
+                t = v * xh[c]
+                if abs(g - t.sum()) > 1e-6 * max(abs(t.sum()),
+                                                 1e-3 * np.abs(t).sum()):
+                    raise RuntimeError("parity check failed on row %d" % r)
+            return len(rows)
+        nrows = together(job, check)
         ev = [(torch.cuda.Event(enable_timing=True),
                torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         job.barrier()
@@ -902,15 +1068,19 @@ def partitioned_matrix_run(job, A, partition, xchg, steps, kernel=None):
         kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         allk = torch.zeros(world, dtype=torch.float64, device=job.dev)
         if job.use_dist:
-            job.dist.all_gather_into_tensor(
-                allk, torch.tensor([kms], dtype=torch.float64, device=job.dev))
+            mine = torch.tensor([kms], dtype=torch.float64, device=job.dev)
+            if job.args.backend == "gloo":  # rehearsal: host-staged
+                host = torch.zeros(world, dtype=torch.float64)
+                job.dist.all_gather_into_tensor(host, mine.cpu())
+                allk = host
+            else:
+                job.dist.all_gather_into_tensor(allk, mine)
         else:
             allk[0] = kms
         exch = job.exchange_alone(sh, 5) if job.use_dist else None
-        return {"rows_per_rank": [starts[k + 1] - starts[k]
-                                  for k in range(world)],
-                "nnz_per_rank": per_nnz,
-                "nnz_max_over_min": round(balance, 3),
+        return {"rows_per_rank": [st[k + 1] - st[k] for k in range(world)],
+                "nnz_per_rank": self.per_nnz,
+                "nnz_max_over_min": round(self.balance, 3),
                 "kernel": "csr_" + S.CSR_KERNEL_LABELS[kernel],
                 "kernel_ms_per_rank": [round(float(v), 5)
                                        for v in allk.tolist()],
@@ -918,31 +1088,88 @@ def partitioned_matrix_run(job, A, partition, xchg, steps, kernel=None):
                 "exchange": sh.mode,
                 "exchange_ms_alone": round(exch, 5) if exch else None,
                 "alg_bytes": dA.algorithmic_bytes,
-                "rows_checked": len(rows)}, kernel
-    finally:
-        dA.release()
-        del x, y
+                "rows_checked": nrows}
+
+    def release(self):
+        if self.dA is not None:
+            self.dA.release()
+        self.dA = self.x = self.y = None
 
 
-def kkt_partition_leg(job, kkt_n):
+def together(job, fn):
+    """LOCAL work in the middle of a collective sequence: run fn() here, then
+    let the ranks agree -- if it failed anywhere, EVERY rank raises (and so
+    leaves the sequence at the same point) instead of one rank leaving the
+    others inside the next collective"""
+    err = res = None
+    try:
+        res = fn()
+    except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
+        err = e
+    bad = job.legs.ranks_where(err is not None)
+    if bad:
+        raise RuntimeError("failed on rank(s) %s%s" % (
+            bad, ": %r" % (err,) if err is not None else ""))
+    return res
+
+
+class KktLeg:
     """config.partition_kkt: the nlpkkt160-shaped matrix (42 entries per
     state row in the upper half, 15 per constraint row below) over this
     run's ranks, equal ROWS vs near-equal ENTRIES per GPU -- per-rank
-    entries, per-rank kernel ms, ms per step of each"""
-    A, info = load_matrix_on_every_rank(job, "", kkt_n)
-    try:
-        even, kernel = partitioned_matrix_run(job, A, "even", "p2p", 5)
-        nnz, _ = partitioned_matrix_run(job, A, "nnz",
-                                        job.args.ragged_exchange, 5, kernel)
-        for d in (even, nnz):
+    entries, per-rank kernel ms, ms per step of each.  make_file / load are
+    local (benchlib.legs prepare steps), run holds the collectives."""
+
+    def __init__(self, job, kkt_n, mtx=""):
+        self.job, self.kkt_n, self.mtx = job, kkt_n, mtx
+        self.A, self.info, self.runs = None, {}, []
+
+    def make_file(self):
+        """rank 0 makes sure the file and its .bin sidecar exist (writes /
+        parses once); the others load the sidecar afterwards"""
+        if self.job.rank == 0:
+            S = self.job.S
+            path, self.info = config4_file(self.mtx, self.kkt_n)
+            S.csr_free(S.io_load_csr_cached(path))  # writes the sidecar
+        return None
+
+    def load(self, _=None):
+        S = self.job.S
+        path, info2 = config4_file(self.mtx, self.kkt_n)
+        t0 = time.time()
+        self.A = S.io_load_csr_cached(path)
+        self.info = dict(info2, **self.info)
+        self.info["load_s"] = round(time.time() - t0, 2)
+        return None
+
+    def run(self, *_):
+        job, A = self.job, self.A
+        even = PartitionedRun(job, A, "even", "p2p")
+        self.runs.append(even)
+        together(job, even.prepare)
+        r_even = even.run(5)
+        even.release()
+        nnz = PartitionedRun(job, A, "nnz", job.args.ragged_exchange,
+                             even.kernel)
+        self.runs.append(nnz)
+        together(job, nnz.prepare)
+        r_nnz = nnz.run(5)
+        for d in (r_even, r_nnz):
             d.pop("alg_bytes", None)
         return {"matrix": "%dx%d, %d entries (%s)" % (
-                    A.contents.M, A.contents.N, A.contents.NZ, info["source"]),
-                "even_rows": even, "nnz_balanced": nnz,
+                    A.contents.M, A.contents.N, A.contents.NZ,
+                    self.info["source"]),
+                "even_rows": r_even, "nnz_balanced": r_nnz,
                 "speedup_nnz_over_even": round(
-                    even["ms_per_step"] / nnz["ms_per_step"], 3)}
-    finally:
-        job.S.csr_free(A)
+                    r_even["ms_per_step"] / r_nnz["ms_per_step"], 3)}
+
+    def release(self):
+        for r in self.runs:
+            r.release()
+        self.runs = []
+        if self.A is not None:
+            self.job.S.csr_free(self.A)
+            self.A = None
 
 
 def run_matrix_rank(args, argv, omp_team):
@@ -957,15 +1184,20 @@ def run_matrix_rank(args, argv, omp_team):
     job = RankJob(args, omp_team)
     job.init_process_group()
     t0 = time.time()
-    A, info = load_matrix_on_every_rank(job, args.mtx, args.kkt_n)
-    res, kernel = partitioned_matrix_run(
-        job, A, args.partition, args.ragged_exchange, args.steps,
-        args.kernel if args.kernel >= 0 else None)
+    kk = KktLeg(job, args.kkt_n, args.mtx)
+    together(job, kk.make_file)
+    together(job, kk.load)
+    A, info = kk.A, kk.info
+    run = PartitionedRun(job, A, args.partition, args.ragged_exchange,
+                         args.kernel if args.kernel >= 0 else None)
+    together(job, run.prepare)
+    res = run.run(args.steps)
+    run.release()
     rccl, _ = describe_job(job.S, job.torch, job.dist, job.dev, job.local_rank,
                            job.world, args.backend, [1.0])
     M, N, NZ = A.contents.M, A.contents.N, A.contents.NZ
     name = A.contents.name.decode()
-    job.S.csr_free(A)
+    kk.release()
     if job.rank == 0:
         kname = res["kernel"]
         alg = res.pop("alg_bytes")

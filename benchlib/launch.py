@@ -67,8 +67,10 @@ def launch_ranks(args, argv, out=None):
     MASTER_* set, rendezvous on 127.0.0.1), relay rank 0's JSON line, exit
     with the worst return code.  The parent never loads a GPU runtime (devices
     are counted by a child, visible_gpus), so nothing that initialised HIP is
-    ever re-executed.  `out`: a text buffer that takes rank 0's stdout instead
-    of this process's stdout (bench.py orchestrate merges into the line)."""
+    ever re-executed.  Rank 0's stdout is passed on AS IT ARRIVES (its
+    provisional line must survive whatever happens later -- to the ranks or to
+    this parent); `out`: a text buffer that receives a copy (bench.py
+    orchestrate merges the native leg into the last line)."""
     n = args.gpus
     if args.backend == "nccl":
         have = visible_gpus()
@@ -97,6 +99,8 @@ def launch_ranks(args, argv, out=None):
             if rd:
                 chunk = os.read(procs[0].stdout.fileno(), 65536)
                 out0 += chunk
+                sys.stdout.write(chunk.decode(errors="replace"))
+                sys.stdout.flush()
         else:
             time.sleep(0.2)
         for r in list(live):
@@ -105,7 +109,10 @@ def launch_ranks(args, argv, out=None):
                 continue
             live.discard(r)
             if r == 0:
-                out0 += procs[0].stdout.read() or b""
+                rest = procs[0].stdout.read() or b""
+                out0 += rest
+                sys.stdout.write(rest.decode(errors="replace"))
+                sys.stdout.flush()
             if rc != 0:
                 worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
                 failed_at = failed_at or time.time()
@@ -115,9 +122,6 @@ def launch_ranks(args, argv, out=None):
                 procs[r].kill()  # exactly the children started above
     if out is not None:
         out.write(out0.decode(errors="replace"))
-    else:
-        sys.stdout.write(out0.decode(errors="replace"))
-        sys.stdout.flush()
     return worst if worst >= 0 else 128 - worst
 
 

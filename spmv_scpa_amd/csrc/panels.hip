@@ -999,6 +999,20 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         grid = cus * per_cu;
         tile_max = sweep_tile_rows_max(per_cu);
         tr = sweep_tile_rows(M, grid, tile_max);
+#ifdef SPMV_ABLATIONS
+        /* round-6 probe (tools/tall_tile_probe.py): a sweep copy with tiles
+         * TALLER than a CU's LDS can hold, launched with variant ablation 5 / 6
+         * (LDS index aliased, y WRONG by design): the L2 request pattern of
+         * accumulators that do not exist yet */
+        if (const char *e = getenv("SPMV_ABL_SWEEP_TILE_ROWS")) {
+            const long long v = atoll(e) / 32 * 32;
+            if (v >= 32 && v < (1 << 20)) {
+                per_cu = 1;
+                grid = cus;
+                tr = v;
+            }
+        }
+#endif
     }
     if (!sweep && tile_rows >= 32 && tile_rows <= tile_max)
         tr = tile_rows / 32 * 32;
@@ -1396,7 +1410,8 @@ template <int Q> struct sweep_chunk {
 
 template <int NT, int Q, int ABL = 0, bool DET = false>
 /* ABL: timing ablations, 1 = no LDS add, 2 = gathers from one 8 KiB window
- * (L1 hits); DET: deterministic mode */
+ * (L1 hits), 8 = tile taller than its LDS slice: row index aliased into 16384
+ * rows (y wrong by design; round-6 tall-tile probe); DET: deterministic mode */
 __global__ void __launch_bounds__(NT)
     k_tiles_sweep(int M, int tile_rows, int tiles, int panels, int shift,
                   int lag, int spin, int stagger, int pmajor, unsigned total,
@@ -1438,7 +1453,8 @@ __global__ void __launch_bounds__(NT)
                     phase_arrive(cnt + (size_t)(q0 + p) * CNT_STRIDE);
             continue;
         }
-        for (int i = tid; i < tile_rows; i += NT)
+        for (int i = tid; i < ((ABL & 8) && tile_rows > 16384 ? 16384 : tile_rows);
+             i += NT)
             ytile[i] = 0.0;
         __syncthreads();
 
@@ -1529,6 +1545,8 @@ __global__ void __launch_bounds__(NT)
                     const unsigned col = 64 * u < on[g] ? (c.en[g][u] & lowmask) : 0u;
                     pr[g][u] = xp[col];
                     rr[g][u] = c.en[g][u] >> shift;
+                    if (ABL & 8)
+                        rr[g][u] &= 16383u;
                 }
                 w[g][0] = c.va[g][0];
                 w[g][1] = c.va[g][1];
@@ -1584,7 +1602,8 @@ __global__ void __launch_bounds__(NT)
         __syncthreads();
         const int64_t row0 = (int64_t)t * tile_rows;
         for (int i = tid; i < tile_rows && row0 + i < M; i += NT)
-            __builtin_nontemporal_store(ytile[i], y + row0 + i);
+            __builtin_nontemporal_store(ytile[(ABL & 8) ? (i & 16383) : i],
+                                        y + row0 + i);
         __syncthreads();
     }
 }
@@ -1924,6 +1943,10 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
 #endif
     (void)hipGetLastError(); /* an earlier caller's unread error is not ours */
     size_t lds = (size_t)P->tile_rows * sizeof(double);
+#ifdef SPMV_ABLATIONS
+    if (P->sweep && lds > (size_t)BIG_LDS_BYTES) /* tall-tile probe: aliased */
+        lds = 16384 * sizeof(double);
+#endif
     if (waves <= 0)
         waves = P->waves_hint;
     if ((size_t)P->lds_min > lds) /* tuning: caps workgroups per CU */
@@ -1967,6 +1990,16 @@ static int panels_launch_tiles(const spmv_panels *P, int M, int waves,
         else if (abl == 3) { SW(256, 1, 3); }
         else if (abl == 4) { SW(256, 1, 4); }
         else if (abl == 7) { SW(256, 1, 7); }
+        else if (abl == 5) { /* tall-tile probe, the production launch shapes */
+            if (waves > 8) SW(1024, 2, 8);
+            else if (waves > 0 && waves < 8) SW(256, 2, 8);
+            else SW(512, 2, 8);
+        }
+        else if (abl == 6) {
+            if (waves > 8) SW(1024, 1, 8);
+            else if (waves > 0 && waves < 8) SW(256, 1, 8);
+            else SW(512, 1, 8);
+        }
         else
 #endif
         if (P->wgs_per_cu == 1) {

@@ -3,10 +3,14 @@ share the card (`--backend gloo`: RCCL refuses duplicate devices, so the y
 fragments are staged through host memory by dist.all_gather_fragments).  The
 timings of such a run mean nothing; what it proves is that every line the
 driver's 2 / 4 / 8-GPU scaling run will execute has run once: rank 0's pick
-broadcast and rebuilt by the other rank, the measured choice between the two
-exchange arrangements of the sweep schedule, logical shards, the fixed
-80M-style problem of `config.strong`, the cross-rank result check (each rank
-verifies rows the OTHER rank computed), nnz summed over ranks.  It also runs
+broadcast and rebuilt by the other rank, the PLAIN arrangement as the line's
+measurement with its provisional line, the overlapped arrangement of each
+kernel class as an optional leg beside it (`config.arrangements`,
+`value_best`), logical shards, the fixed 80M-style problem of
+`config.strong`, the cross-rank result check (each rank verifies rows the
+OTHER rank computed), nnz summed over ranks -- and the fault isolation of the
+legs: a failure injected on rank 1 only, a rank that hangs in a leg, a job
+killed after the main measurement.  It also runs
 two persistent sweep launches on one GPU at the same time -- their grids
 cannot both be resident, the phase waits must expire and the kernels still
 finish (bounded waits: slower, never hung)."""
@@ -23,10 +27,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("extra", [
-    # blocked path, sweep schedule: both exchange arrangements are built and
-    # timed, the faster kept; config.strong = 4 logical shards per rank
+    # blocked path, sweep schedule: the plain arrangement is the line, the
+    # split arrangement an optional leg; config.strong = 4 logical shards
     ["--kernel", "4", "--window", "0"],
-    # autotuned pick on a banded matrix (direct kernel): row chunks, staged
+    # autotuned pick on a banded matrix (direct kernel): row chunks, staged,
+    # as the optional arrangement leg
     ["--kernel", "-1", "--window", "4096"],
     # ragged rows: nnz differs between ranks and is summed, every family's
     # rows are checked through the host generator
@@ -47,8 +52,13 @@ def test_two_ranks_share_one_gpu(extra):
     r = subprocess.run(cmd + extra, capture_output=True, text=True, env=env,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    # the line is printed right after the main measurement and again at the
+    # end; same measurement in both, the last one is the record
+    assert len(lines) >= 2 and lines[0]["provisional"] is True
+    assert lines[0]["value"] == lines[-1]["value"] > 0
+    assert lines[0]["legs_pending"] and "provisional" not in lines[-1]
+    j = lines[-1]
     c = j["config"]
     strong = "--strong" in extra
     assert j["n_gpus"] == 2 and j["value"] > 0
@@ -87,17 +97,29 @@ def test_two_ranks_share_one_gpu(extra):
         alt = c["exchange_alternatives_ms"]
         assert sorted(alt) == ["bcast", "p2p", "padded"], alt
     if strong:
+        # asked for on the command line: 4 logical shards per rank ARE the
+        # main arrangement (shard c all-gathered under the kernel of c+1)
         assert c["logical_shards_per_gpu"] == 4 and c["strong"] is None
         assert c["nnz_global"] == 8 * 320000 * 32 and c["exchange"] == "staged"
+        assert c["arrangements"] is None and "value_best" not in j
         return
+    # the main line is the PLAIN arrangement, whatever the kernel
+    assert c["logical_shards_per_gpu"] == 1 and c["chunks"] == 1
+    assert c["exchange"] == "allgather"
+    assert c["exchange_arrangement"].startswith("plain")
+    arr = c["arrangements"]
+    assert arr["plain_ms_per_step"] > 0 and arr["alternative_ms_per_step"] > 0
+    assert arr["winner"] in ("plain", arr["alternative_kind"])
+    assert j["value_best"] >= j["value"] * 0.999
+    assert j["ms_per_step_best"] <= j["ms_per_step"] * 1.001
+    if arr["winner"] != "plain":
+        assert arr["best_ms_per_step"] == j["ms_per_step_best"]
     if "ragged" in extra:
         assert c["nnz_global"] != 2 * 320000 * 32  # summed, not assumed equal
     else:
         assert c["nnz_global"] == 2 * 320000 * 32
     if extra[:2] == ["--kernel", "4"]:
-        arr = c["exchange_arrangement"]
-        assert "exchange after the kernel" in arr and "overlapped" in arr
-        assert c["logical_shards_per_gpu"] in (1, 2)
+        assert arr["alternative_kind"] == "sweep_split"
         st = c["strong"]
         assert "error" not in st, st
         assert st["ms_per_step"] > 0
@@ -106,13 +128,14 @@ def test_two_ranks_share_one_gpu(extra):
         assert st["speedup_vs_1gpu"] is None and st["one_gpu_source"]
         assert "4 logical shards" in st["problem"]
     else:
-        assert c["exchange"] in ("staged", "allgather")
+        assert arr["alternative_kind"] in ("row_chunks", "logical_shards")
 
 
 def test_four_ranks_share_one_gpu():
-    """the N = 4 line of a scaling run, rehearsed: sweep schedule, both
-    exchange arrangements timed, config.strong = 2 logical shards per rank of
-    the fixed problem, each rank checking rows of the three others"""
+    """the N = 4 line of a scaling run, rehearsed: sweep schedule, the plain
+    arrangement measured and the split one timed beside it, config.strong = 2
+    logical shards per rank of the fixed problem, each rank checking rows of
+    the three others"""
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -130,7 +153,8 @@ def test_four_ranks_share_one_gpu():
     assert len(j["roofline"]["kernel_ms_per_rank"]) == 4
     assert j["rows_checked"] >= 258 + 9  # own rows + 3 of each other rank
     assert c["nnz_global"] == 4 * 320000 * 32
-    assert "exchange after the kernel" in c["exchange_arrangement"]
+    assert c["exchange_arrangement"].startswith("plain")
+    assert c["arrangements"]["alternative_kind"] == "sweep_split"
     st = c["strong"]
     assert "error" not in st and "2 logical shards" in st["problem"], st
     assert st["ms_per_step"] > 0
@@ -212,3 +236,94 @@ def test_under_torchrun_rank0_starts_the_native_child_itself():
     assert set(j["legs_s"]) >= {"exchange_alone", "exchange_alternatives",
                                 "partition_kkt", "native_mgpu"}
     assert j["config"]["partition_kkt"]["speedup_nnz_over_even"] > 0
+
+
+def _bench(extra, env_extra=None, launcher=False, port="29583"):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE",
+                        "SPMV_BENCH_INJECT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(env_extra or {})
+    head = [sys.executable]
+    if launcher:
+        head += ["-m", "torch.distributed.run", "--nnodes=1",
+                 "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", port]
+    cmd = head + [os.path.join(S.ROOT, "bench.py"),
+                  "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                  "--warmup", "1", "--rows-per-gpu", "320000",
+                  "--no-cpu-baseline", "--no-extras", "--kkt-n", "24"] + extra
+    return cmd, env
+
+
+@pytest.mark.parametrize("launcher", [False, True],
+                         ids=["own-ranks", "torchrun"])
+def test_a_failure_on_rank_1_only_inside_the_arrangement_leg(launcher):
+    """rank 1 alone fails while building the alternative
+    arrangement.  Before: rank 0 went on into the leg's collectives and the
+    run ended at the process group's 300 s timeout without a line.  Now: the
+    ranks agree, both skip the leg, every later leg still runs, rc 0, the
+    main line stands and legs_failed names the leg and the rank."""
+    cmd, env = _bench(["--kernel", "4", "--window", "0"],
+                      {"SPMV_BENCH_INJECT": "arrangement:1:prepare"},
+                      launcher)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines[0]["provisional"] is True
+    j = lines[-1]
+    assert j["value"] == lines[0]["value"] > 0 and "provisional" not in j
+    bad = [f for f in j["legs_failed"] if f.startswith("arrangement")]
+    assert len(bad) == 1 and "rank(s) [1]" in bad[0], j["legs_failed"]
+    assert len(j["legs_failed"]) == 1
+    c = j["config"]
+    assert c["arrangements"] is None and "value_best" not in j
+    assert c["exchange_ms_alone"] > 0           # the legs before it ...
+    assert c["strong"]["ms_per_step"] > 0       # ... and after it ran
+    assert c["partition_kkt"]["speedup_nnz_over_even"] > 0
+    assert j["native"]["ms_per_step"] > 0
+
+
+def test_a_rank_that_hangs_inside_a_leg_ends_with_the_line_not_a_timeout():
+    """rank 1 never reaches the collectives of the strong leg: the watchdog
+    ends the run at the leg's limit with rank 0's final line and rc 0"""
+    import time
+    cmd, env = _bench(["--kernel", "4", "--window", "0", "--no-native-leg"],
+                      {"SPMV_BENCH_INJECT": "exchange_alternatives:1:hang",
+                       "SPMV_BENCH_LEG_LIMIT": "20"})
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert time.time() - t0 < 200
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    j = lines[-1]
+    assert j["value"] == lines[0]["value"] > 0 and "provisional" not in j
+    assert any("exchange_alternatives" in f and "limit" in f
+               for f in j["legs_failed"]), j["legs_failed"]
+    assert j["config"]["exchange_ms_alone"] > 0  # the leg before the hang
+
+
+def test_a_job_killed_after_the_main_measurement_has_left_its_line():
+    """the provisional line is on stdout (flushed) before any optional leg
+    starts: kill the whole job while it sits in a leg and parse what is there"""
+    import signal
+    cmd, env = _bench(["--kernel", "4", "--window", "0"],
+                      {"SPMV_BENCH_INJECT":
+                       "exchange_alone:0:hang,exchange_alone:1:hang",
+                       "SPMV_BENCH_LEG_LIMIT": "600"})
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         text=True, env=env, start_new_session=True)
+    try:
+        line = ""
+        while not line.startswith("{"):
+            line = p.stdout.readline()
+            assert line, "bench.py ended without a line"
+        j = json.loads(line)
+        assert j["provisional"] is True and j["value"] > 0
+        assert j["n_gpus"] == 2 and j["roofline"]["frac"] > 0
+        assert "exchange_alone" in j["legs_pending"]
+    finally:
+        os.killpg(p.pid, signal.SIGKILL)  # exactly the session started above
+        p.wait()
