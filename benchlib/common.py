@@ -128,7 +128,9 @@ def parse_args(argv=None):
     ap.add_argument("--chunks", type=int, default=0,
                     help="N>1: split each shard into row chunks and overlap "
                          "the all-gather of chunk c with the kernel of c+1 "
-                         "(0 = auto: 4 when N > 1, else 1)")
+                         "AS THE MAIN ARRANGEMENT (0 = the plain one: whole "
+                         "shard, then one exchange; the chunked form is then "
+                         "an optional leg reported as value_best)")
     ap.add_argument("--shards-per-gpu", type=int, default=1,
                     help="logical shards of --rows-per-gpu rows held by each "
                          "GPU (each its own int32-safe matrix)")
@@ -197,8 +199,11 @@ def parse_args(argv=None):
                     help="N>1: skip `native` (the library's own multi-GPU "
                          "path in a child process after the ranks are done)")
     ap.add_argument("--no-arrangement-choice", action="store_true",
-                    help="--native-mgpu: do not build and time the logical-"
-                         "shard arrangement next to the plain one")
+                    help="N>1: skip the optional leg that builds and times "
+                         "the overlapped arrangement (logical shards / row "
+                         "chunks) beside the plain one (config.arrangements, "
+                         "value_best); the line's `value` is the plain "
+                         "arrangement's either way")
     ap.add_argument("--native-rehearsal", action="store_true",
                     help="--native-mgpu on a REHEARSAL handle: --gpus N "
                          "logical devices on the visible card(s), copies "

@@ -123,7 +123,7 @@ typedef struct spmv_panel_opts {
                              having the library read past it.  ABI: the struct
                              grew in library versions 0.3 (bucket_order),
                              0.4 (this field, first) and 0.5 (deterministic,
-                             last); spmv_version() tells
+                             last; 0.6: its values 0 / 1 / 2); spmv_version() tells
                              which library is loaded.  Fill the struct with
                              spmv_panel_opts_default() and then set fields */
     int sched;            /* -1 process default, 0 steps, 1 sweep, 2 chain */
@@ -158,20 +158,27 @@ typedef struct spmv_panel_opts {
                              neighbouring tiles an XCD runs together sit on
                              at most two panels of x at a time), 1 = always
                              ascending panels */
-    int deterministic;    /* 1: bitwise-reproducible launches (added in 0.5,
-                             last).  By default the wavefronts of a workgroup
-                             add their products into the tile's LDS slice of
-                             y with ds_add_f64 as they come: the ORDER of the
-                             additions to one row, and so the last bits of y,
-                             vary from launch to launch (held to 1e-12 of the
-                             row scale).  With this flag the wavefronts of a
-                             workgroup add chunk by chunk, one wavefront after
-                             the other (an LDS turn counter, no barrier): every
-                             row's additions happen in one fixed order -- the
-                             same bits on every launch of the copy, as the
-                             reference's kernels and the nine direct kernels
-                             give.  Costs time (blocked path);
-                             never picked by spmv_*_autotune */
+    int deterministic;    /* bitwise-reproducible launches (added in 0.5,
+                             last; tri-state since 0.6): 0 = default, 1 = on,
+                             2 = off.  Without it the wavefronts of a
+                             workgroup add their products into the tile's LDS
+                             slice of y with ds_add_f64 as they come: the
+                             ORDER of the additions to one row, and so the
+                             last bits of y, vary from launch to launch (held
+                             to 1e-12 of the row scale).  With it they add
+                             chunk by chunk, one wavefront after the other (an
+                             LDS turn counter, no barrier): every row's
+                             additions happen in one fixed order -- the same
+                             bits on every launch of the copy, as the
+                             reference's kernels (cuda_hll.cu:49-72, csr.c:
+                             201-216) and the nine direct kernels give.
+                             DEFAULT: on for sweep layouts, where it is free
+                             (+-2 %: the hand-offs hide under the
+                             request-bound loop), off for chain / steps
+                             (+9..+31 % there, DESIGN.md: opt-in with 1).
+                             spmv_*_autotune builds its candidates with the
+                             default, so the blocked copy it keeps on a matrix
+                             whose columns reach anywhere is reproducible */
 } spmv_panel_opts;
 
 /* every field at its default (struct_size set, sched -1, sweep_layout -1,

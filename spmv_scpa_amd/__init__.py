@@ -635,7 +635,7 @@ def _pinned_opts(pin):
 
 def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
                 reserve_cus=0, lds_min=0, sweep_layout=None,
-                deterministic=False):
+                deterministic=None):
     o = PanelOpts()
     _lib.spmv_panel_opts_default(C.byref(o))  # struct_size, the -1 defaults
     assert o.struct_size == C.sizeof(PanelOpts), "spmv_panel_opts ABI drift"
@@ -651,7 +651,10 @@ def _panel_opts(panel_cols=0, sched=None, tile_rows=0, sweep_wgs_per_cu=0,
         sweep_layout = int(ev) if ev in ("0", "1") else -1
     o.sweep_layout = sweep_layout
     o.bucket_order = _env_int("SPMV_BUCKET_ORDER", 0, 1)
-    o.deterministic = 1 if deterministic else 0
+    # None: the library's default (on for sweep layouts, off for chain /
+    # steps); True / False: forced on / off (spmv_engine.h: 1 / 2)
+    o.deterministic = 0 if deterministic is None else (1 if deterministic
+                                                       else 2)
     return o
 
 
@@ -1084,7 +1087,7 @@ class CsrDevice:
 
     def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
                      sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0,
-                     sweep_layout=None, deterministic=False):
+                     sweep_layout=None, deterministic=None):
         """blocked copy in the process default schedule, or in an explicit
         one ("steps" / "sweep" / "chain"), with explicit build options
         (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
@@ -1219,7 +1222,7 @@ class HllDevice:
 
     def build_panels(self, panel_cols=0, sched=None, tile_rows=0,
                      sweep_wgs_per_cu=0, reserve_cus=0, lds_min=0,
-                     sweep_layout=None, deterministic=False):
+                     sweep_layout=None, deterministic=None):
         """blocked copy in the process default schedule, or in an explicit
         one ("steps" / "sweep" / "chain"), with explicit build options
         (spmv_panel_opts).  The experiment knobs SPMV_TILE_ROWS,
@@ -1475,7 +1478,7 @@ class MultiGpu:
     def fill_x(self, seed=7):
         _check(_lib.spmv_mgpu_fill_x(self.h, seed), "spmv_mgpu_fill_x")
 
-    def build_panels(self, sched=None, tile_rows=0, deterministic=False):
+    def build_panels(self, sched=None, tile_rows=0, deterministic=None):
         """the blocked copy on every shard (needed before running the blocked
         kernel id without autotune())"""
         o = _panel_opts(0, sched, tile_rows, deterministic=deterministic)

@@ -144,7 +144,7 @@ extern "C" {
 
 /* 0.3: spmv_panel_opts.bucket_order; 0.4: spmv_panel_opts.struct_size (first
  * field), spmv_*_release_checked, handle checks on every entry point */
-const char *spmv_version(void) { return "spmv_scpa_amd 0.5 gfx950"; }
+const char *spmv_version(void) { return "spmv_scpa_amd 0.6 gfx950"; }
 
 /* HIP_VERSION of the headers this library was compiled against, and of the
  * runtime it is bound to now (hipRuntimeGetVersion; needs no device).  The

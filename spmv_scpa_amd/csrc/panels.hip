@@ -952,7 +952,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
         o->reserve_cus < 0 || o->lds_min < 0 || o->lds_min > BIG_LDS_BYTES ||
         o->tile_order < 0 || o->tile_order > 2 || o->sweep_layout < -1 ||
         o->sweep_layout > 1 || o->bucket_order < 0 || o->bucket_order > 1 ||
-        o->deterministic < 0 || o->deterministic > 1)
+        o->deterministic < 0 || o->deterministic > 2)
         return -EINVAL;
     const int panel_cols = o->panel_cols, tile_rows = o->tile_rows;
     int sched = o->sched;
@@ -1046,7 +1046,10 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P->pmajor = sweep && o->sweep_layout != 0;
     P->lds_min = o->lds_min;
     P->bucket_order = o->bucket_order;
-    P->det = o->deterministic != 0;
+    /* 0 = default: ordered additions on sweep layouts (free there: the
+     * hand-offs hide under the request-bound loop, +-2 %), arrival order on
+     * chain / steps (+9..+31 % there); 1 = always, 2 = never */
+    P->det = o->deterministic == 1 || (o->deterministic == 0 && sweep);
     P->order = sweep ? 0 : o->tile_order;
     /* bucket ids: tile-major, or panel-major inside rounds of P->grid tiles */
     const int pm_grid = P->pmajor ? P->grid : 0;
@@ -2212,7 +2215,7 @@ void panels_get_opts(const spmv_panels *P, spmv_panel_opts *o) {
     o->tile_order = P->order;
     o->sweep_layout = P->pmajor;
     o->bucket_order = P->bucket_order;
-    o->deterministic = P->det;
+    o->deterministic = P->det ? 1 : 2; /* explicit: a rebuild repeats it */
 }
 
 /* one-line description of a blocked copy: schedule, geometry, launch shape

@@ -45,8 +45,11 @@ def main():
         pin = dH.panels_pin()
         res = {}
         for det in (0, 1):
-            dH.build_panels_pinned(pin.replace("deterministic=0",
-                                               "deterministic=%d" % det))
+            # spmv_engine.h: 1 = ordered additions, 2 = arrival order
+            import re
+            dH.build_panels_pinned(re.sub(r"deterministic=\d",
+                                          "deterministic=%d" % (1 if det else 2),
+                                          pin))
             ms = np.median(dH.time(S.HLL_KERNEL_PANELS, d_x.ptr, d_y.ptr, 3, 20))
             seen = set()
             for _ in range(20):
