@@ -60,16 +60,32 @@ void set_csr_waves_per_block(int waves);
  *            y downloaded on every call.
  *   level 2  also skips the upload of x when the same x (pointer + sampled
  *            fingerprint) is already on the device.
+ *   level 3  like 2, but the fingerprints are a 64-bit hash of EVERY byte of
+ *            IRP / JA / AS (HLL: of every hack block) and of x, recomputed on
+ *            every call: the level that cannot return a stale result
+ *            whatever was edited in place, at the price of reading the
+ *            matrix once per call on the host (config 2, 212 MB: tens of
+ *            milliseconds single-threaded, a few with the host's cores --
+ *            DESIGN.md has the measured figure; still no PCIe traffic).
  *   level 0  releases what is held (call it before the process exits when
  *            spmv_live_handles() matters to you).
- * THE CALLER PROMISES not to modify a matrix (level 1) or x (level 2) in
- * place between calls in a way the samples miss -- the reference's driver
- * never writes to either (main.c:258-354: 27 calls per matrix on one A, one
- * x).  Results and the returned kernel time are those of the uncached call.
+ * A copy belongs to the HIP device that was current when it was uploaded: a
+ * call made with another device current is a miss (and re-uploads there).
+ * CONTRACT of levels 1 and 2: THE CALLER PROMISES not to modify a matrix
+ * (level 1) or x (level 2) in place between calls in a way the samples miss
+ * -- the reference's driver never writes to either (main.c:258-354: 27 calls
+ * per matrix on one A, one x).  A caller that does edit in place either runs
+ * level 3 or says so: spmv_seam_cache_invalidate(ptr) drops the copy of the
+ * matrix struct `ptr` (sparse_csr* / sparse_hll*), or marks the uploaded x
+ * stale when `ptr` is that x; NULL drops everything held and keeps the
+ * level.  Results and the returned kernel time are those of the uncached
+ * call.
  */
 void spmv_seam_cache(int level);
 /* matrices held now (0..3); *hits / *misses (may be NULL) since start */
 int spmv_seam_cache_stats(long *hits, long *misses);
+/* -> slots touched (see above) */
+int spmv_seam_cache_invalidate(const void *host);
 
 double csr_spmv_hip_thread_row(const sparse_csr *A, const double *x, double *y,
                                void *arg);

@@ -372,6 +372,7 @@ for _n in HLL_KERNEL_NAMES:
     _sig("hll_spmv_hip_" + _n, C.c_double, _HLLp, _dp, _dp, C.c_void_p)
 _sig("spmv_seam_cache", None, C.c_int)
 _sig("spmv_seam_cache_stats", C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long))
+_sig("spmv_seam_cache_invalidate", C.c_int, C.c_void_p)
 _sig("set_csr_waves_per_block", None, C.c_int)
 _sig("set_hll_waves_per_block", None, C.c_int)
 _sig("logger_init", C.c_int, C.c_char_p)
@@ -545,8 +546,24 @@ if os.environ.get("SPMV_DEBUG", "") not in ("", "0"):
 
 def seam_cache(level):
     """opt-in "keep the last upload" behind the one-shot seam (hip_csr.h):
-    0 off (default, releases what is held), 1 matrix, 2 matrix + x"""
+    0 off (default, releases what is held), 1 matrix, 2 matrix + x (sampled
+    fingerprints: the caller promises not to edit in place), 3 matrix + x
+    with a full 64-bit hash of every byte per call (cannot be stale)"""
     _lib.spmv_seam_cache(int(level))
+
+
+def seam_cache_invalidate(obj=None):
+    """drop the cached copy of a matrix (sparse_csr / sparse_hll pointer),
+    mark an uploaded x (numpy array) stale, or -- None -- drop everything
+    held; -> slots touched (hip_csr.h: for callers that edit in place under
+    levels 1 / 2)"""
+    if obj is None:
+        p = None
+    elif isinstance(obj, np.ndarray):
+        p = C.c_void_p(obj.ctypes.data)
+    else:
+        p = C.cast(obj, C.c_void_p)
+    return _lib.spmv_seam_cache_invalidate(p)
 
 
 def seam_cache_stats():

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <time.h>
 #include <unordered_map>
 #include <vector>
@@ -25,6 +26,7 @@
 #include "spmv_synth.h"
 #include "stream_table.h"
 #include "tune_blocked.h"
+#include "utils.h"
 
 /* Process defaults behind set_*_waves_per_block (the reference's seam sets
  * them before every call).  0 = never set: the launch then picks by size --
@@ -1934,6 +1936,10 @@ int spmv_hll_tune_log(const spmv_hll_dev *H, char *buf, size_t len) {
  */
 struct seam_slot {
     const void *host;      /* the caller's struct */
+    int device;            /* the HIP device the copy lives on: a call made
+                              with another device current is a miss (the
+                              uncached path and the reference's seam always
+                              use the current device) */
     uint64_t print;        /* fingerprint of the matrix */
     spmv_csr_dev *csr;
     spmv_hll_dev *hll;
@@ -1979,22 +1985,126 @@ static uint64_t fp_array(uint64_t h, const void *p, size_t n, size_t item) {
     return h;
 }
 
+/*
+ * Level 3: EVERY byte of the arrays, every call -- the one level that cannot
+ * return a stale result whatever the caller changed in place.  Four
+ * independent multiply-rotate lanes per 1 MiB chunk (instruction-level
+ * parallelism), chunks hashed by up to 8 host threads and combined in order.
+ * Priced on config 2 (212 MB of IRP / JA / AS + 8 MB of x): see DESIGN.md.
+ */
+static uint64_t fp_chunk(const unsigned char *b, size_t bytes) {
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full,
+                     0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t v[4];
+        memcpy(v, b + i, 32);
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (h[k] ^ v[k]) * 0xFF51AFD7ED558CCDull;
+            h[k] = (h[k] << 29) | (h[k] >> 35);
+        }
+    }
+    uint64_t tail = 0, out = fp_mix(fp_mix(h[0], h[1]), fp_mix(h[2], h[3]));
+    for (; i < bytes; ++i) {
+        tail = (tail << 8) | b[i];
+        if ((i & 7) == 7) {
+            out = fp_mix(out, tail);
+            tail = 0;
+        }
+    }
+    return fp_mix(out, tail ^ bytes);
+}
+
+static uint64_t fp_full(uint64_t h, const void *p, size_t n, size_t item) {
+    h = fp_mix(h, (uint64_t)(uintptr_t)p);
+    h = fp_mix(h, n);
+    if (!p || !n)
+        return h;
+    const unsigned char *b = (const unsigned char *)p;
+    const size_t bytes = n * item, CH = (size_t)1 << 20;
+    const size_t chunks = (bytes + CH - 1) / CH;
+    std::vector<uint64_t> part(chunks);
+    int T = spmv_host_threads();
+    T = T > 8 ? 8 : T;
+    if ((size_t)T > chunks / 4)
+        T = (int)(chunks / 4); /* at least 4 MiB per thread */
+    auto work = [&](size_t c0, size_t c1) {
+        for (size_t c = c0; c < c1; ++c)
+            part[c] = fp_chunk(b + c * CH, std::min(CH, bytes - c * CH));
+    };
+    if (T <= 1) {
+        work(0, chunks);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t)
+            th.emplace_back(work, chunks * t / T, chunks * (t + 1) / T);
+        work(0, chunks / T);
+        for (std::thread &t : th)
+            t.join();
+    }
+    for (uint64_t v : part)
+        h = fp_mix(h, v);
+    return h;
+}
+
+/* the fingerprint of one array at the cache's current level (g_seam.mu held) */
+static uint64_t fp_level(uint64_t h, const void *p, size_t n, size_t item);
+
+/* releases what the slot holds, with the device that owns it current */
 static void seam_drop(seam_slot *c) {
+    int cur = -1;
+    const bool held = c->csr || c->hll || c->d_x || c->d_y;
+    if (held && hipGetDevice(&cur) == hipSuccess && cur != c->device)
+        (void)hipSetDevice(c->device);
+    else
+        cur = -1;
     if (c->csr)
         spmv_csr_release(c->csr);
     if (c->hll)
         spmv_hll_release(c->hll);
     (void)hipFree(c->d_x);
     (void)hipFree(c->d_y);
+    if (cur >= 0)
+        (void)hipSetDevice(cur);
     memset(c, 0, sizeof *c);
 }
 
 void spmv_seam_cache(int level) {
     std::lock_guard<std::mutex> g(g_seam.mu);
-    g_seam.level = level < 0 ? 0 : (level > 2 ? 2 : level);
-    if (g_seam.level == 0)
+    const int old = g_seam.level;
+    g_seam.level = level < 0 ? 0 : (level > 3 ? 3 : level);
+    /* the fingerprints of levels 1 / 2 (samples) and 3 (every byte) are
+     * different functions: what is held was keyed under the old one */
+    if (g_seam.level == 0 || (old != 0 && (old == 3) != (g_seam.level == 3)))
         for (seam_slot &c : g_seam.slot)
             seam_drop(&c);
+}
+
+static uint64_t fp_level(uint64_t h, const void *p, size_t n, size_t item) {
+    return g_seam.level >= 3 ? fp_full(h, p, n, item) : fp_array(h, p, n, item);
+}
+
+/* Targeted invalidate: `host` = a matrix struct (sparse_csr* / sparse_hll*)
+ * handed to the seam earlier -> its device copy is dropped (the next call
+ * uploads again); `host` = an x vector -> the next call uploads x again;
+ * NULL -> everything held is dropped, the level stays.  For a caller that
+ * edits a matrix or x IN PLACE and runs level 1 / 2 (sampled fingerprints).
+ * Returns how many slots it touched. */
+int spmv_seam_cache_invalidate(const void *host) {
+    std::lock_guard<std::mutex> g(g_seam.mu);
+    int n = 0;
+    for (seam_slot &c : g_seam.slot) {
+        if (!(c.csr || c.hll))
+            continue;
+        if (!host || c.host == host) {
+            seam_drop(&c);
+            ++n;
+        } else if (c.x_host == host && c.x_valid) {
+            c.x_valid = false;
+            ++n;
+        }
+    }
+    return n;
 }
 
 int spmv_seam_cache_stats(long *hits, long *misses) {
@@ -2031,11 +2141,14 @@ static int seam_acquire(int which, const void *host, uint64_t print, int M,
                         seam_slot **out) {
     int rc = 0;
     seam_slot *c = &g_seam.slot[which];
+    int dev = 0;
+    HIP_RET(hipGetDevice(&dev));
     const bool hit = (c->csr || c->hll) && c->host == host && c->print == print &&
-                     c->M == M && c->N == N;
+                     c->M == M && c->N == N && c->device == dev;
     if (!hit) {
         seam_drop(c);
         ++g_seam.misses;
+        c->device = dev;
         rc = upload(c);
         if (rc) {
             seam_drop(c);
@@ -2054,7 +2167,7 @@ static int seam_acquire(int which, const void *host, uint64_t print, int M,
     }
     {
         const uint64_t xp = g_seam.level >= 2
-                                ? fp_array(0x78, x, (size_t)N, sizeof(double))
+                                ? fp_level(0x78, x, (size_t)N, sizeof(double))
                                 : 0;
         if (!(g_seam.level >= 2 && c->x_valid && c->x_host == x &&
               c->x_print == xp)) {
@@ -2088,9 +2201,9 @@ static double csr_one_shot(const sparse_csr *A, const double *x, double *y,
             const double t0s = panels_ops::now_s();
             uint64_t fp = fp_mix(fp_mix(fp_mix(0x637372, (uint64_t)A->M),
                                         (uint64_t)A->N), (uint64_t)A->NZ);
-            fp = fp_array(fp, A->IRP, (size_t)A->M + 1, sizeof(int));
-            fp = fp_array(fp, A->JA, (size_t)A->NZ, sizeof(int));
-            fp = fp_array(fp, A->AS, (size_t)A->NZ, sizeof(double));
+            fp = fp_level(fp, A->IRP, (size_t)A->M + 1, sizeof(int));
+            fp = fp_level(fp, A->JA, (size_t)A->NZ, sizeof(int));
+            fp = fp_level(fp, A->AS, (size_t)A->NZ, sizeof(double));
             seam_slot *c = NULL;
             const double t1 = panels_ops::now_s();
             rc = seam_acquire(0, A, fp, A->M, A->N, x,
@@ -2144,14 +2257,25 @@ static double hll_one_shot(const sparse_hll *H, const double *x, double *y,
                                         (uint64_t)H->N), (uint64_t)H->NZ);
             fp = fp_mix(fp, (uint64_t)H->num_blocks);
             fp = fp_mix(fp, (uint64_t)(uintptr_t)H->blocks);
-            /* first, middle and last hack block: shape + array fingerprints */
+            /* first, middle and last hack block: shape + array fingerprints
+             * (level 3: EVERY block, every byte) */
             const int pick[3] = {0, H->num_blocks / 2, H->num_blocks - 1};
-            for (int k = 0; k < 3 && H->num_blocks > 0; ++k) {
-                const ellpack_block *b = &H->blocks[pick[k]];
+            const int npick = g_seam.level >= 3 ? H->num_blocks
+                                                : (H->num_blocks > 0 ? 3 : 0);
+            for (int k = 0; k < npick; ++k) {
+                const ellpack_block *b =
+                    &H->blocks[g_seam.level >= 3 ? k : pick[k]];
                 const size_t n = (size_t)b->M * (size_t)b->max_NZ;
                 fp = fp_mix(fp, ((uint64_t)b->M << 32) | (uint32_t)b->max_NZ);
-                fp = fp_array(fp, b->JA, n, sizeof(int));
-                fp = fp_array(fp, b->AS, n, sizeof(double));
+                if (g_seam.level >= 3) { /* small arrays: no thread spawn */
+                    fp = fp_mix(fp, fp_chunk((const unsigned char *)b->JA,
+                                             n * sizeof(int)));
+                    fp = fp_mix(fp, fp_chunk((const unsigned char *)b->AS,
+                                             n * sizeof(double)));
+                } else {
+                    fp = fp_array(fp, b->JA, n, sizeof(int));
+                    fp = fp_array(fp, b->AS, n, sizeof(double));
+                }
             }
             seam_slot *c = NULL;
             rc = seam_acquire(col_major ? 2 : 1, H, fp, H->M, H->N, x,

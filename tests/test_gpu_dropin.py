@@ -212,3 +212,90 @@ def test_seam_cache_keeps_the_last_upload_and_notices_a_change():
           % (wall, wall_uncached, kms))
     # 0.7 vs 6.4 ms on a quiet box; on a busy host both stretch
     assert wall < 2.5 or wall < 0.6 * wall_uncached, (wall, wall_uncached)
+
+
+def test_seam_cache_level_3_cannot_be_stale_and_levels_1_2_say_what_they_miss():
+    """VERDICT r05 next #6.  One entry in the MIDDLE of AS -- outside the 64
+    head + 64 tail + 64 strided samples of the level-1/2 fingerprint -- is
+    edited in place between two calls on the same struct:
+      level 2  returns the PREVIOUS y (the documented contract of the sampled
+               levels: the caller promised not to do that) -- until
+               spmv_seam_cache_invalidate(A) is called;
+      level 3  hashes every byte on every call: it re-uploads by itself.
+    Same for x: an unsampled element edited in place."""
+    import time
+
+    import numpy as np
+
+    import _oracle as O
+    M = N = 1_000_000
+    A = S.csr_generate(S.SYNTH_BANDED, M, N, 16, 0, 0, 42)
+    IRP, JA, AS = S.csr_arrays(A)
+    NZ = len(AS)
+    x = O.synth_x(7, 0, N)
+    step = NZ // 64
+    spot = 37 * step + step // 2 + 3     # between two strided samples
+    assert spot % step and 64 <= spot < NZ - 64
+    row = int(np.searchsorted(np.array(IRP), spot, side="right") - 1)
+    xs = 500_003                          # x: N // 64 = 15625; not a sample
+    assert xs % (N // 64) and 64 <= xs < N - 64
+
+    def ref():
+        return O.csr_spmv(np.array(IRP), np.array(JA), np.array(AS), x)
+
+    try:
+        # ---- level 2: sampled fingerprints, the stale result and its cure
+        S.seam_cache(2)
+        y0, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert np.allclose(y0, ref(), rtol=1e-12, atol=1e-12)
+        AS[spot] += 1000.0
+        y_stale, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert np.array_equal(y_stale, y0)          # the contract's fine print
+        assert abs(ref()[row] - y0[row]) > 1.0      # ... and it IS stale
+        assert S.seam_cache_invalidate(A) == 1
+        y_new, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert np.allclose(y_new, ref(), rtol=1e-12, atol=1e-12)
+        x[xs] += 7.0
+        y_xstale, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert np.array_equal(y_xstale, y_new)
+        assert S.seam_cache_invalidate(x) == 1      # x only: the matrix stays
+        m_before = S.seam_cache_stats()[2]
+        y_x, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert S.seam_cache_stats()[2] == m_before  # a hit, x re-uploaded
+        assert np.allclose(y_x, ref(), rtol=1e-12, atol=1e-12)
+        # ---- level 3: every byte, every call
+        S.seam_cache(3)
+        assert S.seam_cache_stats()[0] == 0  # keyed under the other function
+        y3, _ = S.csr_spmv_hip(A, x, kernel=4)
+        AS[spot] -= 500.0
+        h0, m0 = S.seam_cache_stats()[1:]
+        y3b, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert S.seam_cache_stats()[2] == m0 + 1    # noticed: re-uploaded
+        assert np.allclose(y3b, ref(), rtol=1e-12, atol=1e-12)
+        assert abs(y3b[row] - y3[row]) > 1.0
+        x[xs] -= 3.0
+        y3c, _ = S.csr_spmv_hip(A, x, kernel=4)
+        assert S.seam_cache_stats()[1] == h0 + 1    # matrix hit, x re-sent
+        assert np.allclose(y3c, ref(), rtol=1e-12, atol=1e-12)
+        # what level 3 costs per call on config-2's 212 MB (the C entry point,
+        # one caller buffer for y)
+        import ctypes as C
+        y2 = np.full(M, -1.0)
+        xp = x.ctypes.data_as(C.POINTER(C.c_double))
+        yp = y2.ctypes.data_as(C.POINTER(C.c_double))
+        t0 = time.perf_counter()
+        for _ in range(5):
+            S._lib.csr_spmv_hip_stream(A, xp, yp, None)
+        ms3 = (time.perf_counter() - t0) * 1e3 / 5
+        S.seam_cache(2)
+        S._lib.csr_spmv_hip_stream(A, xp, yp, None)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            S._lib.csr_spmv_hip_stream(A, xp, yp, None)
+        ms2 = (time.perf_counter() - t0) * 1e3 / 5
+        print("seam cache on 1M x 16 (%d MB): level 3 %.2f ms per call, "
+              "level 2 %.2f ms" % ((12 * NZ + 4 * M + 8 * N) >> 20, ms3, ms2))
+        assert np.array_equal(y2, y3c)
+    finally:
+        S.seam_cache(0)
+    S.csr_free(A)
