@@ -42,15 +42,26 @@ class RankJob:
 
     def __init__(self, args, omp_team):
         import numpy as np
-        import torch
-        import torch.distributed as dist
-        import spmv_scpa_amd as S
-        from spmv_scpa_amd import dist as D
-        self.np, self.torch, self.dist, self.S, self.D = np, torch, dist, S, D
         self.args, self.omp_team = args, omp_team
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1 or args.force_exchange:
+            # ranks: torch.distributed over RCCL.  torch FIRST: the binding
+            # then shares the ROCm runtime torch's wheel has mapped (one
+            # runtime per process; `config.rocm` says which, and flags a
+            # major.minor mismatch with the build)
+            import torch
+            import torch.distributed as dist
+        else:
+            # one GPU: no torch in the process -- device memory, stream and
+            # events come from the library's C-ABI (benchlib.devshim) and the
+            # library runs on the ROCm runtime it was built for
+            from . import devshim as torch
+            dist = None
+        import spmv_scpa_amd as S
+        from spmv_scpa_amd import dist as D
+        self.np, self.torch, self.dist, self.S, self.D = np, torch, dist, S, D
         self.stat0 = cgroup_cpu_stat()
         self.t_start = time.time()
         if not torch.cuda.is_available() or S.device_count() == 0:
@@ -97,10 +108,11 @@ class RankJob:
         return self.torch.cuda.current_stream().cuda_stream
 
     def max_over_ranks(self, value):
+        if not self.use_dist:
+            return float(value)
         t = self.torch.tensor([float(value)], dtype=self.torch.float64,
                               device=self.dev)
-        if self.use_dist:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def time_steps(self, sh, n):
@@ -258,7 +270,7 @@ class RankJob:
             waves_per_block=a.waves,
             chunks=self.chunks if chunks is None else chunks,
             force_exchange=a.force_exchange, mode=mode, halo_rows=self.halo,
-            starts=self.starts if self.ragged else None)
+            starts=self.starts if self.ragged else None, backend=self.torch)
 
     # ---------------------------------------- the overlapped arrangements
     def alternative_kind(self):
@@ -1032,10 +1044,13 @@ class PartitionedRun:
                               dA.panels_tile_rows() or 0)
                 pick = D.agree_on_pick(job.dist, mine, job.dev)
                 kernel = pick.kernel
-                if (kernel == S.CSR_KERNEL_PANELS
-                        and not pick.same_build(mine)):
-                    together(job, lambda: dA.build_panels(
-                        0, pick.schedule, pick.tile_rows))
+                # EVERY rank enters the agreement, whether or not it is the
+                # one that has to rebuild (rank 0 never is)
+                rebuild = (kernel == S.CSR_KERNEL_PANELS
+                           and not pick.same_build(mine))
+                together(job, (lambda: dA.build_panels(
+                    0, pick.schedule, pick.tile_rows)) if rebuild
+                    else (lambda: None))
         self.kernel = kernel
         sh = together(job, build)
         yy = sh.y

@@ -84,6 +84,27 @@ int spmv_dev_memset(void *dptr, int byte, size_t bytes, void *stream);
 int spmv_copy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int spmv_copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int spmv_stream_sync(void *stream);
+int spmv_device_sync(void); /* every stream of the current device */
+/* GPU timer (reference src/cuda_timer.cu:15-21): events recorded on a stream
+ * around whatever the caller enqueues; elapsed_ms waits for `stop` */
+int spmv_event_create(void **ev);
+int spmv_event_record(void *ev, void *stream);
+int spmv_event_elapsed_ms(void *start, void *stop, float *ms);
+int spmv_event_destroy(void *ev);
+/* Streams, and a hipGraph of whatever is enqueued on one between begin and
+ * end: every launch of this API is stream-ordered and capturable (the main
+ * kernel, the side launch of long rows / wide hack blocks, the sweep
+ * schedule's memset + persistent kernel, the steps schedule's launch
+ * sequence), so a solver that iterates y = A x records the launches once and
+ * replays them -- x is read where it lives.  Launch each kernel id once
+ * eagerly before capturing it (one-off function attributes).  Limits of a
+ * replay: INTEGRATION.md "Contracts". */
+int spmv_stream_create(void **stream);  /* non-blocking stream */
+int spmv_stream_destroy(void *stream);
+int spmv_graph_begin_capture(void *stream); /* not the default (NULL) stream */
+int spmv_graph_end_capture(void *stream, void **graph_exec);
+int spmv_graph_launch(void *graph_exec, void *stream);
+int spmv_graph_destroy(void *graph_exec);
 /* x[i] = synth_x(seed, first + i) generated on the device */
 int spmv_dev_fill_synth(double *d_x, int64_t n, uint64_t seed, int64_t first,
                         void *stream);

@@ -34,50 +34,72 @@ if not os.path.exists(LIB_PATH):
         % LIB_PATH)
 
 
-def _share_the_rocm_runtime_with_torch():
-    """One copy of the ROCm runtime per process, and no global symbols.
-
-    ROOT CAUSE of the `double free or corruption (!prev)` abort at the exit of
-    round 2's GPU test process (gpurun_out/r2c4_1.log) and of round 4's first
-    run with an in-process `import torch` (gpurun_out/r4c2_1.log), found by
-    reproducing it on the CPU-only build box with nothing but imports
-    (tests/test_rocm_runtime_once.py):
-
-      this module loaded libspmv_scpa_amd.so with RTLD_GLOBAL.  That puts the
-      symbols of its whole dependency closure -- librccl and, through it,
-      librocm_smi64 -- into the process-wide namespace.  A LATER `import
-      torch` then binds symbols of its own libraries against those copies
-      (`ctypes.CDLL(".../librocm_smi64.so", RTLD_GLOBAL); import torch` alone
-      aborts the same way), objects end up destroyed by two owners, and glibc
-      aborts inside exit().  No GPU, no handle, no kernel is involved; the
-      other import order (torch first: bench.py, the dist workers) never
-      showed it, and neither did test processes that did not import torch
-      (round 3 -- which is why the abort "went away").
-
-    Fix: RTLD_LOCAL (nothing needs this library's symbols globally: the
-    reference's driver and the C driver link it directly).  And because
-    PyTorch's ROCm wheels bundle their own libamdhip64 / librccl /
-    libhsa-runtime64 under torch/lib and ask for them by UNVERSIONED file name
-    (DT_NEEDED libamdhip64.so, RPATH $ORIGIN), which the dynamic loader does
-    not recognise as /opt/rocm's libamdhip64.so.7, the ours-then-torch order
-    would still map TWO HIP / HSA / RCCL runtimes into the process: when torch
-    ships such copies and has not been imported yet, they are loaded first
-    (locally, by path, without importing torch) so that this library's
-    versioned DT_NEEDED names resolve to them by SONAME -- one runtime, one
-    OpenMP runtime, whatever the import order; the same libraries bench.py has
-    always measured with.  SPMV_NO_TORCH_PRELOAD=1 (harness knob) keeps
-    /opt/rocm's runtime for a process that never imports torch."""
+def _torch_lib_dir():
+    """torch/lib of an installed PyTorch WITHOUT importing it, or None"""
     import importlib.util
-    import sys
-    if "torch" in sys.modules or os.environ.get("SPMV_NO_TORCH_PRELOAD"):
-        return None
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if not spec or not spec.submodule_search_locations:
         return None
-    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    return d if os.path.isdir(d) else None
+
+
+def _bind_the_rocm_runtime():
+    """ONE copy of the ROCm runtime per process, no global symbols -- and, by
+    default, the runtime the library was BUILT for.  -> ("system" | "torch",
+    [bundled libraries preloaded] or None)
+
+    Why one copy (rounds 2-4): this module once loaded libspmv_scpa_amd.so
+    with RTLD_GLOBAL; the symbols of its dependency closure (librccl ->
+    librocm_smi64) became process-wide, a later `import torch` bound against
+    them, objects ended up destroyed by two owners and glibc aborted inside
+    exit() (`double free or corruption (!prev)`; no GPU, handle or kernel
+    involved -- tests/test_rocm_runtime_once.py reproduces it with imports
+    alone).  Hence RTLD_LOCAL.  And PyTorch's ROCm wheels bundle their own
+    libamdhip64 / librccl / libhsa-runtime64 under torch/lib and ask for them
+    by UNVERSIONED file name (RPATH $ORIGIN), which the loader does not take
+    for /opt/rocm's libamdhip64.so.7: torch and this library in one process
+    map TWO runtimes unless one of them gives way.
+
+    Which copy (round 6): the library is compiled by
+    /opt/rocm's hipcc (HIP 7.2); torch 2.10's wheel bundles HIP 7.0.  Until
+    round 5 torch's copy was always preloaded, so every Python-side run --
+    tests and bench -- executed 7.2-built code objects on a 7.0 runtime.  Now:
+      * torch NOT imported yet (default): nothing is preloaded; the library's
+        RUNPATH binds /opt/rocm's runtime, the one it was built against
+        (`rocm_runtime_report()`: hip_built == hip_runtime).  A later `import
+        torch` in the same process would map the second runtime, so it is
+        REFUSED with an ImportError that says what to do (import torch first,
+        or SPMV_ROCM_RUNTIME=torch) -- loud, not a crash at exit.
+      * torch already imported (bench.py's ranks, the dist workers: they need
+        torch.distributed): its runtime is the process's runtime; the
+        library's versioned DT_NEEDED names resolve to the mapped copies by
+        SONAME.  A major.minor difference to the build is warned about at the
+        first device query and flagged (`rocm.mismatch`) in the bench line.
+      * SPMV_ROCM_RUNTIME=torch: preload torch's copies now (a process that
+        will import torch LATER); =system: never share (the default's
+        behaviour, stated).  SPMV_NO_TORCH_PRELOAD=1 (older knob) = system."""
+    import sys
+    mode = os.environ.get("SPMV_ROCM_RUNTIME", "").strip().lower() or "auto"
+    if mode not in ("auto", "system", "torch"):
+        raise ImportError("SPMV_ROCM_RUNTIME=%r: auto, system or torch" % mode)
+    if os.environ.get("SPMV_NO_TORCH_PRELOAD") and mode == "auto":
+        mode = "system"
+    if "torch" in sys.modules:
+        if mode == "system":
+            import warnings
+            warnings.warn("spmv_scpa_amd: SPMV_ROCM_RUNTIME=system, but torch "
+                          "is already imported: its bundled ROCm runtime is "
+                          "this process's runtime", RuntimeWarning)
+        return "torch", None
+    if mode != "torch":
+        return "system", None
+    libdir = _torch_lib_dir()
+    if not libdir:
+        return "system", None
     # A bundled copy can stand in for /opt/rocm's only if the loader will
     # take it for the name this library asks for: its DT_SONAME must equal our
     # DT_NEEDED entry (libamdhip64.so.7, librccl.so.1, libgomp.so.1).  Another
@@ -99,10 +121,64 @@ def _share_the_rocm_runtime_with_torch():
                 "libspmv_scpa_amd.so needs %r: not sharing torch's ROCm "
                 "runtime (importing torch later in this process would map a "
                 "second one)" % (name, soname, want[0]), RuntimeWarning)
-            return loaded or None
+            return ("torch", loaded) if loaded else ("system", None)
         C.CDLL(path, mode=C.RTLD_LOCAL)
         loaded.append(path)
-    return loaded or None
+    return ("torch", loaded) if loaded else ("system", None)
+
+
+class _RefusingLoader:
+    def __init__(self, why):
+        self.why = why
+
+    def create_module(self, spec):
+        raise ImportError(self.why)
+
+    def exec_module(self, module):
+        raise ImportError(self.why)
+
+
+class _NoTorchAfterTheSystemRuntime:
+    """meta-path guard installed when the library is bound to /opt/rocm's
+    runtime and PyTorch bundles its own: `import torch` now would map a second
+    HIP / HSA / RCCL runtime into the process (two owners of one device
+    state).  Refused, loudly, with the two ways out.  Only the IMPORT is
+    refused: importlib.util.find_spec("torch") still answers (the real spec,
+    with a loader that raises)."""
+
+    def find_spec(self, name, path=None, target=None):
+        if name != "torch":
+            return None
+        import sys
+        spec = None
+        for f in sys.meta_path:
+            if f is self or not hasattr(f, "find_spec"):
+                continue
+            spec = f.find_spec(name, path, target)
+            if spec is not None:
+                break
+        if spec is None:
+            return None
+        spec.loader = _RefusingLoader(
+            "spmv_scpa_amd is bound to the system ROCm runtime (%s); "
+            "PyTorch bundles its own copy and importing it now would map "
+            "a second runtime into this process.  Import torch BEFORE "
+            "spmv_scpa_amd (the library then shares torch's runtime), or "
+            "set SPMV_ROCM_RUNTIME=torch."
+            % ((mapped_rocm_runtimes().get("libamdhip64.so") or ["?"])[0]))
+        return spec
+
+
+def _guard_against_a_second_runtime():
+    import sys
+    if ROCM_RUNTIME_BOUND != "system":
+        return False
+    libdir = _torch_lib_dir()
+    if not libdir or not os.path.exists(os.path.join(libdir,
+                                                     "libamdhip64.so")):
+        return False  # no torch, or a torch that uses the system runtime
+    sys.meta_path.insert(0, _NoTorchAfterTheSystemRuntime())
+    return True
 
 
 def _elf_dynamic(path):
@@ -169,15 +245,18 @@ def _fmt_hip(v):
 
 def rocm_runtime_report():
     """what this process runs the library on: the HIP version it was built
-    against, the one the bound runtime reports, whether torch's bundled
-    runtime is shared, and every runtime copy mapped (bench.py prints it)"""
+    against, the one the bound runtime reports, which copy that is (the
+    system's or torch's bundled one), every runtime copy mapped, and
+    `mismatch`: built and bound differ in major.minor (bench.py prints it)"""
     built = _lib.spmv_hip_build_version()
     run = _lib.spmv_hip_runtime_version()
     maps = mapped_rocm_runtimes()
     lib = (maps.get("libamdhip64.so") or [None])[0]
     return {"hip_built": _fmt_hip(built),
             "hip_runtime": _fmt_hip(run) if run > 0 else None,
-            "shared_with_torch": bool(ROCM_RUNTIME_SHARED_WITH_TORCH),
+            "bound": ROCM_RUNTIME_BOUND,
+            "shared_with_torch": ROCM_RUNTIME_BOUND == "torch",
+            "mismatch": bool(run > 0 and run // 100_000 != built // 100_000),
             # copies of the HIP / RCCL / HSA runtime mapped: 1 each when healthy
             "runtimes_mapped": max([len(v) for v in maps.values()] or [0]),
             "hip_from": "torch/lib" if lib and "/torch/lib/" in lib else lib}
@@ -201,25 +280,30 @@ _versions_checked = False
 
 
 def _check_the_hip_version_once():
-    """first device query: the HIP runtime the library is bound to must have
-    the major version it was built with (a minor difference -- /opt/rocm's
-    headers, torch's bundled runtime -- is reported by rocm_runtime_report(),
-    not refused)"""
+    """first device query: the HIP runtime the library is bound to should be
+    the one it was built with -- a different major.minor (torch's bundled
+    runtime in a process that needs torch) is warned about, loudly, once, and
+    flagged by rocm_runtime_report()["mismatch"]"""
     global _versions_checked
     if _versions_checked:
         return
     _versions_checked = True
     built = _lib.spmv_hip_build_version()
     run = _lib.spmv_hip_runtime_version()
-    if run > 0 and run // 10_000_000 != built // 10_000_000:
+    if run > 0 and run // 100_000 != built // 100_000:
         import warnings
         warnings.warn("spmv_scpa_amd: built against HIP %s, bound to a HIP %s "
-                      "runtime" % (_fmt_hip(built), _fmt_hip(run)),
-                      RuntimeWarning)
+                      "runtime (%s): gfx950 code objects of one toolchain on "
+                      "another runtime -- works today, nothing guarantees it"
+                      % (_fmt_hip(built), _fmt_hip(run),
+                         "torch's bundled copy: this process imported torch"
+                         if ROCM_RUNTIME_BOUND == "torch" else
+                         "the system's"), RuntimeWarning)
 
 
-ROCM_RUNTIME_SHARED_WITH_TORCH = _share_the_rocm_runtime_with_torch()
+ROCM_RUNTIME_BOUND, ROCM_RUNTIME_SHARED_WITH_TORCH = _bind_the_rocm_runtime()
 _lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)  # never RTLD_GLOBAL: see above
+ROCM_TORCH_IMPORT_GUARDED = _guard_against_a_second_runtime()
 for _n in ("spmv_hip_build_version", "spmv_hip_runtime_version"):
     getattr(_lib, _n).restype = C.c_int
     getattr(_lib, _n).argtypes = []
@@ -370,6 +454,18 @@ for _n in CSR_KERNEL_NAMES:
 for _n in HLL_KERNEL_NAMES:
     _sig("bench_hll_hip_" + _n, C.c_int, _HLLp, _dp, C.POINTER(BenchHip))
     _sig("hll_spmv_hip_" + _n, C.c_double, _HLLp, _dp, _dp, C.c_void_p)
+_sig("spmv_device_sync", C.c_int)
+_sig("spmv_event_create", C.c_int, C.POINTER(C.c_void_p))
+_sig("spmv_event_record", C.c_int, C.c_void_p, C.c_void_p)
+_sig("spmv_event_elapsed_ms", C.c_int, C.c_void_p, C.c_void_p,
+     C.POINTER(C.c_float))
+_sig("spmv_event_destroy", C.c_int, C.c_void_p)
+_sig("spmv_stream_create", C.c_int, C.POINTER(C.c_void_p))
+_sig("spmv_stream_destroy", C.c_int, C.c_void_p)
+_sig("spmv_graph_begin_capture", C.c_int, C.c_void_p)
+_sig("spmv_graph_end_capture", C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
+_sig("spmv_graph_launch", C.c_int, C.c_void_p, C.c_void_p)
+_sig("spmv_graph_destroy", C.c_int, C.c_void_p)
 _sig("spmv_seam_cache", None, C.c_int)
 _sig("spmv_seam_cache_stats", C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long))
 _sig("spmv_seam_cache_invalidate", C.c_int, C.c_void_p)
@@ -1028,6 +1124,91 @@ class DevBuffer:
 def dev_fill_synth(ptr, n, seed, first=0, stream=None):
     _check(_lib.spmv_dev_fill_synth(ptr, n, seed, first, stream),
            "spmv_dev_fill_synth")
+
+
+def device_sync():
+    _check(_lib.spmv_device_sync(), "spmv_device_sync")
+
+
+class Event:
+    """GPU timer event (spmv_engine.h spmv_event_*; reference cuda_timer.cu):
+    record() on a stream, a.elapsed_ms(b) waits for b"""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(_lib.spmv_event_create(C.byref(h)), "spmv_event_create")
+        self.h = h
+
+    def record(self, stream=None):
+        _check(_lib.spmv_event_record(self.h, stream), "spmv_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        _check(_lib.spmv_event_elapsed_ms(self.h, stop.h, C.byref(ms)),
+               "spmv_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _closed is False and _lib is not None:
+            _lib.spmv_event_destroy(h)
+
+
+class Stream:
+    """a non-blocking HIP stream (spmv_stream_create); .ptr goes wherever a
+    launch takes `stream`"""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(_lib.spmv_stream_create(C.byref(h)), "spmv_stream_create")
+        self.ptr = h
+
+    def sync(self):
+        stream_sync(self.ptr)
+
+    def capture(self):
+        """context manager: what is enqueued on this stream inside becomes a
+        Graph (`with st.capture() as g: ...; g.launch()`)"""
+        return _Capture(self)
+
+    def __del__(self):
+        h, self.ptr = getattr(self, "ptr", None), None
+        if h and _closed is False and _lib is not None:
+            _lib.spmv_stream_destroy(h)
+
+
+class Graph:
+    """an instantiated hipGraph of captured launches (spmv_graph_*)"""
+    h = None
+
+    def launch(self, stream=None):
+        _check(_lib.spmv_graph_launch(self.h, stream), "spmv_graph_launch")
+
+    def destroy(self):
+        h, self.h = self.h, None
+        if h and _closed is False and _lib is not None:
+            _lib.spmv_graph_destroy(h)
+
+    def __del__(self):
+        self.destroy()
+
+
+class _Capture:
+    def __init__(self, stream):
+        self.stream, self.graph = stream, Graph()
+
+    def __enter__(self):
+        _check(_lib.spmv_graph_begin_capture(self.stream.ptr),
+               "spmv_graph_begin_capture")
+        return self.graph
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        rc = _lib.spmv_graph_end_capture(self.stream.ptr, C.byref(h))
+        if et is None:
+            _check(rc, "spmv_graph_end_capture")
+            self.graph.h = h
+        return False
 
 
 def stream_sync(stream=None):

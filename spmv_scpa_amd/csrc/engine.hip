@@ -333,6 +333,94 @@ int spmv_stream_sync(void *stream) {
     return 0;
 }
 
+int spmv_device_sync(void) {
+    HIP_RET(hipDeviceSynchronize());
+    return 0;
+}
+
+/* the reference's GPU timer (cuda_timer.cu:15-21) as plain handles: an event
+ * pair recorded on the launch stream around whatever the caller enqueues */
+int spmv_event_create(void **ev) {
+    if (!ev)
+        return -EINVAL;
+    hipEvent_t e = NULL;
+    HIP_RET(hipEventCreate(&e));
+    *ev = (void *)e;
+    return 0;
+}
+
+int spmv_event_record(void *ev, void *stream) {
+    if (!ev)
+        return -EINVAL;
+    HIP_RET(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return 0;
+}
+
+int spmv_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!start || !stop || !ms)
+        return -EINVAL;
+    HIP_RET(hipEventSynchronize((hipEvent_t)stop));
+    HIP_RET(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+int spmv_event_destroy(void *ev) {
+    if (ev)
+        HIP_RET(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+
+/* ---- streams and hipGraph capture of stream-ordered launches ---- */
+int spmv_stream_create(void **stream) {
+    if (!stream)
+        return -EINVAL;
+    hipStream_t s = NULL;
+    HIP_RET(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return 0;
+}
+
+int spmv_stream_destroy(void *stream) {
+    if (stream)
+        HIP_RET(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
+int spmv_graph_begin_capture(void *stream) {
+    if (!stream)
+        return -EINVAL; /* the legacy default stream cannot be captured */
+    HIP_RET(hipStreamBeginCapture((hipStream_t)stream,
+                                  hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+
+int spmv_graph_end_capture(void *stream, void **graph_exec) {
+    if (!stream || !graph_exec)
+        return -EINVAL;
+    hipGraph_t g = NULL;
+    hipGraphExec_t e = NULL;
+    HIP_RET(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipError_t err = hipGraphInstantiate(&e, g, NULL, NULL, 0);
+    (void)hipGraphDestroy(g);
+    if (err != hipSuccess)
+        return hip_errno(err);
+    *graph_exec = (void *)e;
+    return 0;
+}
+
+int spmv_graph_launch(void *graph_exec, void *stream) {
+    if (!graph_exec)
+        return -EINVAL;
+    HIP_RET(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+
+int spmv_graph_destroy(void *graph_exec) {
+    if (graph_exec)
+        HIP_RET(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
 } /* extern "C" */
 
 /* ------------------------------------------------------------------ */

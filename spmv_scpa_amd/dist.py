@@ -384,9 +384,16 @@ class ShardedSpmv:
 
     def __init__(self, mat, kernel, rank, world, rows_per_rank, x, y,
                  waves_per_block=0, chunks=1, mode=None, compute=None,
-                 force_exchange=False, halo_rows=0, starts=None):
-        import torch
-        self.torch = torch
+                 force_exchange=False, halo_rows=0, starts=None,
+                 backend=None):
+        # backend: the module that provides cuda.current_stream() (and the
+        # tensors x / y): torch, or -- one rank, no exchange -- any stand-in
+        # with the same names (benchlib.devshim: the single-GPU bench never
+        # imports torch).  With ranks it is torch: the exchange is
+        # torch.distributed's
+        if backend is None:
+            import torch as backend
+        self.torch = backend
         self.mats = list(mat) if isinstance(mat, (list, tuple)) else None
         if self.mats is not None and len(self.mats) == 1:
             mat, self.mats = self.mats[0], None
@@ -425,6 +432,12 @@ class ShardedSpmv:
                     or self.bounds != [ch * i for i in range(k + 1)]):
                 mode, self.bounds = "allgather", [0, rows_per_rank]
         self.mode = mode
+        if world == 1 and not force_exchange:
+            # nothing travels: no exchange object (and no torch.distributed)
+            self.mode = mode if mode in ("allgather", "halo") else "allgather"
+            if self.mats is None:
+                self.bounds = [0, rows_per_rank]
+            return
         self.staged = (StagedExchange(y, rank, world, rows_per_rank,
                                       len(self.bounds) - 1)
                        if mode == "staged" else None)

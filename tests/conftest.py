@@ -32,14 +32,6 @@ def _ensure_built():
 _ensure_built()
 
 
-def gpu_available():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
-
-
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

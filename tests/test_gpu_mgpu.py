@@ -128,7 +128,7 @@ def test_native_leg_of_bench_prints_the_same_line_shape():
 def test_native_path_and_dist_path_give_the_same_y_on_one_shard():
     """the two N > 1 implementations (mgpu.hip and spmv_scpa_amd/dist.py) run
     the same shard with the same kernel: their y must agree bit for bit"""
-    import torch
+    from benchlib import devshim as T  # torch's names over the C-ABI
     from spmv_scpa_amd import dist as D
     rows, K, W = 320_000, 32, 1 << 30
     g = S.MultiGpu(1)
@@ -145,17 +145,15 @@ def test_native_path_and_dist_path_give_the_same_y_on_one_shard():
     # a destroyed handle is refused (-EBADF), not dereferenced
     assert S._lib.spmv_mgpu_fill_x(raw, 7) == -9
 
-    dev = torch.device("cuda", 0)
-    x = torch.empty(rows, dtype=torch.float64, device=dev)
-    y = torch.zeros(rows, dtype=torch.float64, device=dev)
+    x, y = T.empty(rows), T.zeros(rows)
     S.dev_fill_synth(x.data_ptr(), rows, 7, 0,
-                     torch.cuda.current_stream().cuda_stream)
+                     T.cuda.current_stream().cuda_stream)
     dA = S.CsrDevice.generate(S.SYNTH_RANDOM, rows, rows, K, W, 0, 42)
     dH = dA.to_hll(True)
     dA.release()
-    sh = D.ShardedSpmv(dH, 1, 0, 1, rows, x, y)
+    sh = D.ShardedSpmv(dH, 1, 0, 1, rows, x, y, backend=T)
     sh.step()
-    torch.cuda.synchronize()
+    T.cuda.synchronize()
     y_dist = y.cpu().numpy()
     dH.release()
     assert np.array_equal(y_native.view(np.uint64), y_dist.view(np.uint64))

@@ -6,9 +6,15 @@ pinned WITHOUT a GPU: the children below only import.
 The binding loaded libspmv_scpa_amd.so with RTLD_GLOBAL; the symbols of its
 dependency closure (librccl -> librocm_smi64) became process-global, a later
 `import torch` bound against them, and glibc aborted inside exit().  The
-binding now loads with RTLD_LOCAL and shares ONE copy of the ROCm runtime with
-torch (its bundled copies are loaded first, by path, when torch is installed):
-either import order ends with one HIP / RCCL / HSA runtime and a clean exit."""
+binding now loads with RTLD_LOCAL and keeps ONE copy of the ROCm runtime in
+the process, whatever the import order.
+
+Round 6: WHICH copy.  The library is built by
+/opt/rocm's hipcc; torch's wheel bundles an older HIP.  A process that does
+not need torch -- the tests, `python bench.py` at one GPU -- binds the
+system runtime the library was built for (hip_built == hip_runtime) and
+refuses a later `import torch`; a process that imported torch first (the
+ranks of an N > 1 run) shares torch's copy and says `mismatch`."""
 import importlib.util
 import os
 import subprocess
@@ -47,14 +53,34 @@ def run_child(imports, **env_extra):
     return r, copies
 
 
+REPORT = ("import json; print('REPORT', json.dumps("
+          "spmv_scpa_amd.rocm_runtime_report()))")
+
+
+def report_of(r):
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("REPORT")][-1]
+    return json.loads(line.split(" ", 1)[1])
+
+
 @needs_torch
-@pytest.mark.parametrize("imports", [
-    "import spmv_scpa_amd\nimport torch",          # the order that aborted
-    "import torch\nimport spmv_scpa_amd",          # bench.py's order
-    "import spmv_scpa_amd",                        # never imports torch
-], ids=["ours_then_torch", "torch_then_ours", "ours_only"])
-def test_one_rocm_runtime_whatever_the_import_order(imports):
-    r, copies = run_child(imports)
+@pytest.mark.parametrize("imports,env,bound", [
+    # the order that aborted in round 2: now refused, loudly, by the guard
+    ("import spmv_scpa_amd\n"
+     "try:\n    import torch\n    print('TORCH imported')\n"
+     "except ImportError as e:\n    print('TORCH refused:', e)\n" + REPORT,
+     {}, "system"),
+    # ... unless the process says up front that torch is coming
+    ("import spmv_scpa_amd\nimport torch\n" + REPORT,
+     {"SPMV_ROCM_RUNTIME": "torch"}, "torch"),
+    # bench.py's ranks, the dist workers: torch first
+    ("import torch\nimport spmv_scpa_amd\n" + REPORT, {}, "torch"),
+    # never imports torch: tests, tools, `python bench.py` at one GPU
+    ("import spmv_scpa_amd\n" + REPORT, {}, "system"),
+], ids=["ours_then_torch_refused", "ours_then_torch_announced",
+        "torch_then_ours", "ours_only"])
+def test_one_rocm_runtime_whatever_the_import_order(imports, env, bound):
+    r, copies = run_child(imports, **env)
     tail = r.stdout[-1500:] + "\n---- stderr ----\n" + r.stderr[-1500:]
     assert r.returncode == 0, tail
     assert "child-ok" in r.stdout, tail
@@ -62,6 +88,44 @@ def test_one_rocm_runtime_whatever_the_import_order(imports):
         assert word not in r.stderr, tail
     assert copies["libamdhip64.so"] == 1 and copies["librccl.so"] == 1, tail
     assert copies["libhsa-runtime64.so"] <= 1, tail
+    rep = report_of(r)
+    assert rep["bound"] == bound and rep["runtimes_mapped"] == 1, rep
+    if "refused" in (imports + " ") and bound == "system" and "try:" in imports:
+        assert "TORCH refused:" in r.stdout and "import torch BEFORE".lower() \
+            in r.stdout.lower(), tail
+    if bound == "system":
+        # VERDICT r05 next #5, "done": the runtime the code was built for
+        assert rep["hip_from"].startswith("/opt/rocm"), rep
+        assert rep["hip_built"].split(".")[:2] == \
+            rep["hip_runtime"].split(".")[:2], rep
+        assert rep["mismatch"] is False and not rep["shared_with_torch"]
+    else:
+        assert rep["hip_from"] == "torch/lib" and rep["shared_with_torch"]
+        # flagged exactly when torch's bundled HIP is another major.minor
+        assert rep["mismatch"] == (rep["hip_built"].split(".")[:2] !=
+                                   rep["hip_runtime"].split(".")[:2]), rep
+
+
+def test_the_single_gpu_bench_path_never_imports_torch():
+    """`python bench.py` at one GPU takes device memory, stream and events
+    from the library's C-ABI (benchlib.devshim): its process binds the system
+    runtime, so the driver's line carries hip_built == hip_runtime.  Checked
+    here without a GPU: building the job object imports what the run imports
+    (it then stops at 'no GPU visible')."""
+    code = ("import sys\nsys.path.insert(0, %r)\n"
+            "import bench\nfrom benchlib import dist\n"
+            "args = bench.parse_args([])\n"
+            "try:\n    dist.RankJob(args, 1)\n"
+            "except SystemExit as e:\n    print('EXIT', e)\n"
+            "print('TORCH' if 'torch' in sys.modules else 'NO-TORCH')\n"
+            "import spmv_scpa_amd as S\nprint('BOUND', S.ROCM_RUNTIME_BOUND)\n"
+            % ROOT)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "NO-TORCH" in r.stdout and "BOUND system" in r.stdout, r.stdout
 
 
 @needs_torch
@@ -131,7 +195,8 @@ def test_a_bundled_runtime_with_another_soname_is_not_preloaded(tmp_path):
             "print('WARNED', [str(x.message)[:60] for x in w])\n"
             "print('MAPS', S.mapped_rocm_runtimes())\n" % (ROOT, str(tmp_path)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=300,
+                       env=dict(os.environ, SPMV_ROCM_RUNTIME="torch"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "SHARED None" in r.stdout, r.stdout
     assert "SONAME" in r.stdout and "libamdhip64.so.6" not in r.stdout.split(
