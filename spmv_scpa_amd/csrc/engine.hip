@@ -484,7 +484,15 @@ __global__ void __launch_bounds__(SYNTH_WG)
         len = irp[i + 1] - beg;
         mine = !synth_row_is_parallel(&s, s.row0 + i, len); /* k_synth_long_rows */
     }
-    if (total > cap) { /* workgroup-uniform: direct stores */
+    /* A row left to k_synth_long_rows (longer than SYNTH_PARALLEL_ROW = 4096
+     * entries, which can be BELOW cap: up to 12288) would leave its part of
+     * the staged range unwritten, and the write-out loop would copy that
+     * uninitialised LDS to ja / as -- harmless only as long as
+     * k_synth_long_rows runs later on the same stream and overwrites it
+     * (ADVICE r05).  No such ordering dependency: a workgroup that holds such
+     * a row is not staged. */
+    const int skipped = __syncthreads_or(i < r1 && !mine);
+    if (total > cap || skipped) { /* workgroup-uniform: direct stores */
         if (mine)
             synth_fill_row(&s, s.row0 + i, len, ja + beg, as + beg);
         return;
@@ -495,7 +503,8 @@ __global__ void __launch_bounds__(SYNTH_WG)
         synth_fill_row_at(&s, s.row0 + i, len, cols, vals, beg - beg0,
                           SYNTH_SKEW);
     __syncthreads();
-    /* rows left to k_synth_long_rows are longer than cap: none in here */
+    /* every row of the range was generated above (none left to
+     * k_synth_long_rows in a staged workgroup) */
     for (int p = (int)threadIdx.x; p < total; p += SYNTH_WG) {
         ja[beg0 + p] = cols[SYNTH_AT(p, SYNTH_SKEW)];
         as[beg0 + p] = vals[SYNTH_AT(p, SYNTH_SKEW)];

@@ -198,6 +198,16 @@ static int adopt_logical_shards(spmv_mgpu *g) {
     return 0;
 }
 
+/* a load / generate has succeeded on this handle (vectors exist) */
+static bool mg_loaded(const spmv_mgpu *g) {
+    if (!g->y[0] || !g->x[0])
+        return false;
+    for (int r = 0; r < g->n; ++r)
+        if (g->csr[(size_t)r] || g->hll[(size_t)r])
+            return true;
+    return false;
+}
+
 extern "C" {
 
 void spmv_mgpu_destroy(spmv_mgpu *g) {
@@ -412,6 +422,10 @@ int spmv_mgpu_load_csr_part(spmv_mgpu *g, const sparse_csr *A, int as_hll,
         rc = alloc_vectors(g);
 fail:
     free(starts);
+    if (rc) /* nothing half-loaded stays behind: M, N, the ranges and whatever
+               shards were built go; the next step finds an EMPTY handle and
+               says -EINVAL instead of handing NULL vectors to a collective */
+        drop_shards(g);
     return rc;
 }
 
@@ -464,6 +478,10 @@ int spmv_mgpu_generate_part(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
         rc = alloc_vectors(g);
 fail:
     free(starts);
+    if (rc) /* nothing half-loaded stays behind: M, N, the ranges and whatever
+               shards were built go; the next step finds an EMPTY handle and
+               says -EINVAL instead of handing NULL vectors to a collective */
+        drop_shards(g);
     return rc;
 }
 
@@ -476,6 +494,8 @@ int spmv_mgpu_generate(spmv_mgpu *g, int kind, int rows_per_gpu, int K,
 int spmv_mgpu_set_x(spmv_mgpu *g, const double *x_host) {
     MG_OK(g);
     if (!g || !x_host)
+        return -EINVAL;
+    if (!mg_loaded(g))
         return -EINVAL;
     int rc = 0;
     device_guard keep;
@@ -491,6 +511,8 @@ fail:
 int spmv_mgpu_fill_x(spmv_mgpu *g, uint64_t seed) {
     MG_OK(g);
     if (!g)
+        return -EINVAL;
+    if (!mg_loaded(g))
         return -EINVAL;
     int rc = 0;
     device_guard keep;
@@ -641,6 +663,8 @@ int spmv_mgpu_spmv(spmv_mgpu *g, int kernel, int warmup, int iters,
     MG_OK(g);
     if (!g || iters < 0 || warmup < 0 || (iters && !ms_each))
         return -EINVAL;
+    if (!mg_loaded(g))
+        return -EINVAL; /* nothing loaded (or the last load failed) */
     int rc = 0;
     device_guard keep;
     if (kernel < 0)
@@ -1073,6 +1097,8 @@ int spmv_mgpu_run(spmv_mgpu *g, int kernel, int warmup, int steps,
     MG_OK(g);
     if (!g || steps < 1 || warmup < 0 || !wall_ms_total)
         return -EINVAL;
+    if (!mg_loaded(g))
+        return -EINVAL;
     int rc = 0;
     device_guard keep;
     if (kernel < 0)
@@ -1144,6 +1170,8 @@ fail:
 int spmv_mgpu_exchange_only(spmv_mgpu *g, int iters, double *ms_avg) {
     MG_OK(g);
     if (!g || iters < 1 || !ms_avg)
+        return -EINVAL;
+    if (!mg_loaded(g))
         return -EINVAL;
     device_guard keep;
     *ms_avg = 0.0;
@@ -1223,6 +1251,8 @@ int spmv_mgpu_shard_info(const spmv_mgpu *g, int rank, int64_t *stored,
 int spmv_mgpu_get_y(spmv_mgpu *g, int rank, double *y_host) {
     MG_OK(g);
     if (!g || rank < 0 || rank >= g->n || !y_host)
+        return -EINVAL;
+    if (!mg_loaded(g) || !g->y[rank])
         return -EINVAL;
     device_guard keep;
     HIP_RET(hipSetDevice(g->dev[rank]));

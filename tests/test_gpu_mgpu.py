@@ -487,6 +487,17 @@ def test_logical_shards_on_logical_devices_and_what_is_refused():
         g.generate(S.SYNTH_RANDOM, 64_032, 16, 4096, 42)
     with pytest.raises(OSError):
         g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, partition="nnz")
+    # a load that failed leaves an EMPTY handle, not a half-set one (ADVICE
+    # r05: M / N / ranges were set with NULL vectors behind them, and the
+    # next step would have handed those to a collective): every step says
+    # -EINVAL until something is loaded again
+    assert g.partition()[0] == [0, 0, 0, 0]
+    for call in (lambda: g.spmv(iters=1), lambda: g.run(1, 0, 1),
+                 lambda: g.exchange_only(1), lambda: g.get_y(0),
+                 lambda: g.fill_x(7), lambda: g.autotune()):
+        with pytest.raises(OSError) as e:
+            call()
+        assert e.value.errno == 22, e.value
     g.set_logical_shards(1)
     g.generate(S.SYNTH_RAGGED, rows, 24, 4096, 42, partition="nnz")  # fine again
     with pytest.raises(OSError):
