@@ -734,11 +734,11 @@ def run_rank(args, argv, omp_team):
         """the line as it stands (callable from the watchdog thread)"""
         with legs.lock:
             line = json.loads(json.dumps(out))  # a snapshot
-            if world > 1 or legs.failed or legs.skipped:
+            if world > 1:
                 line.setdefault("native", None)
-                line["legs_failed"] = list(legs.failed)
-                line["legs_skipped"] = list(legs.skipped)
-                line["legs_s"] = dict(legs.seconds)
+            line["legs_failed"] = list(legs.failed)
+            line["legs_skipped"] = list(legs.skipped)
+            line["legs_s"] = dict(legs.seconds)
             if world > 1 and per_rank:
                 # SURVEY 8d: y-throughput (global rows per second) kernel
                 # only, kernel + exchange one after the other, as measured

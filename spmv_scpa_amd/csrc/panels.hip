@@ -1391,10 +1391,19 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
  * and loading; all wavefronts of a workgroup consume the same number of
  * chunks (the chunk walk is workgroup-uniform), so the turn always arrives.
  */
+/* SPMV_DET_SLEEP: s_sleep argument between two polls of the turn counter
+ * (x 64 clocks); 0 = poll back to back.  Experiment knob of round 6
+ * (`make abl EXTRA=-DSPMV_DET_SLEEP=0`, tools/det_cost.py): see EXPERIMENTS */
+#ifndef SPMV_DET_SLEEP
+#define SPMV_DET_SLEEP 1
+#endif
 __device__ __forceinline__ void det_wait(int *turn, int want) {
     while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE,
-                             __HIP_MEMORY_SCOPE_WORKGROUP) != want)
-        __builtin_amdgcn_s_sleep(1);
+                             __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+#if SPMV_DET_SLEEP > 0
+        __builtin_amdgcn_s_sleep(SPMV_DET_SLEEP);
+#endif
+    }
 }
 
 __device__ __forceinline__ void det_pass(int *turn, int next) {

@@ -58,13 +58,48 @@ def test_bench_through_torchrun_one_rank(extra):
         assert j["config"]["exchange"] == "halo"
         assert j["config"]["halo_rows"] == 2048  # half of --window 4096
     if expect:
-        arr = j["config"]["exchange_arrangement"]
-        assert "exchange after the kernel" in arr and "overlapped" in arr
-        L = j["config"]["logical_shards_per_gpu"]
-        assert L in (1, 2) and j["config"]["rows_per_gpu"] == 320000
-        assert j["config"]["exchange"] == ("staged" if L == 2 else "allgather")
-        assert arr.endswith("-> overlapped" if L == 2
-                            else "-> exchange after the kernel")
+        # the sweep schedule: the plain arrangement is the line; the split one
+        # (two logical shards beside RCCL on reserved CUs) is the optional leg
+        c = j["config"]
+        assert c["exchange_arrangement"].startswith("plain")
+        assert c["logical_shards_per_gpu"] == 1 and c["rows_per_gpu"] == 320000
+        assert c["exchange"] == "allgather"
+        arr = c["arrangements"]
+        assert arr["alternative_kind"] == "sweep_split", arr
+        assert arr["winner"] in ("plain", "sweep_split")
+        assert j["value_best"] >= j["value"] * 0.999 and j["legs_failed"] == []
+    # every line of a run with an exchange is printed twice: provisional
+    # right after the main measurement, final at the end
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines[0]["provisional"] is True and "provisional" not in lines[-1]
+    assert lines[0]["value"] == lines[-1]["value"]
+    # ranks import torch (torch.distributed): the line says which runtime ran
+    rocm = j["config"]["rocm"]
+    assert rocm["bound"] == "torch" and rocm["runtimes_mapped"] == 1
+    assert rocm["mismatch"] == (rocm["hip_built"].split(".")[:2] !=
+                                rocm["hip_runtime"].split(".")[:2])
+
+
+def test_the_single_gpu_line_runs_on_the_runtime_it_was_built_for():
+    """`python bench.py` (what the driver runs at N = 1)
+    never imports torch: the library is bound to /opt/rocm's runtime, the
+    line's config.rocm shows hip_built == hip_runtime (major.minor), one
+    runtime mapped, no mismatch."""
+    r = subprocess.run([sys.executable, os.path.join(S.ROOT, "bench.py"),
+                        "--steps", "3", "--warmup", "1", "--rows-per-gpu",
+                        "640000", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    j = lines[-1]
+    rocm = j["config"]["rocm"]
+    assert rocm["bound"] == "system" and not rocm["shared_with_torch"], rocm
+    assert rocm["hip_from"].startswith("/opt/rocm"), rocm
+    assert rocm["hip_built"].split(".")[:2] == rocm["hip_runtime"].split(".")[:2]
+    assert rocm["mismatch"] is False and rocm["runtimes_mapped"] == 1
+    assert "rocm_mismatch" not in j
+    assert j["value"] > 0 and j["rows_checked"] >= 258
+    assert j["config"]["deterministic"] in (True, False)
 
 
 @pytest.mark.parametrize("args,kernel_prefix", [
