@@ -474,6 +474,21 @@ def config4_file(mtx, kkt_n):
     return path, info
 
 
+def last_json_line(path):
+    """the record of a saved bench run: its LAST line that is a JSON object
+    (a run prints its line provisionally after the main measurement and
+    again, complete, at the end; older records are one pretty-printed or
+    one-line object)"""
+    text = open(path).read()
+    for line in reversed(text.splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return json.loads(text)
+
+
 def strong_one_gpu():
     """(ms per step, source) of the fixed 80M x 80M problem on ONE MI355X:
     the newest committed `bench.py --strong --gpus 1` line under profiles/
@@ -486,7 +501,7 @@ def strong_one_gpu():
                                             "*_strong_1gpu.json")),
                      reverse=True):
         try:
-            j = json.load(open(fn))
+            j = last_json_line(fn)
             ks = j["config"].get("kernel_source") or {}
             if j["scaling"] != "strong" or j["n_gpus"] != 1:
                 continue

@@ -43,7 +43,9 @@ def main():
         print("%-40s %-30s %s %s" % (os.path.basename(fn), t["kernel"],
                                      "ok " if good else "STALE",
                                      t.get("blocked_schedule")))
-    j = json.load(open(os.path.join(ROOT, "profiles", rnd + "_bench_full.json")))
+    sys.path.insert(0, ROOT)
+    from benchlib.common import last_json_line
+    j = last_json_line(os.path.join(ROOT, "profiles", rnd + "_bench_full.json"))
     r = j["roofline"]
     print("headline: %.1f GFLOP/s, %.3f ms per step, frac %.4f, traffic %.3f GB"
           % (j["value"], j["ms_per_step"], r["frac"],
