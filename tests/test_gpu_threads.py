@@ -17,7 +17,6 @@ pytestmark = pytest.mark.gpu
 
 
 def test_two_host_threads_two_handles_two_streams():
-    torch = pytest.importorskip("torch")
     specs = [(S.SYNTH_HUB, 200_000, 6, 4096), (S.SYNTH_POWERLAW, 300_000, 8, 1 << 30)]
     work = []
     for kind, M, K, W in specs:
@@ -38,12 +37,12 @@ def test_two_host_threads_two_handles_two_streams():
             y = d_y.to_numpy(np.float64, M)
             assert np.max(np.abs(y[rows] - want[:, 0]) / want[:, 1]) <= 1e-12, tag
             ref[tag] = (h, k, y)
-        work.append((M, d_x, d_y, ref, torch.cuda.Stream(), dA, dH))
+        work.append((M, d_x, d_y, ref, S.Stream(), dA, dH))
     errors = []
     start = threading.Barrier(len(work))
 
     def worker(M, d_x, d_y, ref, stream, *_):
-        st = stream.cuda_stream
+        st = stream.ptr
         try:
             start.wait()
             for it in range(60):
