@@ -94,6 +94,10 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     omp_team = cap_openmp_env()
+    # RCCL between processes needs dmabuf IPC on this pool's host driver
+    # (exported on the boxes already; set before any runtime loads, for a
+    # launcher that starts the ranks with a scrubbed environment)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.native_mgpu:
         if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
             raise SystemExit("--native-mgpu is ONE process driving --gpus N "

@@ -188,6 +188,11 @@ def native_mgpu_bench(args, argv, omp_team):
                     alt["allgather"] = round(g.exchange_only(5), 5)
         except Exception as e:  # noqa: BLE001 - an optional leg
             failed.append("exchange_alone: %r" % (e,))
+            try:  # whatever failed, the handle goes back to its main engine
+                if not args.native_rehearsal:
+                    g.set_exchange_engine("rccl")
+            except OSError:
+                pass
         secs["exchange_alone"] = round(time.time() - t0, 1)
     if arrange and not failed:
         t0 = time.time()
