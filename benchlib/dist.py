@@ -94,6 +94,18 @@ class RankJob:
         self.legs = LegRunner(
             self.rank, self.world, self.t_start, self.dist,
             self.dev if self.args.backend == "nccl" else None, self.use_dist)
+        if self.use_dist:
+            # from here on a run that gets stuck BEFORE its line exists (a
+            # first collective that never completes) ends with a record that
+            # names the phase, not with the process group's timeout
+            from .common import METRIC as metric
+            self.legs.failure_record = lambda: {
+                "metric": metric, "unit": "GFLOP/s", "steps": self.args.steps,
+                "warmup": self.args.warmup, "higher_is_better": True}
+            if os.environ.get("SPMV_BENCH_MAIN_LIMIT"):  # tests
+                self.legs.main_limit_s = float(
+                    os.environ["SPMV_BENCH_MAIN_LIMIT"])
+            self.legs.start_watchdog()
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -543,8 +555,11 @@ def run_rank(args, argv, omp_team):
 
     # ---- build the shard(s) in HBM (device-side generator + converter) ----
     t_setup = time.time()
+    legs.phase("generate + convert the shard in HBM")
     job.alloc_vectors()
     job.mats, job.nnz_local, job.slots = job.build_shards(job.L, job.Mshard)
+    legs.phase("kernel selector + agreement on rank 0's pick (first "
+               "collective: a broadcast)")
     job.pick_kernel()
     if job.blocked:
         for m in job.mats[1:]:  # the tuned shard's schedule and tile height
@@ -569,16 +584,20 @@ def run_rank(args, argv, omp_team):
     t_setup = time.time() - t_setup
 
     # ---- the main measurement: the PLAIN arrangement, exactly K steps ----
+    legs.phase("first step + result check (first exchange of y)")
     job.check_result()
     stat1 = cgroup_cpu_stat()
+    legs.phase("warm-up + K timed steps")
     job.measure()
     kern_ms = job.kern_ms
     # what joined, on which cards, and every rank's own kernel time
+    legs.phase("describe the job + reductions over the ranks")
     rccl = per_rank = None
     if job.use_dist:
         rccl, per_rank = describe_job(S, torch, dist, job.dev, job.local_rank,
                                       job.world, args.backend, kern_ms)
     job.reduce_over_ranks()
+    legs.phase(None)
 
     a, world, L, Mshard = args, job.world, job.L, job.Mshard
     # everything the line needs from the device is read NOW: the line must be
@@ -692,6 +711,7 @@ def run_rank(args, argv, omp_team):
             "cfs_total": stat_delta(job.stat0, job.stat3),
         },
         "setup_s": round(t_setup, 2),
+        "phases_s": dict(legs.phases),  # the main measurement, by phase
         "rows_checked": job.checked,
     }
     if job.retried:
@@ -771,11 +791,9 @@ def run_rank(args, argv, omp_team):
         print(json.dumps(current_line(provisional)), flush=True)
 
     # ---- the line goes out NOW; whatever happens in a leg, it stands ----
-    legs.emit_final = emit
+    legs.emit_final = emit  # from here on the watchdog guards LEGS
     if job.rank == 0:
         emit(provisional=True)
-    if job.use_dist:
-        legs.start_watchdog()
 
     def note(key, value, where=None):
         with legs.lock:
@@ -1199,15 +1217,19 @@ def run_matrix_rank(args, argv, omp_team):
     job = RankJob(args, omp_team)
     job.init_process_group()
     t0 = time.time()
+    job.legs.phase("config 4: write / load the matrix on every rank")
     kk = KktLeg(job, args.kkt_n, args.mtx)
     together(job, kk.make_file)
     together(job, kk.load)
     A, info = kk.A, kk.info
     run = PartitionedRun(job, A, args.partition, args.ragged_exchange,
                          args.kernel if args.kernel >= 0 else None)
+    job.legs.phase("config 4: upload the row ranges + selector")
     together(job, run.prepare)
+    job.legs.phase("config 4: pick agreement, first exchange, K timed steps")
     res = run.run(args.steps)
     run.release()
+    job.legs.phase("config 4: describe the job")
     rccl, _ = describe_job(job.S, job.torch, job.dist, job.dev, job.local_rank,
                            job.world, args.backend, [1.0])
     M, N, NZ = A.contents.M, A.contents.N, A.contents.NZ
@@ -1243,5 +1265,6 @@ def run_matrix_rank(args, argv, omp_team):
                "rows_checked": res["rows_checked"] * job.world}
         print(json.dumps(out))
         sys.stdout.flush()
+    job.legs.finished = True  # the line is out: the watchdog stands down
     if job.use_dist:
         job.dist.destroy_process_group()

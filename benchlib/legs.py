@@ -21,6 +21,11 @@ main measurement's line from being lost to a leg:
     process group's own timeout.  Nothing is ever exec'ed.
  4. Once a collective has failed the group is `broken`: no further
     collective leg is started.
+ 5. BEFORE the line exists the same watchdog bounds the main measurement: the
+    run names the phase it is in (`phase()`), and if the line is not out
+    MAIN_LIMIT_S after the start -- a first collective that never completes
+    on a node nobody has seen -- rank 0 prints a failure record (`value`
+    null, `failed_in`, seconds per phase) and every rank exits with code 3.
 """
 import os
 import sys
@@ -34,6 +39,11 @@ LEG_BUDGET_S = 200.0
 RUN_DEADLINE_S = 270.0
 # default bound of ONE leg (its prepare steps + run)
 LEG_LIMIT_S = 75.0
+# seconds from process start by which the MAIN measurement of a run with
+# collectives must have printed its line: past it, rank 0 prints a failure
+# record that names the phase the run is stuck in and every rank leaves with
+# exit code 3 -- instead of the process group's timeout and a traceback
+MAIN_LIMIT_S = 240.0
 
 
 class InjectedFailure(RuntimeError):
@@ -84,6 +94,10 @@ class LegRunner:
         self.finished = False     # the final line is out
         self._current = None      # (name, started, limit_s)
         self._watchdog = None
+        self.main_limit_s = MAIN_LIMIT_S
+        self.phases = {}          # main measurement: seconds per phase
+        self._phase = None        # (name, started)
+        self.failure_record = None  # () -> dict, the line of a stuck main run
 
     # ------------------------------------------------------------ plumbing
     def spent(self):
@@ -111,6 +125,46 @@ class LegRunner:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [r for r, v in enumerate(t.tolist()) if v > 0.5]
 
+    # -------------------------------------------------- the main measurement
+    def phase(self, name):
+        """the main measurement enters phase `name` (None: it is done)"""
+        now = time.time()
+        if self._phase:
+            self.phases[self._phase[0]] = round(
+                self.phases.get(self._phase[0], 0.0) + now - self._phase[1], 2)
+        self._phase = (name, now) if name else None
+        if name and name.startswith("first step"):
+            injected("main", self.rank, "run")  # tests: a rank that hangs here
+
+    def _main_stuck(self):
+        """the line is not out and the main limit has passed: say where"""
+        with self.lock:
+            if self.finished:
+                return
+            self.finished = True
+            ph = self._phase
+            rec = {"value": None, "failed": True, "n_gpus": self.world,
+                   "failed_in": ph[0] if ph else None,
+                   "failed_after_s": round(self.spent(), 1),
+                   "stuck_in_phase_s": round(time.time() - ph[1], 1)
+                   if ph else None,
+                   "phases_s": dict(self.phases),
+                   "why": "the main measurement did not complete within "
+                          "%.0f s; rank %d was in this phase (a collective "
+                          "that never completes looks like this)"
+                          % (self.main_limit_s, self.rank)}
+            try:
+                if self.failure_record:
+                    rec = dict(self.failure_record(), **rec)
+                if self.rank == 0:
+                    import json
+                    print(json.dumps(rec), flush=True)
+            finally:
+                sys.stderr.write("bench.py rank %d: stuck in %r\n"
+                                 % (self.rank, rec["failed_in"]))
+                sys.stderr.flush()
+                os._exit(3)
+
     # ------------------------------------------------------------ watchdog
     def start_watchdog(self):
         """from now on a leg that outlives its limit, or a run that outlives
@@ -128,6 +182,11 @@ class LegRunner:
             cur = self._current
             now = time.time()
             why = None
+            if self.emit_final is None:  # the line does not exist yet
+                if now - self.t0 > self.main_limit_s - lead:
+                    self._main_stuck()
+                    return
+                continue
             if cur and now - cur[1] > cur[2] - lead:
                 why = ("%s: still running after its %.0f s limit on rank %d "
                        "(deadline; the remaining legs were dropped)"

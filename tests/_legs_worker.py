@@ -35,6 +35,19 @@ def main():
                 line.update(provisional=True, legs_pending=list(legs.pending))
         print(json.dumps(line), flush=True)
 
+    if scenario == "main_stuck":
+        # the line does not exist yet: rank 1 never joins the first collective
+        legs.main_limit_s = float(os.environ.get("LEGS_MAIN_LIMIT", "6"))
+        legs.failure_record = lambda: {"metric": "toy"}
+        legs.start_watchdog()
+        legs.phase("setup")
+        time.sleep(0.5)
+        legs.phase("first step + result check (first exchange of y)")
+        if rank == 1:
+            time.sleep(600)
+        t = torch.tensor([1.0])
+        dist.all_reduce(t)
+        raise SystemExit("not reached")
     legs.emit_final = emit
     legs.announce(["first", "second", "third"])
     if rank == 0:

@@ -145,3 +145,20 @@ def test_killing_the_job_after_the_main_measurement_leaves_a_parsable_line():
             p.send_signal(signal.SIGKILL)
         for p in procs:
             p.wait()
+
+
+def test_a_run_stuck_before_its_line_exists_says_where_and_exits_3():
+    """rule 5: rank 1 never joins the first collective of the MAIN
+    measurement (what a broken fabric looks like on a node nobody has seen):
+    instead of the process group's timeout and a traceback, rank 0 prints a
+    failure record -- value null, the phase, seconds per phase -- and every
+    rank exits with code 3"""
+    t0 = time.time()
+    outs = _finish(_start("main_stuck", LEGS_MAIN_LIMIT="6"))
+    assert time.time() - t0 < 60
+    assert [rc for rc, _, _ in outs] == [3, 3], outs
+    rec = _lines(outs[0][1])[-1]
+    assert rec["value"] is None and rec["failed"] is True and rec["n_gpus"] == 2
+    assert rec["failed_in"].startswith("first step + result check")
+    assert rec["phases_s"]["setup"] >= 0.4 and rec["metric"] == "toy"
+    assert _lines(outs[1][1]) == []

@@ -327,3 +327,24 @@ def test_a_job_killed_after_the_main_measurement_has_left_its_line():
     finally:
         os.killpg(p.pid, signal.SIGKILL)  # exactly the session started above
         p.wait()
+
+
+def test_a_rank_that_never_joins_the_first_exchange_gives_a_failure_record():
+    """the MAIN measurement has a deadline too: rank 1 hangs before the first
+    exchange of y; the run ends with rc 3 and ONE parsable record that names
+    the phase -- not with the process group's 300 s timeout"""
+    import time
+    cmd, env = _bench(["--kernel", "4", "--window", "0"],
+                      {"SPMV_BENCH_INJECT": "main:1:hang",
+                       "SPMV_BENCH_MAIN_LIMIT": "40"})
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert time.time() - t0 < 200
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = lines[0]
+    assert rec["value"] is None and rec["failed"] is True and rec["n_gpus"] == 2
+    assert rec["failed_in"].startswith("first step + result check")
+    assert "kernel selector" in " ".join(rec["phases_s"])
