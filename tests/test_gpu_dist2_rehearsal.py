@@ -291,7 +291,7 @@ def test_a_rank_that_hangs_inside_a_leg_ends_with_the_line_not_a_timeout():
     import time
     cmd, env = _bench(["--kernel", "4", "--window", "0", "--no-native-leg"],
                       {"SPMV_BENCH_INJECT": "exchange_alternatives:1:hang",
-                       "SPMV_BENCH_LEG_LIMIT": "20"})
+                       "SPMV_BENCH_LEG_LIMIT": "12"})
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env,
                        timeout=600)
@@ -336,7 +336,7 @@ def test_a_rank_that_never_joins_the_first_exchange_gives_a_failure_record():
     import time
     cmd, env = _bench(["--kernel", "4", "--window", "0"],
                       {"SPMV_BENCH_INJECT": "main:1:hang",
-                       "SPMV_BENCH_MAIN_LIMIT": "30"})
+                       "SPMV_BENCH_MAIN_LIMIT": "20"})
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env,
                        timeout=600)
