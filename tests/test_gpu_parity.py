@@ -194,11 +194,23 @@ def test_bench_wrappers_and_reference_abi_names():
     (S.SYNTH_RAGGED, 30_011, 60_000, 300, 8192),
     # every 64th row 8x longer than the others
     (S.SYNTH_KKT, 50_021, 60_000, 16, 2048),
-], ids=["ragged", "powerlaw", "hub", "wide_rows", "kkt"])
+    # nine rows of 4097..12288 entries, each inside a 128-row range that fits
+    # the generator's LDS stage: rows handed to the parallel-row kernel in a
+    # workgroup that would otherwise be staged (such a workgroup
+    # is not staged any more; before, it wrote the row's uninitialised LDS
+    # range out and relied on the later kernel to overwrite it)
+    (S.SYNTH_POWERLAW, 400_000, 400_000, 8, 1 << 30),
+], ids=["ragged", "powerlaw", "hub", "wide_rows", "kkt", "powerlaw_mid_rows"])
 def test_persistent_handles_and_device_generation(kind, M, N, K, W):
     """upload once / launch many; device-side generation and device-side
     CSR->HLL agree bit-for-bit with the host path."""
     IRP, JA, AS = O.synth_csr(kind, M, N, K, W, 42)
+    if M == 400_000:
+        L = np.diff(IRP)
+        mid = np.nonzero((L > 4096) & (L <= 12288))[0]
+        assert len(mid) >= 5 and any(
+            IRP[min(r // 128 * 128 + 128, M)] - IRP[r // 128 * 128] <= 12288
+            for r in mid), "the case no longer holds the rows it is about"
     x = O.synth_x(7, 0, N)
     y_ref = O.csr_spmv(IRP, JA, AS, x)
     scale = O.csr_abs_spmv(IRP, JA, AS, x)
