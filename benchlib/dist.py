@@ -726,12 +726,14 @@ def run_rank(args, argv, omp_team):
         plan += ["exchange_alone", "exchange_alternatives"]
         if job.alternative_kind() and not a.no_arrangement_choice:
             plan.append("arrangement")
-    want_strong = (world > 1 and not a.strong and not a.no_strong_leg
+    # (--force-exchange at one rank runs them too: the same legs over 1-rank
+    # RCCL collectives -- the nccl backend's code paths on a 1-GPU box)
+    want_strong = (job.use_dist and not a.strong and not a.no_strong_leg
                    and 8 % world == 0 and a.family == "random"
                    and a.window <= 0 and not job.ragged)
     if want_strong:
         plan.append("strong")
-    if world > 1 and not a.no_partition_leg:
+    if job.use_dist and not a.no_partition_leg:
         plan.append("partition_kkt")
     # the library's OWN multi-GPU path (mgpu.hip), in a child process once
     # every rank has freed its HBM -- unless a GPU-free parent of ours does

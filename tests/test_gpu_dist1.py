@@ -36,6 +36,7 @@ def test_bench_through_torchrun_one_rank(extra):
            "--master-port", "29577", os.path.join(S.ROOT, "bench.py"),
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu",
            "320000", "--window", "4096", "--kernel", "2", "--force-exchange",
+           "--kkt-n", "24",
            "--no-cpu-baseline", "--no-extras"]  # later flags override
     expect = None
     if "--expect-shards" in extra:
@@ -68,6 +69,14 @@ def test_bench_through_torchrun_one_rank(extra):
         assert arr["alternative_kind"] == "sweep_split", arr
         assert arr["winner"] in ("plain", "sweep_split")
         assert j["value_best"] >= j["value"] * 0.999 and j["legs_failed"] == []
+        # the fixed-problem leg over 1-rank RCCL: 8 logical shards on this GPU
+        st = c["strong"]
+        assert st["ms_per_step"] > 0 and "8 logical shards" in st["problem"]
+    # the nnz-balanced partition leg runs over the 1-rank RCCL group too
+    kkt = j["config"]["partition_kkt"]
+    assert kkt["nnz_balanced"]["ms_per_step"] > 0, j["legs_failed"]
+    assert kkt["nnz_balanced"]["exchange"] == "p2p"
+    assert j["legs_failed"] == [] and "partition_kkt" in j["legs_s"]
     # every line of a run with an exchange is printed twice: provisional
     # right after the main measurement, final at the end
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
