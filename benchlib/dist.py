@@ -1050,12 +1050,13 @@ class PartitionedRun:
         def build():  # LOCAL work inside the collective half: agreed on
             if kernel == S.CSR_KERNEL_PANELS and dA.panels_info() is None:
                 dA.build_panels(0)
+            force = job.args.force_exchange  # 1-rank RCCL rehearsal
             if self.ragged:
                 return D.ShardedSpmv(dA, kernel, rank, world, None, self.x,
                                      self.y, chunks=1, mode=self.xchg,
-                                     starts=st)
+                                     starts=st, force_exchange=force)
             return D.ShardedSpmv(dA, kernel, rank, world, st[1], self.x,
-                                 self.y, chunks=1)
+                                 self.y, chunks=1, force_exchange=force)
 
         if kernel is None:
             kernel = self.tuned
