@@ -48,6 +48,13 @@ Partitions
 `compute` is pluggable so that the partition + exchange logic is testable on
 CPU with the gloo backend (tests/test_dist_gloo.py); the product binds it to
 the HIP launch.
+
+Import order: a process that exchanges (world > 1) needs torch.distributed,
+and torch must be imported BEFORE spmv_scpa_amd -- the binding then shares the
+ROCm runtime torch's wheel has mapped instead of binding the system's (one
+runtime per process; spmv_scpa_amd/__init__.py, INTEGRATION.md "Contracts").
+With one rank and no exchange, `backend=` takes any module with torch's
+`cuda.current_stream()` (benchlib.devshim) and torch is not needed at all.
 """
 import numpy as np
 
