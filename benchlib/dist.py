@@ -1009,9 +1009,13 @@ class PartitionedRun:
     (slice, upload, x, y, the selector); run(steps) holds the collectives ->
     dict with per-rank rows / entries / kernel ms, ms_per_step, exchange."""
 
-    def __init__(self, job, A, partition, xchg, kernel=None):
+    def __init__(self, job, A, partition, xchg, kernel=None, layout=None):
+        """layout: (schedule, tile rows) of the blocked copy to build when
+        `kernel` is the blocked path and was picked elsewhere (the nnz run
+        repeats the even run's pick: same kernel AND same layout)"""
         S, D = job.S, job.D
         self.job, self.A, self.xchg, self.kernel = job, A, xchg, kernel
+        self.layout = layout
         self.M, self.N = A.contents.M, A.contents.N
         self.IRP, _, _ = S.csr_arrays(A)
         self.starts = (D.nnz_row_partition(self.IRP, job.world)
@@ -1049,7 +1053,10 @@ class PartitionedRun:
 
         def build():  # LOCAL work inside the collective half: agreed on
             if kernel == S.CSR_KERNEL_PANELS and dA.panels_info() is None:
-                dA.build_panels(0)
+                if self.layout and self.layout[0]:
+                    dA.build_panels(0, self.layout[0], self.layout[1])
+                else:
+                    dA.build_panels(0)
             force = job.args.force_exchange  # 1-rank RCCL rehearsal
             if self.ragged:
                 return D.ShardedSpmv(dA, kernel, rank, world, None, self.x,
@@ -1074,6 +1081,8 @@ class PartitionedRun:
                     else (lambda: None))
         self.kernel = kernel
         sh = together(job, build)
+        if kernel == S.CSR_KERNEL_PANELS:  # what a later run repeats
+            self.layout = (dA.panels_schedule(), dA.panels_tile_rows() or 0)
         yy = sh.y
         sh.step()
         job.sync()
@@ -1186,7 +1195,7 @@ class KktLeg:
         r_even = even.run(5)
         even.release()
         nnz = PartitionedRun(job, A, "nnz", job.args.ragged_exchange,
-                             even.kernel)
+                             even.kernel, even.layout)
         self.runs.append(nnz)
         together(job, nnz.prepare)
         r_nnz = nnz.run(5)
