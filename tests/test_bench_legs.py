@@ -122,7 +122,7 @@ def test_a_rank_that_dies_inside_a_leg_breaks_the_group_not_the_line():
 
 def test_the_whole_run_has_a_deadline_too():
     outs = _finish(_start("healthy", SPMV_BENCH_INJECT="third:0:hang",
-                          LEGS_LIMIT="8", LEGS_DEADLINE="6"))
+                          LEGS_LIMIT="60", LEGS_DEADLINE="12"))
     assert [rc for rc, _, _ in outs] == [0, 0], outs
     last = _lines(outs[0][1])[-1]
     assert any("deadline" in f or "limit" in f for f in last["legs_failed"])
