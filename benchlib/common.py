@@ -195,6 +195,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-partition-leg", action="store_true",
                     help="N>1: skip config.partition_kkt (the nlpkkt160-"
                          "shaped matrix over the ranks, even vs nnz-balanced)")
+    ap.add_argument("--no-family-leg", action="store_true",
+                    help="N>1: skip config.family_variants (the banded and "
+                         "the W = 2^20 members of the family through the same "
+                         "plain path at this N)")
     ap.add_argument("--no-native-leg", action="store_true",
                     help="N>1: skip `native` (the library's own multi-GPU "
                          "path in a child process after the ranks are done)")

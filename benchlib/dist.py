@@ -175,21 +175,24 @@ class RankJob:
                               self.stream())
         self.sync()
 
-    def build_shards(self, count, rows, first_row=None, ncols=None, w=None):
+    def build_shards(self, count, rows, first_row=None, ncols=None, w=None,
+                     kind=None, col_major=None):
         """`count` logical shards of `rows` rows starting at `first_row`
         -> (handles, true entries, stored slots)"""
         a, S = self.args, self.S
         first_row = self.row0 if first_row is None else first_row
         ncols = self.Nglob if ncols is None else ncols
         w = self.W if w is None else w
+        kind = self.kind if kind is None else kind
         out, nnz, stored = [], 0, 0
         for j in range(count):
-            dA = S.CsrDevice.generate(self.kind, rows, ncols, self.K, w,
+            dA = S.CsrDevice.generate(kind, rows, ncols, self.K, w,
                                       first_row + j * rows, MATRIX_SEED)
             nnz += dA.NZ
             if a.format == "hll":
-                col_major = True if a.kernel in (-1, 4) else \
-                    S.HLL_KERNEL_COL_MAJOR[a.kernel]
+                if col_major is None:
+                    col_major = True if a.kernel in (-1, 4) else \
+                        S.HLL_KERNEL_COL_MAJOR[a.kernel]
                 m = dA.to_hll(col_major)
                 stored += m.slots
                 dA.release()
@@ -693,6 +696,7 @@ def run_rank(args, argv, omp_team):
             "halo_rows": job.halo or None,
             "rows_per_s": round(job.Mglob / (ms_per_step * 1e-3), 1),
             "strong": None,
+            "family_variants": None,
             "partition_kkt": None,
             "rocm": S.rocm_runtime_report(),
         },
@@ -733,6 +737,11 @@ def run_rank(args, argv, omp_team):
                    and a.window <= 0 and not job.ragged)
     if want_strong:
         plan.append("strong")
+    want_family = (job.use_dist and not a.no_family_leg and not job.ragged
+                   and not a.strong and L == 1 and not job.halo
+                   and a.family == "random" and a.window <= 0)
+    if want_family:
+        plan.append("family_variants")
     if job.use_dist and not a.no_partition_leg:
         plan.append("partition_kkt")
     # the library's OWN multi-GPU path (mgpu.hip), in a child process once
@@ -838,6 +847,12 @@ def run_rank(args, argv, omp_team):
         st = StrongLeg(job)
         note("strong", legs.run("strong", st.run, prepare=[st.build],
                                 cleanup=lambda *_: st.release()))
+    # ---- N > 1: the banded and the W = 2^20 members of the family at this N
+    if want_family:
+        fv = FamilyVariantLeg(job)
+        note("family_variants", legs.run(
+            "family_variants", fv.run, prepare=[fv.build],
+            cleanup=lambda *_: fv.release()))
     # ---- N > 1: the nlpkkt160-shaped matrix over the same ranks, even rows
     # vs nnz-balanced rows (reference csr.c:218-276)
     if "partition_kkt" in plan:
@@ -1000,6 +1015,106 @@ class StrongLeg:
         for m in self.ms_:
             m.release()
         self.ms_, self.sh, self.xs, self.ys = [], None, None, None
+
+
+class FamilyVariantLeg:
+    """N > 1: the OTHER members of the synthetic family through the same plain
+    path at this N (north star: "GFLOP/s and achieved HBM GB/s on synthetic
+    banded/random sparse matrices reported at 1/2/4/8 GPUs"; at N = 1 they
+    ride on the line as roofline.variants): the banded matrix and the random
+    one with columns within 2^20 of the diagonal, same rows per GPU and
+    entries per row as the line's workload, autotuned (rank 0's pick for
+    all), rows of y checked against the host generator, 5 timed steps of
+    kernel + ONE all-gather.  With locality the kernel time does not grow
+    with N, so these are the members whose weak scaling the exchange bounds,
+    not the 80M columns.  build() is local, run() holds the collectives."""
+
+    VARIANTS = (("banded", "banded", 0), ("W=2^20", "random", 1 << 20))
+
+    def __init__(self, job):
+        self.job, self.built = job, []
+
+    def build(self):
+        job, S = self.job, self.job.S
+        for tag, fam, window in self.VARIANTS:
+            kind = FAMILIES[fam]
+            W = window if window > 0 else 2 * job.Nglob
+            ms_, nnz, slots = job.build_shards(1, job.Mshard, w=W, kind=kind,
+                                               col_major=True)
+            m = ms_[0]
+            self.built.append([tag, fam, kind, W, m, nnz, None])
+            best, _ = m.autotune(job.x.data_ptr(),
+                                 job.y.data_ptr() + 8 * job.row0)
+            self.built[-1][6] = best
+        return None
+
+    def run(self, _=None):
+        job, S, D, torch, np = (self.job, self.job.S, self.job.D,
+                                self.job.torch, self.job.np)
+        out = {}
+        for tag, fam, kind, W, m, nnz, best in self.built:
+            mine = D.Pick(best, m.panels_schedule(), m.panels_tile_rows() or 0)
+            pick = D.agree_on_pick(job.dist, mine, job.dev)
+            kernel = pick.kernel
+            labels = S.HLL_KERNEL_LABELS if job.args.format == "hll" \
+                else S.CSR_KERNEL_LABELS
+            blocked = labels[kernel] == "tile_panels"
+            rebuild = blocked and (m.panels_info() is None
+                                   or not pick.same_build(mine))
+            together(job, (lambda: m.build_panels(
+                0, pick.schedule, pick.tile_rows)) if rebuild
+                else (lambda: None))
+            sh = together(job, lambda: D.ShardedSpmv(
+                m, kernel, job.rank, job.world, job.Mshard, job.x, job.y,
+                chunks=1, force_exchange=job.args.force_exchange,
+                backend=torch))
+            sh.step()
+            job.sync()
+
+            def check():  # own rows + a row of every other rank's range
+                rng = np.random.default_rng(4321 + job.rank)
+                rows = np.concatenate(
+                    [rng.integers(0, job.Mloc, 32) + job.row0,
+                     [job.starts[r] for r in range(job.world)]])
+                got = job.y[torch.as_tensor(rows, device=job.dev)].cpu().numpy()
+                try:
+                    return check_rows(S, kind, job.Nglob, job.K, W, got, rows)
+                except SystemExit as e:
+                    raise RuntimeError(str(e))
+            checked = together(job, check)
+            ev = [(torch.cuda.Event(enable_timing=True),
+                   torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            job.barrier()
+            t0 = time.perf_counter()
+            for k in range(5):
+                sh.step(events=ev[k])
+            job.barrier()
+            ms = job.max_over_ranks(time.perf_counter() - t0) * 1e3 / 5
+            kms = job.max_over_ranks(
+                float(np.mean([a.elapsed_time(b) for a, b in ev])))
+            t = torch.tensor([float(nnz)], dtype=torch.float64, device=job.dev)
+            job.dist.all_reduce(t)
+            nnz_glob = int(t.item())
+            b = m.kernel_bytes(kernel)
+            out[tag] = {
+                "workload": workload_name(fam, job.args.format, job.Mshard,
+                                          job.Nglob, job.Mglob, job.K,
+                                          0 if W >= 2 * job.Nglob else W, W),
+                "kernel": ("hll_" if job.args.format == "hll" else "csr_")
+                + labels[kernel],
+                "layout": m.panels_describe() if blocked else None,
+                "ms_per_step": round(ms, 5),
+                "value_gflops": round(2.0 * nnz_glob / (ms * 1e6), 2),
+                "kernel_ms_max_rank": round(kms, 5),
+                "kernel_frac_of_8TBps": round(b / (kms * 1e6) / 8000.0, 4),
+                "rows_per_s": round(job.Mglob / (ms * 1e-3), 1),
+                "rows_checked": checked}
+        return out
+
+    def release(self):
+        for item in self.built:
+            item[4].release()
+        self.built = []
 
 
 # ------------------------------------------------- a host matrix over N ranks

@@ -120,6 +120,13 @@ def test_two_ranks_share_one_gpu(extra):
         assert c["nnz_global"] == 2 * 320000 * 32
     if extra[:2] == ["--kernel", "4"]:
         assert arr["alternative_kind"] == "sweep_split"
+        # the banded and the W = 2^20 members of the family at this N
+        fam = c["family_variants"]
+        assert sorted(fam) == ["W=2^20", "banded"], fam
+        for v in fam.values():
+            assert v["value_gflops"] > 0 and v["rows_checked"] >= 34
+            assert 0 < v["kernel_ms_max_rank"] <= v["ms_per_step"] * 1.05
+        assert "banded" in fam["banded"]["workload"]
         st = c["strong"]
         assert "error" not in st, st
         assert st["ms_per_step"] > 0
@@ -129,6 +136,7 @@ def test_two_ranks_share_one_gpu(extra):
         assert "4 logical shards" in st["problem"]
     else:
         assert arr["alternative_kind"] in ("row_chunks", "logical_shards")
+        assert c["family_variants"] is None  # only beside the W = N line
 
 
 def test_four_ranks_share_one_gpu():
