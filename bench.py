@@ -28,6 +28,7 @@ arrangement: each rank's kernel, then one exchange of y) -- complete, flagged
 the optional legs added: `config.exchange_ms_alone` + `exchange_alternatives_ms`,
 `config.arrangements` (the overlapped arrangement timed beside the plain one;
 `value_best` when it wins), `config.strong` (the fixed 80M x 80M problem),
+`config.family_variants` (the banded and W = 2^20 members of the family at this N),
 `config.partition_kkt` (even vs nnz-balanced rows on the nlpkkt160-shaped
 matrix), `native` (the library's own multi-GPU path, from a fresh child once
 the ranks have released the devices); at N = 1 `roofline.variants`,
