@@ -270,8 +270,8 @@ class LegRunner:
                     if k == 0:
                         injected(name, self.rank, "prepare")
                     built.append(step(*built))
-                except Exception as e:  # noqa: BLE001 - an optional figure
-                    err = e
+                except (Exception, SystemExit) as e:  # noqa: BLE001 - an
+                    err = e                           # optional figure
                 bad = self._agree(name, err) if collective else \
                     ([self.rank] if err is not None else [])
                 if bad is None:
@@ -287,8 +287,8 @@ class LegRunner:
             try:
                 injected(name, self.rank, "run")
                 result = run(*built)
-            except Exception as e:  # noqa: BLE001
-                err = e
+            except (Exception, SystemExit) as e:  # noqa: BLE001 (a leg's
+                err = e                 # own parity check may SystemExit)
             bad = self._agree(name, err) if collective else \
                 ([self.rank] if err is not None else [])
             if bad is None:
