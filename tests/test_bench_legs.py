@@ -162,3 +162,18 @@ def test_a_run_stuck_before_its_line_exists_says_where_and_exits_3():
     assert rec["failed_in"].startswith("first step + result check")
     assert rec["phases_s"]["setup"] >= 0.4 and rec["metric"] == "toy"
     assert _lines(outs[1][1]) == []
+
+
+def test_eight_ranks_agree_on_a_local_failure_of_one():
+    """the world size of the driver's largest run: rank 5 alone fails in the
+    local half of a leg; all eight skip it, the next leg runs on all eight"""
+    outs = _finish(_start("healthy", world=8,
+                          SPMV_BENCH_INJECT="second:5:prepare"), timeout=240)
+    assert [rc for rc, _, _ in outs] == [0] * 8, [o[0] for o in outs]
+    last = _lines(outs[0][1])[-1]
+    assert last["config"]["first"] == {"tag": "first", "sum": 36.0}
+    assert last["config"]["second"] is None
+    assert last["config"]["third"] == {"tag": "third", "sum": 36.0}
+    assert len(last["legs_failed"]) == 1
+    assert "rank(s) [5]" in last["legs_failed"][0]
+    assert all(_lines(o[1]) == [] for o in outs[1:])  # rank 0 alone prints
