@@ -29,7 +29,9 @@ def main():
            "size (10M rows per rank, columns anywhere) and how long the legs "
            "take on the driver's clock.",
            "At most 6 processes may touch the card on a test box, so 4 ranks "
-           "is the largest full rehearsal;",
+           "is the largest full rehearsal (a 6-rank",
+           "torchrun attempt was ended by the box's process guard: 7 "
+           "processes had the GPU open);",
            "the 8-rank control flow is covered by the gloo tests on CPU "
            "(tests/test_dist_gloo.py, world 8) and",
            "by 8 logical devices in one process (tests/test_gpu_mgpu.py, "
