@@ -167,6 +167,8 @@ def native_mgpu_bench(args, argv, omp_team):
     if pending:
         print(json.dumps(dict(out, provisional=True, legs_pending=pending)),
               flush=True)
+        if os.environ.get("SPMV_BENCH_NATIVE_HANG_AFTER_LINE"):
+            time.sleep(3600)  # tests: a child that never finishes its legs
     if multi:
         t0 = time.time()
         try:

@@ -699,3 +699,26 @@ def test_kkt_family_nnz_partition_on_8_logical_devices_vs_the_oracle():
         got = g.get_y(r)[picks]
         assert np.max(np.abs(got - want) / np.maximum(scale, 1e-300)) <= 1e-12, r
     g.destroy()
+
+
+def test_native_leg_keeps_the_childs_provisional_line_when_it_runs_out_of_time():
+    """the `native` leg of an N > 1 line is a child process with a timeout cut
+    from the run's remaining budget: a child that has printed its (plain
+    arrangement) line and then never finishes its own optional legs still
+    delivers that line -- flagged provisional, with the timeout it hit"""
+    import sys
+    sys.path.insert(0, S.ROOT)
+    import bench
+    from benchlib.native import native_leg
+    args = bench.parse_args(["--gpus", "2", "--backend", "gloo", "--steps", "2",
+                             "--warmup", "1", "--rows-per-gpu", "320000",
+                             "--kernel", "4", "--window", "0"])
+    os.environ["SPMV_BENCH_NATIVE_HANG_AFTER_LINE"] = "1"
+    try:
+        nat = native_leg(args, 2, timeout_s=45)
+    finally:
+        del os.environ["SPMV_BENCH_NATIVE_HANG_AFTER_LINE"]
+    assert nat["provisional"] is True and nat["timed_out_after_s"] == 45
+    assert nat["ms_per_step"] > 0 and nat["value"] > 0
+    assert nat["backend"].startswith("native REHEARSAL")
+    assert len(nat["kernel_ms_per_rank"]) == 2 and nat["rows_checked"] >= 2 * 258
