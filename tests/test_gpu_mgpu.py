@@ -715,10 +715,10 @@ def test_native_leg_keeps_the_childs_provisional_line_when_it_runs_out_of_time()
                              "--kernel", "4", "--window", "0"])
     os.environ["SPMV_BENCH_NATIVE_HANG_AFTER_LINE"] = "1"
     try:
-        nat = native_leg(args, 2, timeout_s=45)
+        nat = native_leg(args, 2, timeout_s=30)
     finally:
         del os.environ["SPMV_BENCH_NATIVE_HANG_AFTER_LINE"]
-    assert nat["provisional"] is True and nat["timed_out_after_s"] == 45
+    assert nat["provisional"] is True and nat["timed_out_after_s"] == 30
     assert nat["ms_per_step"] > 0 and nat["value"] > 0
     assert nat["backend"].startswith("native REHEARSAL")
     assert len(nat["kernel_ms_per_rank"]) == 2 and nat["rows_checked"] >= 2 * 258
