@@ -196,7 +196,7 @@ typedef struct spmv_panel_opts {
                              DEFAULT: on for sweep layouts, where it is free
                              (+-2 %: the hand-offs hide under the
                              request-bound loop), off for chain / steps
-                             (+9..+31 % there, DESIGN.md: opt-in with 1).
+                             (+3..+10 % there, DESIGN.md: opt-in with 1).
                              spmv_*_autotune builds its candidates with the
                              default, so the blocked copy it keeps on a matrix
                              whose columns reach anywhere is reproducible */

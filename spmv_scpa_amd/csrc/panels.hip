@@ -1048,7 +1048,7 @@ static int panels_build(int M, int N, int64_t slots, const spmv_panel_opts *o,
     P->bucket_order = o->bucket_order;
     /* 0 = default: ordered additions on sweep layouts (free there: the
      * hand-offs hide under the request-bound loop, +-2 %), arrival order on
-     * chain / steps (+9..+31 % there); 1 = always, 2 = never */
+     * chain / steps (+3..+10 % there); 1 = always, 2 = never */
     P->det = o->deterministic == 1 || (o->deterministic == 0 && sweep);
     P->order = sweep ? 0 : o->tile_order;
     /* bucket ids: tile-major, or panel-major inside rounds of P->grid tiles */
@@ -1406,6 +1406,17 @@ __device__ __forceinline__ void det_wait(int *turn, int want) {
     }
 }
 
+/* Ordered mode: a wavefront takes its turn only with its products IN HAND --
+ * the gathers of x it is waiting for must not be waited for inside the turn,
+ * where the seven other wavefronts of the workgroup queue behind it.  The
+ * empty asm makes every product a value the compiler has to have computed
+ * (hence its s_waitcnt for the gather passed) before the turn counter is
+ * polled; the stream loads of the chunk after next, issued later, stay in
+ * flight (the vector-memory queue returns in order). */
+__device__ __forceinline__ void det_have(double v) {
+    asm volatile("" ::"v"(v));
+}
+
 __device__ __forceinline__ void det_pass(int *turn, int next) {
     __hip_atomic_store(turn, next, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1572,6 +1583,10 @@ __global__ void __launch_bounds__(NT)
                                                  __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
             fill(f);
+            /* (sweep: the turn is taken BEFORE the gathers are waited for --
+             * with products in hand first, as the chain / steps kernels do,
+             * this request-bound loop measured 1.47 instead of 1.43-1.45 ms:
+             * here the wait for the turn hides under the gathers' latency) */
             if (DET)
                 det_wait(&det_turn, det_seq);
 #pragma unroll
@@ -1716,14 +1731,24 @@ __global__ void __launch_bounds__(NT)
             w[g][3] = c.vb[g][1];
         }
         fill(f, knext); /* past the bucket: slack slots, masked by `live` */
-        if (DET)
+        if (DET) {
+#pragma unroll
+            for (int g = 0; g < Q; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pr[g][u] *= w[g][u];
+                    w[g][u] = 1.0;
+                    det_have(pr[g][u]);
+                }
             det_wait(&det_turn, det_seq);
+        }
 #pragma unroll
         for (int g = 0; g < Q; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (64 * u < on[g])
-                    unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
+                    unsafeAtomicAdd(&ytile[rr[g][u]],
+                                    DET ? pr[g][u] : pr[g][u] * w[g][u]);
         if (DET) {
             det_pass(&det_turn, det_seq + 1);
             det_seq += WAVES;
@@ -1865,14 +1890,24 @@ __global__ void __launch_bounds__(NT)
             w[g][3] = c.vb[g][1];
         }
         fill(f);
-        if (DET)
+        if (DET) {
+#pragma unroll
+            for (int g = 0; g < Q; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pr[g][u] *= w[g][u];
+                    w[g][u] = 1.0;
+                    det_have(pr[g][u]);
+                }
             det_wait(&det_turn, det_seq);
+        }
 #pragma unroll
         for (int g = 0; g < Q; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (64 * u < on[g])
-                    unsafeAtomicAdd(&ytile[rr[g][u]], pr[g][u] * w[g][u]);
+                    unsafeAtomicAdd(&ytile[rr[g][u]],
+                                    DET ? pr[g][u] : pr[g][u] * w[g][u]);
         if (DET) {
             det_pass(&det_turn, det_seq + 1);
             det_seq += WAVES;
