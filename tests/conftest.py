@@ -13,6 +13,18 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config._summary_lines = []  # tests append; printed after the run
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """lines a test wants in the log of a quiet (`-q`, captured) run: the perf
+    floors print measured vs floor here, so the driver's log shows the margin
+    whether or not a floor failed (VERDICT r05 next #7)"""
+    lines = getattr(config, "_summary_lines", [])
+    if lines:
+        terminalreporter.section("measured vs floor (tests/test_gpu_perf_floor.py)")
+        for line in lines:
+            terminalreporter.write_line(line)
 
 
 def _ensure_built():
