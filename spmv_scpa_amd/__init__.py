@@ -142,7 +142,9 @@ class _NoTorchAfterTheSystemRuntime:
     """meta-path guard installed when the library is bound to /opt/rocm's
     runtime and PyTorch bundles its own: `import torch` now would map a second
     HIP / HSA / RCCL runtime into the process (two owners of one device
-    state).  Refused, loudly, with the two ways out.  Only the IMPORT is
+    state: measured on an MI355X with this guard lifted, torch's copy then
+    answers "No HIP GPUs are available" once this library has the device).
+    Refused, loudly, with the two ways out.  Only the IMPORT is
     refused: importlib.util.find_spec("torch") still answers (the real spec,
     with a loader that raises)."""
 
