@@ -171,6 +171,17 @@ class _NoTorchAfterTheSystemRuntime:
         return spec
 
 
+def allow_torch_import():
+    """lift the guard: for a process that only BUILT or inspected the library
+    (no device work through it) and goes on to import torch for its own
+    purposes -- __graft_entry__.build() calls this.  A process that has used
+    the GPU through this library must not: torch's runtime copy would find
+    the device taken."""
+    import sys
+    sys.meta_path[:] = [f for f in sys.meta_path
+                        if not isinstance(f, _NoTorchAfterTheSystemRuntime)]
+
+
 def _guard_against_a_second_runtime():
     import sys
     if ROCM_RUNTIME_BOUND != "system":
