@@ -201,3 +201,20 @@ def test_a_bundled_runtime_with_another_soname_is_not_preloaded(tmp_path):
     assert "SHARED None" in r.stdout, r.stdout
     assert "SONAME" in r.stdout and "libamdhip64.so.6" not in r.stdout.split(
         "MAPS")[1], r.stdout
+
+
+@needs_torch
+def test_a_build_check_may_import_torch_afterwards():
+    """__graft_entry__.build() imports the package to check its symbols and
+    does no device work: it lifts the guard (spmv_scpa_amd.allow_torch_import)
+    so that whoever called it can still import torch in that process"""
+    code = ("import sys\nsys.path.insert(0, %r)\n"
+            "import spmv_scpa_amd as S\n"
+            "assert S.ROCM_TORCH_IMPORT_GUARDED and S.ROCM_RUNTIME_BOUND == 'system'\n"
+            "S.allow_torch_import()\nimport torch\nprint('TORCH', torch.__version__)\n"
+            % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "TORCH " in r.stdout, r.stderr[-2000:]
+    for word in ("double free", "corruption", "Aborted", "core dumped"):
+        assert word not in r.stderr, r.stderr[-2000:]
